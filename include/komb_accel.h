@@ -1,0 +1,150 @@
+/*
+ * komb_accel.h -- C ABI of the MI355X-native k-core / k-truss / CoreA path.
+ *
+ * This is the drop-in boundary for KOMB's decomposition hot path: each entry
+ * point replaces the igraph / CoreA call group named beside it (paths are
+ * relative to the KOMB reference tree).  Plain pointers and sizes only; the
+ * caller allocates every output; the library never frees caller memory; all
+ * device state lives behind the opaque komb_ctx.  Every function returns
+ * KOMB_OK (0) or a negative komb_status; komb_last_error() gives the text.
+ * There is no CPU fallback: without a usable gfx950 device every compute
+ * entry point fails with KOMB_ERR_DEVICE.
+ *
+ * Edge identity across the boundary is the canonical pair (min(u,v),max(u,v))
+ * in lexicographic order -- igraph's internal edge ids are not observable in
+ * any KOMB output (src/graph.cpp:519-534 only maps edges back to vertices).
+ *
+ * Threading: call from one host thread per context (the reference reaches this
+ * seam from its main thread, src/graph.cpp:449 and src/komb2.cpp:132).
+ */
+#ifndef KOMB_ACCEL_H
+#define KOMB_ACCEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KOMB_ACCEL_ABI_VERSION 1
+
+typedef enum komb_status {
+    KOMB_OK          =  0,
+    KOMB_ERR_ARG     = -1,   /* bad argument / graph not loaded / out-of-range id   */
+    KOMB_ERR_DEVICE  = -2,   /* no HIP device, or a HIP call failed                 */
+    KOMB_ERR_NOMEM   = -3,   /* host or device allocation failed                    */
+    KOMB_ERR_LIMIT   = -4,   /* graph exceeds the 32-bit slot/edge-id design limits */
+    KOMB_ERR_STATE   = -5    /* call order violated (e.g. fetch before run)         */
+} komb_status;
+
+typedef struct komb_ctx komb_ctx;
+
+typedef struct komb_opts {
+    int32_t device;        /* HIP device ordinal (LOCAL_RANK for one process per GPU) */
+    int32_t verbosity;     /* 0 silent, 1 progress on stderr                          */
+    int32_t rank;          /* edge-partition rank  (0 for a single GPU)               */
+    int32_t world;         /* edge-partition count (1 for a single GPU)               */
+} komb_opts;
+
+typedef struct komb_stats {
+    int64_t nv, ne;                 /* simple graph: vertices, undirected edges      */
+    int64_t triangles;              /* T (sum of supports / 3), after komb_truss_run */
+    int64_t sum_deg_sq;             /* sum_v d(v)^2 = sum_{(u,v) in E} d(u)+d(v)      */
+    int64_t wedge_items;            /* sum_{(u,v) in E} min(d(u),d(v))                */
+    int32_t max_degree, max_coreness, max_trussness;
+    int32_t core_levels, core_launches;     /* populated levels; launches issued      */
+    int32_t truss_levels, truss_subrounds;  /* populated levels; PROCESS sub-rounds   */
+    int32_t truss_scans, truss_launches;    /* SCAN launches; launches issued         */
+    /* HIP-event times (ms), each measured on the stream the kernels run on */
+    double  ms_build;               /* a1: edge list -> simple CSR                    */
+    double  ms_core;                /* a2+a3: degree + k-core peel launches           */
+    double  ms_orient;              /* truss: degree order + oriented CSR             */
+    double  ms_tri_count;           /* truss: triangle enumeration, support counting  */
+    double  ms_tri_fill;            /* truss: triangle enumeration, incidence fill    */
+    double  ms_support;             /* = ms_tri_count + ms_tri_fill                   */
+    double  ms_peel;                /* truss: all peel launches (SCAN + PROCESS)      */
+    double  ms_gather;              /* truss: canonical-order result gather           */
+    double  ms_corea;               /* a9/a10: CoreA rank kernels                     */
+} komb_stats;
+
+/* ---- lifetime ---------------------------------------------------------- */
+komb_ctx   *komb_create(const komb_opts *opts);      /* NULL only on host OOM      */
+void        komb_destroy(komb_ctx *ctx);
+const char *komb_last_error(const komb_ctx *ctx);    /* "" when no error           */
+int         komb_abi_version(void);
+
+/* ---- graph construction ------------------------------------------------ */
+/* Replaces igraph_create + igraph_simplify(multiple=true, loops=true)
+ * (src/graph.cpp:418, src/graph.cpp:438): n_raw (u,v) pairs exactly as
+ * generateGraph leaves them in `edges` (src/graph.cpp:379-389), vertex ids in
+ * [0,nv).  Removes loops and parallel edges on the device and keeps the
+ * symmetric CSR (rows ascending) resident in HBM. */
+int komb_graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw,
+                          const int64_t *uv_pairs);
+
+/* Same, from an already simple, symmetric, row-sorted CSR (host pointers). */
+int komb_graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr,
+                        const int32_t *col);
+
+/* igraph_vcount / igraph_ecount (src/graph.cpp:443-444). */
+int komb_graph_info(komb_ctx *ctx, int64_t *nv, int64_t *ne);
+
+/* Copy the resident CSR back: rowptr[nv+1], col[2*ne]. */
+int komb_graph_get_csr(komb_ctx *ctx, int64_t *rowptr, int32_t *col);
+
+/* ---- k-core ------------------------------------------------------------ */
+/* Replaces igraph_degree(ALL,NO_LOOPS) + igraph_coreness(ALL)
+ * (src/graph.cpp:462-463).  komb_core_run computes on the device and leaves
+ * degree/coreness in HBM (this is the timed region of bench.py);
+ * komb_core_fetch copies them out; komb_degree_coreness = run + fetch. */
+int komb_core_run(komb_ctx *ctx);
+int komb_core_fetch(komb_ctx *ctx, int32_t *degree /*[nv]*/, int32_t *coreness /*[nv]*/);
+int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness);
+
+/* ---- k-truss ----------------------------------------------------------- */
+/* Replaces igraph_induced_subgraph_map + igraph_trussness
+ * (src/graph.cpp:502, src/graph.cpp:508).  vmask (host, nv bytes, nullable)
+ * selects the induced subgraph exactly like the max-core vertex list built at
+ * src/graph.cpp:470-473; NULL = whole graph.  Edges are reported with ORIGINAL
+ * vertex ids (what invmap gives at src/graph.cpp:531-532), canonical order.
+ * komb_truss_run computes on the device (timed region); komb_truss_fetch
+ * copies (eu,ev,truss)[ne_sub] out.  Trussness of a triangle-free edge is 2. */
+int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
+int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub);
+int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss);
+/* per-edge triangle counts the peel started from (canonical order) */
+int komb_truss_fetch_support(komb_ctx *ctx, int32_t *support);
+int komb_trussness(komb_ctx *ctx, const uint8_t *vmask, int64_t *ne_out,
+                   int32_t *eu, int32_t *ev, int32_t *truss);
+
+/* ---- CoreA ------------------------------------------------------------- */
+/* Replaces CoreA::getAnomalyScore + CoreA::fractionalRank x2
+ * (src/CoreA.h:109-140, 142-187): key = coreness*n + degree in 64-bit
+ * (src/CoreA.h:122 is `int`, undefined once it overflows); fractional ranks by
+ * device sort + run bounds; |ln r_deg - ln r_key| with the host libm so the
+ * "%f" text of CombineCoreA::run (src/CombineCoreA.h:36-39) is unchanged.
+ * degree/coreness are host arrays (what readKOMBOutput returns,
+ * src/CoreA.h:24-56). */
+int komb_corea_scores(komb_ctx *ctx, const int32_t *degree, const int32_t *coreness,
+                      int64_t nv, double *score);
+/* the two rank vectors themselves (exact half-integers), for tests */
+int komb_corea_ranks(komb_ctx *ctx, const int32_t *degree, const int32_t *coreness,
+                     int64_t nv, double *rank_degree, double *rank_key);
+
+/* ---- instrumentation --------------------------------------------------- */
+int komb_get_stats(komb_ctx *ctx, komb_stats *out);
+
+/* ---- synthetic workload (host code, no device) ------------------------- */
+/* Power-law "hybrid unitig graph" generator of SURVEY.md section 8(d): a union
+ * of n_cliques small cliques (size min(1+Geom(0.45),6)) whose members are drawn
+ * from w_i ~ (i+1)^(-1/(alpha-1)) and scattered by a seeded bijection; mirrors
+ * how generateGraph expands read cliques (src/graph.cpp:310-352).  Two-call
+ * pattern: uv_pairs==NULL returns the number of raw pairs; otherwise fills
+ * uv_pairs[2*n_raw] (must be the size the first call returned). */
+int64_t komb_gen_hug_edges(int64_t nv, int64_t n_cliques, double alpha,
+                           uint64_t seed, int64_t *uv_pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOMB_ACCEL_H */

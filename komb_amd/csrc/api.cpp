@@ -1,0 +1,201 @@
+// api.cpp -- the extern "C" surface declared in include/komb_accel.h.
+// Host-only glue: argument checks, device selection, copies in and out.  All
+// arithmetic of the path runs in the HIP kernels of the sibling .hip files;
+// there is no CPU fallback (a missing device is KOMB_ERR_DEVICE).
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace komb;
+
+namespace {
+
+int require_device(komb_ctx *ctx)
+{
+    if (!ctx) return KOMB_ERR_ARG;
+    if (!ctx->device_ok) {
+        if (ctx->err.empty()) ctx->err = "no usable HIP device";
+        return KOMB_ERR_DEVICE;
+    }
+    KOMB_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->err.clear();
+    return KOMB_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int komb_abi_version(void) { return KOMB_ACCEL_ABI_VERSION; }
+
+komb_ctx *komb_create(const komb_opts *opts)
+{
+    komb_ctx *ctx = new (std::nothrow) komb_ctx();
+    if (!ctx) return nullptr;
+    if (opts) ctx->opts = *opts;
+    if (ctx->opts.world <= 0) ctx->opts.world = 1;
+    ctx->device = ctx->opts.device;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        ctx->err = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        (void)hipGetLastError();
+        return ctx;
+    }
+    if (ctx->device < 0 || ctx->device >= ndev) {
+        ctx->err = "device ordinal out of range";
+        return ctx;
+    }
+    e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctrl, 2 * sizeof(PeelCtrl), hipHostMallocDefault);
+    if (e == hipSuccess && !ctx->timer.init()) e = hipErrorUnknown;
+    if (e != hipSuccess) {
+        ctx->err = std::string("device initialisation failed: ") + hipGetErrorString(e);
+        return ctx;
+    }
+    ctx->stream = nullptr;           // the device's default stream
+    ctx->device_ok = true;
+    return ctx;
+}
+
+void komb_destroy(komb_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->device_ok) {
+        (void)hipSetDevice(ctx->device);
+        graph_free(ctx);
+        ctx->timer.destroy();
+        if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
+    }
+    delete ctx;
+}
+
+const char *komb_last_error(const komb_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int komb_graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv_pairs)
+{
+    KOMB_TRY(require_device(ctx));
+    return graph_from_edges(ctx, nv, n_raw, uv_pairs);
+}
+
+int komb_graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col)
+{
+    KOMB_TRY(require_device(ctx));
+    return graph_from_csr(ctx, nv, rowptr, col);
+}
+
+int komb_graph_info(komb_ctx *ctx, int64_t *nv, int64_t *ne)
+{
+    if (!ctx) return KOMB_ERR_ARG;
+    if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_graph_info: no graph loaded");
+    if (nv) *nv = ctx->nv;
+    if (ne) *ne = ctx->ne;
+    return KOMB_OK;
+}
+
+int komb_graph_get_csr(komb_ctx *ctx, int64_t *rowptr, int32_t *col)
+{
+    KOMB_TRY(require_device(ctx));
+    if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_graph_get_csr: no graph loaded");
+    if (!rowptr || (ctx->ne > 0 && !col)) KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_graph_get_csr: null output");
+    std::vector<uint32_t> rp((size_t)ctx->nv + 1);
+    KOMB_HIP(ctx, hipMemcpy(rp.data(), ctx->d_rowptr, rp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < rp.size(); ++i) rowptr[i] = (int64_t)rp[i];
+    if (ctx->ne > 0)
+        KOMB_HIP(ctx, hipMemcpy(col, ctx->d_col, (size_t)(2 * ctx->ne) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return KOMB_OK;
+}
+
+int komb_core_run(komb_ctx *ctx)
+{
+    KOMB_TRY(require_device(ctx));
+    return core_run(ctx);
+}
+
+int komb_core_fetch(komb_ctx *ctx, int32_t *degree, int32_t *coreness)
+{
+    KOMB_TRY(require_device(ctx));
+    if (!ctx->core_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_core_fetch: komb_core_run has not completed");
+    if (ctx->nv == 0) return KOMB_OK;
+    if (degree) KOMB_HIP(ctx, hipMemcpy(degree, ctx->d_deg, (size_t)ctx->nv * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (coreness) KOMB_HIP(ctx, hipMemcpy(coreness, ctx->d_core, (size_t)ctx->nv * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return KOMB_OK;
+}
+
+int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness)
+{
+    KOMB_TRY(komb_core_run(ctx));
+    return komb_core_fetch(ctx, degree, coreness);
+}
+
+int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask)
+{
+    KOMB_TRY(require_device(ctx));
+    return truss_run(ctx, vmask);
+}
+
+int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub)
+{
+    if (!ctx) return KOMB_ERR_ARG;
+    if (!ctx->truss_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_count: komb_truss_run has not completed");
+    if (ne_sub) *ne_sub = ctx->t_ne;
+    return KOMB_OK;
+}
+
+int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss)
+{
+    KOMB_TRY(require_device(ctx));
+    if (!ctx->truss_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch: komb_truss_run has not completed");
+    const size_t bytes = (size_t)ctx->t_ne * sizeof(int32_t);
+    if (bytes == 0) return KOMB_OK;
+    if (eu) KOMB_HIP(ctx, hipMemcpy(eu, ctx->d_t_eu, bytes, hipMemcpyDeviceToHost));
+    if (ev) KOMB_HIP(ctx, hipMemcpy(ev, ctx->d_t_ev, bytes, hipMemcpyDeviceToHost));
+    if (truss) KOMB_HIP(ctx, hipMemcpy(truss, ctx->d_t_truss, bytes, hipMemcpyDeviceToHost));
+    return KOMB_OK;
+}
+
+int komb_truss_fetch_support(komb_ctx *ctx, int32_t *support)
+{
+    KOMB_TRY(require_device(ctx));
+    if (!ctx->truss_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch_support: komb_truss_run has not completed");
+    const size_t bytes = (size_t)ctx->t_ne * sizeof(int32_t);
+    if (bytes && support) KOMB_HIP(ctx, hipMemcpy(support, ctx->d_t_sup, bytes, hipMemcpyDeviceToHost));
+    return KOMB_OK;
+}
+
+int komb_trussness(komb_ctx *ctx, const uint8_t *vmask, int64_t *ne_out, int32_t *eu, int32_t *ev, int32_t *truss)
+{
+    KOMB_TRY(komb_truss_run(ctx, vmask));
+    if (ne_out) *ne_out = ctx->t_ne;
+    return komb_truss_fetch(ctx, eu, ev, truss);
+}
+
+int komb_corea_ranks(komb_ctx *ctx, const int32_t *degree, const int32_t *coreness, int64_t nv,
+                     double *rank_degree, double *rank_key)
+{
+    KOMB_TRY(require_device(ctx));
+    return corea_ranks(ctx, degree, coreness, nv, rank_degree, rank_key);
+}
+
+int komb_corea_scores(komb_ctx *ctx, const int32_t *degree, const int32_t *coreness, int64_t nv, double *score)
+{
+    KOMB_TRY(require_device(ctx));
+    if (nv < 0 || (nv > 0 && !score)) KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_corea_scores: bad arguments");
+    std::vector<double> rd((size_t)nv), rc((size_t)nv);
+    KOMB_TRY(corea_ranks(ctx, degree, coreness, nv, rd.data(), rc.data()));
+    // host libm on purpose: |ln r_deg - ln r_key| as src/CoreA.h:131, same "%f" text downstream
+    for (int64_t i = 0; i < nv; ++i) score[i] = std::fabs(std::log(rd[(size_t)i]) - std::log(rc[(size_t)i]));
+    return KOMB_OK;
+}
+
+int komb_get_stats(komb_ctx *ctx, komb_stats *out)
+{
+    if (!ctx || !out) return KOMB_ERR_ARG;
+    *out = ctx->stats;
+    return KOMB_OK;
+}
+
+} // extern "C"

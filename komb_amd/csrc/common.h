@@ -1,0 +1,172 @@
+// common.h -- shared host-side definitions of libkomb_accel (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "komb_accel.h"
+
+namespace komb {
+
+constexpr int kBlock = 256;                 // 4 wave64 per workgroup
+constexpr int kWave = 64;
+constexpr int32_t kAlive = 0x7FFFFFFF;      // stamp / core value of a live edge / vertex
+
+// Device-side control block of a peel loop.  One 128-byte record; the fields a
+// launch reads at entry are written only by the previous launch's last block.
+struct PeelCtrl {
+    // ---- stable during a launch (written by the finalising block only)
+    int32_t  mode;          // 0 = SCAN, 1 = PROCESS
+    int32_t  level;         // current peel level (degree k / support L)
+    int32_t  round;         // sub-round id stamped on the current frontier
+    int32_t  done;          // 1 once every unit is peeled
+    uint32_t cur_count;     // entries in the current frontier queue
+    int32_t  cur_sel;       // which of the two queues is current
+    uint32_t remaining;     // units not yet peeled
+    int32_t  n_levels;      // stats: populated levels
+    int32_t  n_rounds;      // stats: PROCESS launches that had work
+    int32_t  n_scans;       // stats: SCAN launches
+    int32_t  max_level;     // stats: highest populated level
+    int32_t  pad0;
+    // ---- modified with atomics during a launch
+    uint32_t tail[2];       // append cursors of the two queues
+    int32_t  next_min;      // min live key above the scanned level
+    uint32_t blocks_done;   // finalisation ticket
+    uint32_t acc;           // units peeled in this launch without passing through a queue
+    uint32_t pad1[15];
+};
+static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
+
+struct Timer {                               // HIP-event stopwatch on one stream
+    hipEvent_t a = nullptr, b = nullptr;
+    bool init() { return hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess; }
+    void start(hipStream_t s) { (void)hipEventRecord(a, s); }
+    double stop(hipStream_t s)
+    {
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, a, b);
+        return (double)ms;
+    }
+    void destroy() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); a = b = nullptr; }
+};
+
+} // namespace komb
+
+struct komb_ctx {
+    komb_opts opts{};
+    std::string err;
+    bool device_ok = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    komb::Timer timer;
+
+    // ---- resident simple graph (symmetric CSR, rows ascending)
+    int64_t nv = -1, ne = 0;
+    uint32_t *d_rowptr = nullptr;            // [nv+1]
+    int32_t  *d_col = nullptr;               // [2*ne]
+
+    // ---- k-core results
+    int32_t *d_deg = nullptr;                // [nv] degree (a2)
+    int32_t *d_core = nullptr;               // [nv] coreness (a3)
+    bool core_done = false;
+
+    // ---- k-truss results (internal edge id = oriented slot)
+    int64_t t_ne = -1;                       // edges of the (sub)graph last run
+    int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr; // canonical order
+    bool truss_done = false;
+
+    // ---- pinned host mirror of the control block (double buffered)
+    komb::PeelCtrl *h_ctrl = nullptr;        // [2]
+
+    komb_stats stats{};
+};
+
+// ---- error plumbing -------------------------------------------------------
+#define KOMB_FAIL(ctx, code, ...)                                   \
+    do {                                                            \
+        char _b[512];                                               \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                      \
+        (ctx)->err = _b;                                            \
+        return (code);                                              \
+    } while (0)
+
+#define KOMB_HIP(ctx, call)                                                          \
+    do {                                                                             \
+        hipError_t _e = (call);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            hipError_t _nomem = hipErrorOutOfMemory;                                 \
+            KOMB_FAIL(ctx, _e == _nomem ? KOMB_ERR_NOMEM : KOMB_ERR_DEVICE,          \
+                      "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),         \
+                      __FILE__, __LINE__);                                           \
+        }                                                                            \
+    } while (0)
+
+#define KOMB_TRY(expr)                         \
+    do {                                       \
+        int _s = (expr);                       \
+        if (_s != KOMB_OK) return _s;          \
+    } while (0)
+
+// ---- primitives implemented in prims.hip (rocPRIM/hipCUB behind plain signatures)
+namespace komb {
+int prim_sort_u64(komb_ctx *ctx, uint64_t *keys, uint64_t *tmp_keys, int64_t n, int end_bit, uint64_t **sorted);
+int prim_unique_u64(komb_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, int64_t *n_out);
+int prim_exclusive_sum_u32(komb_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t n);   // out[n-1] valid; in/out may alias
+int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, uint32_t *vals, uint32_t *vals_tmp,
+                             int64_t n, int end_bit, int64_t **sorted_keys, uint32_t **sorted_vals);
+
+// ---- stages (each in its own translation unit)
+int core_run(komb_ctx *ctx);
+int truss_run(komb_ctx *ctx, const uint8_t *vmask_host);
+int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t n, double *rank_deg, double *rank_key);
+int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv);
+int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);
+void graph_free(komb_ctx *ctx);
+void truss_free(komb_ctx *ctx);
+void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t units);
+
+// Issue `launch()` in batches until the device control block reports done.
+// The host never decides what a launch does: every launch reads the control
+// block its predecessor finalised (SCAN or PROCESS, or nothing once done), so
+// there is no host round trip per sub-round; the host only polls a copy of the
+// control block one batch behind the launches it keeps queued.
+template <typename F>
+int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *launches_out)
+{
+    constexpr int kBatch = 24;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const int64_t max_batches = (4 * units + 4096) / kBatch + 16;   // > 2 launches per unit: cannot be reached
+    int launches = 0, slot = 0, status = KOMB_OK;
+    bool have_prev = false, finished = false;
+    for (int64_t batch = 0; batch < max_batches && !finished; ++batch) {
+        for (int i = 0; i < kBatch; ++i) { launch(); ++launches; }
+        if (hipMemcpyAsync(&ctx->h_ctrl[slot], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipEventRecord(ev[slot], ctx->stream) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
+        if (have_prev) {
+            if (hipEventSynchronize(ev[slot ^ 1]) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
+            if (ctx->h_ctrl[slot ^ 1].done) finished = true;
+        }
+        have_prev = true;
+        slot ^= 1;
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (launches_out) *launches_out = launches;
+    if (status != KOMB_OK || e != hipSuccess)
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: HIP failure (%s)", hipGetErrorString(e));
+    if (hipMemcpy(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost) != hipSuccess)
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: control block readback failed");
+    if (!ctx->h_ctrl[0].done)
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: launch budget exhausted before completion (level %d, remaining %u)",
+                  ctx->h_ctrl[0].level, ctx->h_ctrl[0].remaining);
+    return KOMB_OK;
+}
+} // namespace komb

@@ -1,0 +1,489 @@
+// ktruss.hip -- rows a5 + a6 of the hot-path table: per-edge trussness of the
+// (optionally vertex-induced) simple graph, replacing
+// igraph_induced_subgraph_map + igraph_trussness (reference src/graph.cpp:502,
+// src/graph.cpp:508).  Trussness(e) = 2 + the support level at which e is
+// peeled; a triangle-free edge has trussness 2.
+//
+// MI355X-first design (no intersections inside the peel loop):
+//   1. orient every edge from the lower to the higher (degree,id) endpoint and
+//      build the oriented CSR (orow/ocol, rows still ascending by id).  The
+//      internal edge id is the oriented slot.  On power-law unitig graphs the
+//      oriented rows are tiny (max ~10^2), whatever the hub degrees are.
+//   2. enumerate every triangle once (edge a->b, merge N+(a) with N+(b)):
+//      pass 1 counts support with integer atomics; an exclusive scan of the
+//      supports gives each edge a slice of the incidence array; pass 2
+//      enumerates again and writes, for each of the triangle's three edges,
+//      the ids of the other two into its slice.  24 bytes per triangle -- the
+//      288 GB of HBM buy a peel that never touches the adjacency again.
+//   3. peel: level-synchronous sub-rounds driven by the device control block
+//      (peel_dev.h).  A frontier edge walks its incidence slice; a triangle
+//      whose other two edges are both still present loses one support on each
+//      (ties between two frontier edges are broken by edge id so every
+//      triangle is destroyed exactly once); the decrement that lands an edge
+//      exactly on the level enqueues it for the next sub-round.  Frontier
+//      slices are flattened across the wavefront (prefix sum in LDS) so hub
+//      edges with thousands of triangles do not serialise a lane.
+//   4. gather results into canonical (min,max)-lexicographic edge order with
+//      ORIGINAL vertex ids -- the identity the C ABI promises.
+#include "peel_dev.h"
+
+namespace komb {
+
+namespace {
+
+inline int grid_for(int64_t n, int per_block = kBlock, int cap = 256 * 16)
+{
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ row filters
+struct PredMask {                       // keep slot (a,b) when both endpoints are selected
+    const uint8_t *mask;
+    __device__ bool operator()(int32_t a, int32_t b) const { return mask[a] && mask[b]; }
+};
+struct PredOrient {                     // keep slot (a,b) when a precedes b in (degree,id) order
+    const int32_t *deg;
+    __device__ bool operator()(int32_t a, int32_t b) const
+    {
+        const int32_t da = deg[a], db = deg[b];
+        return da < db || (da == db && a < b);
+    }
+};
+struct PredUpper {                      // keep slot (a,b) when a < b: the canonical copy of the edge
+    __device__ bool operator()(int32_t a, int32_t b) const { return a < b; }
+};
+
+// One wavefront per row; ballot + prefix popcount keeps the row order.
+template <class Pred, bool FILL>
+__global__ __launch_bounds__(kBlock) void k_row_filter(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                       int64_t nv, Pred pred, uint32_t *__restrict__ out_count,
+                                                       const uint32_t *__restrict__ out_rowptr, int32_t *__restrict__ out_col,
+                                                       int32_t *__restrict__ out_src)
+{
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t v = wave; v < nv; v += nwaves) {
+        const uint32_t b = rowptr[v], e = rowptr[v + 1];
+        uint32_t cnt = 0;
+        const uint32_t obase = FILL ? out_rowptr[v] : 0u;
+        for (uint32_t j0 = b; j0 < e; j0 += kWave) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            int32_t c = 0;
+            bool keep = false;
+            if (j < e) { c = col[j]; keep = pred((int32_t)v, c); }
+            const uint64_t m = __ballot(keep);
+            if (FILL && keep) {
+                const uint32_t o = obase + cnt + (uint32_t)__popcll(m & lanemask_lt());
+                out_col[o] = c;
+                if (out_src) out_src[o] = (int32_t)v;
+            }
+            cnt += (uint32_t)__popcll(m);
+        }
+        if (!FILL && lane == 0) out_count[v] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ rowptr, int64_t nv, int32_t *__restrict__ deg)
+{
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock)
+        deg[v] = (int32_t)(rowptr[v + 1] - rowptr[v]);
+}
+
+// ------------------------------------------------------ triangle enumeration
+// One thread per oriented edge e = (a -> b): sorted merge of N+(a) and N+(b).
+// A common out-neighbour w at slots i (row a) and j (row b) is the triangle
+// {e, i, j} in internal edge ids.  FILL=false: count supports.  FILL=true:
+// write each edge's (other, other) pair at its cursor.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
+                                                      const int32_t *__restrict__ osrc, int64_t m,
+                                                      uint32_t *sup_or_cursor, int2 *__restrict__ inc)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
+        const int32_t a = osrc[e], b = ocol[e];
+        uint32_t i = orow[a], j = orow[b];
+        const uint32_t ie = orow[a + 1], je = orow[b + 1];
+        if (i == ie || j == je) continue;
+        uint32_t cnt = 0;
+        int32_t x = ocol[i], y = ocol[j];
+        for (;;) {
+            if (x == y) {
+                if (FILL) {
+                    const uint32_t pe = atomicAdd(&sup_or_cursor[e], 1u);
+                    const uint32_t pi = atomicAdd(&sup_or_cursor[i], 1u);
+                    const uint32_t pj = atomicAdd(&sup_or_cursor[j], 1u);
+                    inc[pe] = make_int2((int)i, (int)j);
+                    inc[pi] = make_int2((int)e, (int)j);
+                    inc[pj] = make_int2((int)e, (int)i);
+                } else {
+                    ++cnt;
+                    atomicAdd(&sup_or_cursor[i], 1u);
+                    atomicAdd(&sup_or_cursor[j], 1u);
+                }
+                ++i; ++j;
+                if (i == ie || j == je) break;
+                x = ocol[i]; y = ocol[j];
+            } else if (x < y) {
+                if (++i == ie) break;
+                x = ocol[i];
+            } else {
+                if (++j == je) break;
+                y = ocol[j];
+            }
+        }
+        if (!FILL && cnt) atomicAdd(&sup_or_cursor[e], cnt);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t *__restrict__ off,
+                                                      int32_t *__restrict__ sup, int32_t *__restrict__ stamp)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
+        sup[e] = (int32_t)(off[e + 1] - off[e]);
+        stamp[e] = kAlive;
+    }
+}
+
+// ------------------------------------------------------------------ peel step
+__global__ __launch_bounds__(kBlock) void k_truss_step(PeelCtrl *ctrl, const uint32_t *__restrict__ off,
+                                                       const int2 *__restrict__ inc, int32_t *sup, int32_t *stamp,
+                                                       int32_t *truss, int32_t *q0, int32_t *q1, int64_t m)
+{
+    __shared__ CtrlView sh_cv;
+    __shared__ uint32_t sh_end[kBlock / kWave][kWave];
+    __shared__ uint32_t sh_beg[kBlock / kWave][kWave];
+    __shared__ int32_t sh_edge[kBlock / kWave][kWave];
+    const CtrlView cv = load_ctrl(ctrl, &sh_cv);
+    if (cv.done) return;
+    const int L = cv.level, r = cv.round;
+    const int lane = lane_id();
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+
+    if (cv.mode == MODE_SCAN) {
+        int32_t *q = cv.cur_sel ? q1 : q0;
+        int32_t lmin = 0x7FFFFFFF;
+        for (int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) - lane; base < m; base += nthreads) {
+            const int64_t e = base + lane;
+            bool hit = false;
+            if (e < m && stamp[e] == kAlive) {
+                const int32_t s = sup[e];
+                if (s <= L) { hit = true; stamp[e] = r; truss[e] = L + 2; }
+                else lmin = min(lmin, s);
+            }
+            wave_append(hit, (int32_t)e, q, &ctrl->tail[cv.cur_sel]);
+        }
+        lmin = wave_min(lmin);
+        if (lane == 0 && lmin != 0x7FFFFFFF) atomicMin(&ctrl->next_min, lmin);
+    } else {
+        const int32_t *q = cv.cur_sel ? q1 : q0;
+        int32_t *qn = cv.cur_sel ? q0 : q1;
+        uint32_t *tail_n = &ctrl->tail[cv.cur_sel ^ 1];
+        const int w = (int)(threadIdx.x >> 6);
+        uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w];
+        int32_t *s_edge = sh_edge[w];
+        const int64_t cnt = (int64_t)cv.cur_count;
+        for (int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) - lane; base < cnt; base += nthreads) {
+            // 64 frontier edges per wave: inclusive prefix sum of their slice lengths
+            const int64_t idx = base + lane;
+            int32_t ef = -1;
+            uint32_t beg = 0, len = 0;
+            if (idx < cnt) { ef = q[idx]; beg = off[ef]; len = off[ef + 1] - beg; }
+            uint32_t incl = len;
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= o) incl += t;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+            __builtin_amdgcn_wave_barrier();
+            s_end[lane] = incl; s_beg[lane] = beg; s_edge[lane] = ef;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
+                const uint32_t it = it0 + (uint32_t)lane;
+                bool tx = false, ty = false;
+                int32_t x = -1, y = -1;
+                if (it < total) {
+                    int lo = 0, hi = kWave - 1;                 // smallest t with s_end[t] > it
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_end[mid] > it) hi = mid; else lo = mid + 1;
+                    }
+                    const uint32_t first = lo ? s_end[lo - 1] : 0u;
+                    const int32_t me = s_edge[lo];
+                    const int2 p = inc[s_beg[lo] + (it - first)];
+                    x = p.x; y = p.y;
+                    const int32_t sx = stamp[x], sy = stamp[y];
+                    if (sx >= r && sy >= r) {                   // both other edges still present
+                        const bool xin = (sx == r), yin = (sy == r);
+                        const bool decx = !xin && (!yin || me < y);
+                        const bool decy = !yin && (!xin || me < x);
+                        if (decx && atomicSub(&sup[x], 1) == L + 1) { tx = true; stamp[x] = r + 1; truss[x] = L + 2; }
+                        if (decy && atomicSub(&sup[y], 1) == L + 1) { ty = true; stamp[y] = r + 1; truss[y] = L + 2; }
+                    }
+                }
+                wave_append(tx, x, qn, tail_n);
+                wave_append(ty, y, qn, tail_n);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    finalize_launch(ctrl, cv);
+}
+
+// -------------------------------------------------------------- result gather
+// One wavefront per row of the working CSR; upper slots (u < v) in row order
+// are the canonical edge order.  The oriented slot of {u,v} is found by a
+// binary search of the tiny oriented row of the lower-(degree,id) endpoint.
+__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                             int64_t nv, const int32_t *__restrict__ deg,
+                                                             const uint32_t *__restrict__ ebase,
+                                                             const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
+                                                             const uint32_t *__restrict__ off, const int32_t *__restrict__ truss,
+                                                             int32_t *__restrict__ eu, int32_t *__restrict__ ev,
+                                                             int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
+{
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t u = wave; u < nv; u += nwaves) {
+        const uint32_t b = rowptr[u], e = rowptr[u + 1];
+        uint32_t cnt = 0;
+        const uint32_t obase = ebase[u];
+        const int32_t du = deg[u];
+        for (uint32_t j0 = b; j0 < e; j0 += kWave) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            int32_t v = 0;
+            bool keep = false;
+            if (j < e) { v = col[j]; keep = v > (int32_t)u; }
+            const uint64_t mk = __ballot(keep);
+            if (keep) {
+                const uint32_t o = obase + cnt + (uint32_t)__popcll(mk & lanemask_lt());
+                const int32_t dv = deg[v];
+                const bool u_first = du < dv || (du == dv && (int32_t)u < v);
+                const int32_t a = u_first ? (int32_t)u : v, t = u_first ? v : (int32_t)u;
+                uint32_t lo = orow[a], hi = orow[a + 1];
+                while (lo < hi) {                                   // t is present by construction
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    if (ocol[mid] < t) lo = mid + 1; else hi = mid;
+                }
+                eu[o] = (int32_t)u; ev[o] = v;
+                tr_out[o] = truss[lo];
+                sup_out[o] = (int32_t)(off[lo + 1] - off[lo]);
+            }
+            cnt += (uint32_t)__popcll(mk);
+        }
+    }
+}
+
+// sum_v d(v)^2 and sum_e min(d(u),d(v)) for the roofline's algorithmic bytes
+__global__ __launch_bounds__(kBlock) void k_graph_moments(const int32_t *__restrict__ deg, int64_t nv,
+                                                          const int32_t *__restrict__ osrc, const int32_t *__restrict__ ocol,
+                                                          int64_t m, const uint32_t *__restrict__ cnt,
+                                                          unsigned long long *out /*[4]: sum d^2, sum min, max d, sum cnt*/)
+{
+    unsigned long long s2 = 0, smin = 0, mx = 0, sc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long d = (unsigned long long)deg[i];
+        s2 += d * d;
+        mx = d > mx ? d : mx;
+    }
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock)
+    {
+        smin += (unsigned long long)min(deg[osrc[e]], deg[ocol[e]]);
+        sc += (unsigned long long)cnt[e];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s2 += __shfl_xor(s2, o); smin += __shfl_xor(smin, o); sc += __shfl_xor(sc, o);
+        const unsigned long long t = __shfl_xor(mx, o); mx = t > mx ? t : mx;
+    }
+    if (lane_id() == 0) { atomicAdd(&out[0], s2); atomicAdd(&out[1], smin); atomicMax(&out[2], mx); atomicAdd(&out[3], sc); }
+}
+
+struct DevBufs {                                    // frees everything it still owns
+    static constexpr int kMax = 32;
+    void *p[kMax]; int n = 0;
+    template <class T> hipError_t alloc(T **out, size_t count)
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) { p[n++] = q; *out = (T *)q; }
+        return e;
+    }
+    void release(void *q) { for (int i = 0; i < n; ++i) if (p[i] == q) { (void)hipFree(q); p[i] = nullptr; } }
+    void disown(void *q) { for (int i = 0; i < n; ++i) if (p[i] == q) p[i] = nullptr; }
+    ~DevBufs() { for (int i = 0; i < n; ++i) if (p[i]) (void)hipFree(p[i]); }
+};
+
+// small blocking device-to-host read, ordered on the context's stream
+inline hipError_t d2h(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+}
+
+} // namespace
+
+void truss_free(komb_ctx *ctx)
+{
+    if (ctx->d_t_eu) (void)hipFree(ctx->d_t_eu);
+    if (ctx->d_t_ev) (void)hipFree(ctx->d_t_ev);
+    if (ctx->d_t_truss) (void)hipFree(ctx->d_t_truss);
+    if (ctx->d_t_sup) (void)hipFree(ctx->d_t_sup);
+    ctx->d_t_eu = ctx->d_t_ev = ctx->d_t_truss = ctx->d_t_sup = nullptr;
+    ctx->t_ne = -1; ctx->truss_done = false;
+}
+
+int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
+{
+    if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_run: no graph loaded");
+    truss_free(ctx);
+    const int64_t nv = ctx->nv;
+    hipStream_t s = ctx->stream;
+    komb_stats &st = ctx->stats;
+    st.triangles = 0; st.truss_levels = st.truss_subrounds = st.truss_launches = 0;
+    st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = 0.0;
+    st.truss_scans = 0;
+    if (nv == 0 || ctx->ne == 0) {
+        KOMB_HIP(ctx, hipMalloc(&ctx->d_t_eu, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_ev, 4));
+        KOMB_HIP(ctx, hipMalloc(&ctx->d_t_truss, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_sup, 4));
+        ctx->t_ne = 0; ctx->truss_done = true;
+        return KOMB_OK;
+    }
+    DevBufs bufs;
+    const int gv_wave = grid_for(nv, kBlock / kWave);          // one wave per vertex
+    const int gv = grid_for(nv);
+
+    // ---- a5: working CSR = whole graph, or the subgraph induced by vmask
+    const uint32_t *w_rowptr = ctx->d_rowptr;
+    const int32_t *w_col = ctx->d_col;
+    if (vmask_host) {
+        uint8_t *d_mask = nullptr; uint32_t *d_cnt = nullptr, *d_rp = nullptr; int32_t *d_c = nullptr;
+        KOMB_HIP(ctx, bufs.alloc(&d_mask, (size_t)nv));
+        KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)nv + 1));
+        KOMB_HIP(ctx, bufs.alloc(&d_rp, (size_t)nv + 1));
+        KOMB_HIP(ctx, hipMemcpyAsync(d_mask, vmask_host, (size_t)nv, hipMemcpyHostToDevice, s));
+        KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
+        k_row_filter<PredMask, false><<<gv_wave, kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, nv, PredMask{d_mask}, d_cnt, nullptr, nullptr, nullptr);
+        KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_rp, nv + 1));
+        uint32_t ns_sub = 0;
+        KOMB_HIP(ctx, d2h(ctx, &ns_sub, d_rp + nv, sizeof(uint32_t)));
+        KOMB_HIP(ctx, bufs.alloc(&d_c, (size_t)ns_sub));
+        k_row_filter<PredMask, true><<<gv_wave, kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, nv, PredMask{d_mask}, nullptr, d_rp, d_c, nullptr);
+        bufs.release(d_mask); bufs.release(d_cnt);
+        w_rowptr = d_rp; w_col = d_c;
+        if (ns_sub == 0) {
+            KOMB_HIP(ctx, hipStreamSynchronize(s));
+            KOMB_HIP(ctx, hipMalloc(&ctx->d_t_eu, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_ev, 4));
+            KOMB_HIP(ctx, hipMalloc(&ctx->d_t_truss, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_sup, 4));
+            ctx->t_ne = 0; ctx->truss_done = true;
+            return KOMB_OK;
+        }
+    }
+
+    // ---- orientation: oriented CSR, internal edge id = oriented slot
+    int32_t *d_deg = nullptr; uint32_t *d_ocnt = nullptr, *d_orow = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_deg, (size_t)nv));
+    KOMB_HIP(ctx, bufs.alloc(&d_ocnt, (size_t)nv + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_orow, (size_t)nv + 1));
+    ctx->timer.start(s);
+    k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg);
+    KOMB_HIP(ctx, hipMemsetAsync(d_ocnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
+    k_row_filter<PredOrient, false><<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, PredOrient{d_deg}, d_ocnt, nullptr, nullptr, nullptr);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ocnt, d_orow, nv + 1));
+    uint32_t m32 = 0;
+    KOMB_HIP(ctx, d2h(ctx, &m32, d_orow + nv, sizeof(uint32_t)));
+    const int64_t m = (int64_t)m32;
+    bufs.release(d_ocnt);
+    int32_t *d_ocol = nullptr, *d_osrc = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_ocol, (size_t)m));
+    KOMB_HIP(ctx, bufs.alloc(&d_osrc, (size_t)m));
+    k_row_filter<PredOrient, true><<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, PredOrient{d_deg}, nullptr, d_orow, d_ocol, d_osrc);
+    st.ms_orient = ctx->timer.stop(s);
+
+    // ---- support (pass 1), slice offsets, incidence lists (pass 2)
+    const int ge = grid_for(m);
+    uint32_t *d_cnt = nullptr, *d_off = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)m + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
+    KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
+    ctx->timer.start(s);
+    k_triangles<false><<<ge, kBlock, 0, s>>>(d_orow, d_ocol, d_osrc, m, d_cnt, nullptr);
+    st.ms_tri_count = ctx->timer.stop(s);
+    // the 32-bit slice offsets must not wrap: take the 64-bit total first
+    {
+        unsigned long long *d_mom = nullptr;
+        KOMB_HIP(ctx, bufs.alloc(&d_mom, 4));
+        KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 4 * sizeof(unsigned long long), s));
+        k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_cnt, d_mom);
+        unsigned long long mom[4];
+        KOMB_HIP(ctx, d2h(ctx, mom, d_mom, sizeof(mom)));
+        st.sum_deg_sq = (int64_t)mom[0]; st.wedge_items = (int64_t)mom[1]; st.max_degree = (int32_t)mom[2];
+        st.triangles = (int64_t)(mom[3] / 3);
+        bufs.release(d_mom);
+        if (mom[3] > 0xFFFFFFF0ull)
+            KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %llu triangles; the incidence index is limited to 2^32-16 entries (3 per triangle)",
+                      mom[3] / 3);
+    }
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_off, m + 1));
+    uint32_t total = 0;
+    KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
+    int2 *d_inc = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
+    KOMB_HIP(ctx, hipMemcpyAsync(d_cnt, d_off, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // cursors
+    ctx->timer.start(s);
+    k_triangles<true><<<ge, kBlock, 0, s>>>(d_orow, d_ocol, d_osrc, m, d_cnt, d_inc);
+    st.ms_tri_fill = ctx->timer.stop(s);
+    st.ms_support = st.ms_tri_count + st.ms_tri_fill;
+    bufs.release(d_cnt);
+
+    // ---- peel
+    int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr, *d_q0 = nullptr, *d_q1 = nullptr;
+    PeelCtrl *d_ctrl = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
+    KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
+    KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
+    KOMB_HIP(ctx, bufs.alloc(&d_q0, (size_t)m));
+    KOMB_HIP(ctx, bufs.alloc(&d_q1, (size_t)m));
+    KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
+    ctx->timer.start(s);
+    k_peel_init<<<ge, kBlock, 0, s>>>(m, d_off, d_sup, d_stamp);
+    peel_ctrl_init(s, d_ctrl, (uint32_t)m);
+    const int gp = grid_for(m, kBlock, 2048);
+    int launches = 0;
+    int rc = drive_peel(ctx, d_ctrl, m, [&]() {
+        k_truss_step<<<gp, kBlock, 0, s>>>(d_ctrl, d_off, d_inc, d_sup, d_stamp, d_truss, d_q0, d_q1, m);
+    }, &launches);
+    st.ms_peel = ctx->timer.stop(s);
+    KOMB_TRY(rc);
+    if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss peel ended in an inconsistent state");
+    st.truss_levels = ctx->h_ctrl[0].n_levels;
+    st.truss_subrounds = ctx->h_ctrl[0].n_rounds;
+    st.truss_launches = launches;
+    st.truss_scans = ctx->h_ctrl[0].n_scans;
+    st.max_trussness = ctx->h_ctrl[0].max_level + 2;
+    bufs.release(d_q0); bufs.release(d_q1); bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc);
+
+    // ---- canonical-order results with original vertex ids
+    uint32_t *d_ucnt = nullptr, *d_ebase = nullptr;
+    ctx->timer.start(s);
+    KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
+    KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
+    k_row_filter<PredUpper, false><<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, PredUpper{}, d_ucnt, nullptr, nullptr, nullptr);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
+    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+    k_gather_canonical<<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_deg, d_ebase, d_orow, d_ocol, d_off, d_truss,
+                                                  ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
+    st.ms_gather = ctx->timer.stop(s);
+    ctx->t_ne = m;
+    ctx->truss_done = true;
+    return KOMB_OK;
+}
+
+} // namespace komb

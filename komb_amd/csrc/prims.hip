@@ -1,0 +1,82 @@
+// prims.hip -- device-wide sort / select / scan used by graph construction and
+// CoreA ranking.  These are rocPRIM (via hipCUB) library primitives kept
+// behind plain signatures so the hand-written kernels' translation units do
+// not pull the library headers in.  None of them is on the timed peel path.
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace komb {
+
+namespace {
+struct TempBuf {
+    void *p = nullptr;
+    ~TempBuf() { if (p) (void)hipFree(p); }
+};
+} // namespace
+
+int prim_sort_u64(komb_ctx *ctx, uint64_t *keys, uint64_t *tmp_keys, int64_t n, int end_bit, uint64_t **sorted)
+{
+    if (n > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "sort: %lld keys exceed the 2^31-1 primitive limit", (long long)n);
+    hipcub::DoubleBuffer<uint64_t> db(keys, tmp_keys);
+    size_t bytes = 0;
+    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, db, (int)n, 0, end_bit, ctx->stream));
+    TempBuf t;
+    KOMB_HIP(ctx, hipMalloc(&t.p, bytes ? bytes : 16));
+    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(t.p, bytes, db, (int)n, 0, end_bit, ctx->stream));
+    KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *sorted = db.Current();
+    return KOMB_OK;
+}
+
+int prim_unique_u64(komb_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, int64_t *n_out)
+{
+    if (n > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "unique: %lld keys exceed the 2^31-1 primitive limit", (long long)n);
+    int *d_num = nullptr;
+    KOMB_HIP(ctx, hipMalloc(&d_num, sizeof(int)));
+    size_t bytes = 0;
+    hipError_t e = hipcub::DeviceSelect::Unique(nullptr, bytes, in, out, d_num, (int)n, ctx->stream);
+    TempBuf t;
+    if (e == hipSuccess) e = hipMalloc(&t.p, bytes ? bytes : 16);
+    if (e == hipSuccess) e = hipcub::DeviceSelect::Unique(t.p, bytes, in, out, d_num, (int)n, ctx->stream);
+    int h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_num, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_num);
+    KOMB_HIP(ctx, e);
+    *n_out = h;
+    return KOMB_OK;
+}
+
+int prim_exclusive_sum_u32(komb_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t n)
+{
+    if (n > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "scan: %lld items exceed the 2^31-1 primitive limit", (long long)n);
+    if (n == 0) return KOMB_OK;
+    size_t bytes = 0;
+    KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
+    TempBuf t;
+    KOMB_HIP(ctx, hipMalloc(&t.p, bytes ? bytes : 16));
+    KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(t.p, bytes, in, out, (int)n, ctx->stream));
+    KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KOMB_OK;
+}
+
+int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, uint32_t *vals, uint32_t *vals_tmp,
+                             int64_t n, int end_bit, int64_t **sorted_keys, uint32_t **sorted_vals)
+{
+    if (n > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "sort: %lld keys exceed the 2^31-1 primitive limit", (long long)n);
+    // keys are non-negative, so the unsigned bit order of [0,end_bit) is the value order
+    hipcub::DoubleBuffer<uint64_t> dk((uint64_t *)keys, (uint64_t *)keys_tmp);
+    hipcub::DoubleBuffer<uint32_t> dv(vals, vals_tmp);
+    size_t bytes = 0;
+    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, dk, dv, (int)n, 0, end_bit, ctx->stream));
+    TempBuf t;
+    KOMB_HIP(ctx, hipMalloc(&t.p, bytes ? bytes : 16));
+    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(t.p, bytes, dk, dv, (int)n, 0, end_bit, ctx->stream));
+    KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *sorted_keys = (int64_t *)dk.Current();
+    *sorted_vals = dv.Current();
+    return KOMB_OK;
+}
+
+} // namespace komb

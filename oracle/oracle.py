@@ -1,0 +1,172 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from komb_amd/ (the product).  See
+komb_oracle.h for the parity status of each half ("parity unpinned" for the
+igraph half; CoreA half pinned by oracle/_ref/corea_ref).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i64 = ctypes.c_int64
+
+
+def build():
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    subprocess.run(["make", "-s", "-C", _HERE, "all"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.orc_simplify.restype = _i64
+        L.orc_simplify.argtypes = [_i64, _i64, _i64p, _i64p, _i32p]
+        L.orc_degree.restype = None
+        L.orc_degree.argtypes = [_i64, _i64p, _i32p]
+        L.orc_coreness.restype = ctypes.c_int32
+        L.orc_coreness.argtypes = [_i64, _i64p, _i32p, _i32p]
+        L.orc_induced_subgraph.restype = _i64
+        L.orc_induced_subgraph.argtypes = [_i64, _i64p, _i32p, _u8p, _i64p, _i32p, _i32p]
+        L.orc_edge_list.restype = _i64
+        L.orc_edge_list.argtypes = [_i64, _i64p, _i32p, _i32p, _i32p]
+        L.orc_support.restype = _i64
+        L.orc_support.argtypes = [_i64, _i64p, _i32p, _i32p]
+        L.orc_trussness.restype = ctypes.c_int32
+        L.orc_trussness.argtypes = [_i64, _i64p, _i32p, _i32p]
+        L.orc_fractional_rank_faithful.restype = None
+        L.orc_fractional_rank_faithful.argtypes = [_f64p, _i64, _f64p]
+        L.orc_fractional_rank_fast.restype = None
+        L.orc_fractional_rank_fast.argtypes = [_i64p, _i64, _f64p]
+        L.orc_corea_scores.restype = None
+        L.orc_corea_scores.argtypes = [_i32p, _i32p, _i64, ctypes.c_int, _f64p]
+        _LIB = L
+    return _LIB
+
+
+def ref_corea_path():
+    p = os.path.join(_HERE, "_ref", "corea_ref")
+    return p if os.path.exists(p) else None
+
+
+# ------------------------------------------------------------------ wrappers
+def simplify(nv, uv):
+    """a1: raw (u,v) pairs [n_raw,2] int64 -> (rowptr int64[nv+1], col int32[2*ne])."""
+    uv = np.ascontiguousarray(np.asarray(uv, dtype=np.int64).reshape(-1, 2))
+    n_raw = uv.shape[0]
+    rowptr = np.zeros(nv + 1, dtype=np.int64)
+    col = np.zeros(max(2 * n_raw, 1), dtype=np.int32)
+    ne = lib().orc_simplify(nv, n_raw, uv.reshape(-1), rowptr, col)
+    if ne < 0:
+        raise ValueError("orc_simplify: bad input")
+    return rowptr, np.ascontiguousarray(col[: 2 * ne])
+
+
+def degree(rowptr):
+    nv = len(rowptr) - 1
+    d = np.zeros(max(nv, 1), dtype=np.int32)
+    lib().orc_degree(nv, rowptr, d)
+    return d[:nv]
+
+
+def _colbuf(col):
+    return col if len(col) else np.zeros(1, dtype=np.int32)
+
+
+def coreness(rowptr, col):
+    nv = len(rowptr) - 1
+    c = np.zeros(max(nv, 1), dtype=np.int32)
+    lib().orc_coreness(nv, rowptr, _colbuf(col), c)
+    return c[:nv]
+
+
+def edge_list(rowptr, col):
+    nv = len(rowptr) - 1
+    ne = int(rowptr[nv]) // 2
+    eu = np.zeros(max(ne, 1), dtype=np.int32)
+    ev = np.zeros(max(ne, 1), dtype=np.int32)
+    lib().orc_edge_list(nv, rowptr, _colbuf(col), eu, ev)
+    return eu[:ne], ev[:ne]
+
+
+def support(rowptr, col):
+    nv = len(rowptr) - 1
+    ne = int(rowptr[nv]) // 2
+    s = np.zeros(max(ne, 1), dtype=np.int32)
+    t = lib().orc_support(nv, rowptr, _colbuf(col), s)
+    return s[:ne], int(t)
+
+
+def trussness(rowptr, col):
+    nv = len(rowptr) - 1
+    ne = int(rowptr[nv]) // 2
+    t = np.zeros(max(ne, 1), dtype=np.int32)
+    lib().orc_trussness(nv, rowptr, _colbuf(col), t)
+    return t[:ne]
+
+
+def induced_subgraph(rowptr, col, vmask):
+    nv = len(rowptr) - 1
+    vmask = np.ascontiguousarray(vmask, dtype=np.uint8)
+    srp = np.zeros(nv + 1, dtype=np.int64)
+    scol = np.zeros(max(len(col), 1), dtype=np.int32)
+    inv = np.zeros(max(nv, 1), dtype=np.int32)
+    ns = lib().orc_induced_subgraph(nv, rowptr, _colbuf(col), vmask, srp, scol, inv)
+    srp = np.ascontiguousarray(srp[: ns + 1])
+    return srp, np.ascontiguousarray(scol[: int(srp[ns])]), inv[:ns]
+
+
+def trussness_induced(rowptr, col, vmask):
+    """a5+a6 as KOMB's runTruss composes them (src/graph.cpp:502,508,529-532):
+    returns (eu, ev, truss) with ORIGINAL vertex ids, canonical order."""
+    srp, scol, inv = induced_subgraph(rowptr, col, vmask)
+    t = trussness(srp, scol)
+    su, sv = edge_list(srp, scol)
+    return inv[su].astype(np.int32), inv[sv].astype(np.int32), t
+
+
+def fractional_rank_faithful(scores):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    out = np.zeros(max(len(scores), 1), dtype=np.float64)
+    lib().orc_fractional_rank_faithful(scores if len(scores) else out, len(scores), out)
+    return out[: len(scores)]
+
+
+def fractional_rank_fast(keys):
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    out = np.zeros(max(len(keys), 1), dtype=np.float64)
+    lib().orc_fractional_rank_fast(keys if len(keys) else np.zeros(1, np.int64), len(keys), out)
+    return out[: len(keys)]
+
+
+def corea_scores(deg, core, faithful=False):
+    deg = np.ascontiguousarray(deg, dtype=np.int32)
+    core = np.ascontiguousarray(core, dtype=np.int32)
+    n = len(deg)
+    out = np.zeros(max(n, 1), dtype=np.float64)
+    if n:
+        lib().orc_corea_scores(deg, core, n, 1 if faithful else 0, out)
+    return out[:n]
+
+
+def ref_corea_scores(deg, core):
+    """Scores from the REFERENCE's own CoreA.h (oracle/_ref/corea_ref)."""
+    exe = ref_corea_path()
+    if exe is None:
+        raise FileNotFoundError("oracle/_ref/corea_ref not built")
+    text = "%d\n" % len(deg) + "".join("%d %d\n" % (int(d), int(c)) for d, c in zip(deg, core))
+    out = subprocess.run([exe, "arrays"], input=text, capture_output=True, text=True, check=True).stdout
+    return np.array([float(x) for x in out.split()], dtype=np.float64)

@@ -1,0 +1,215 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the golden
+fixtures and against the oracle on the same seeded inputs.  Integer results are
+compared bit for bit; CoreA scores (f64) are compared bit for bit as well since
+ranks are exact and the logarithm is the host libm on both sides."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O(built):
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def K(built):
+    import komb_amd
+    return komb_amd
+
+
+def _i64(x):
+    return np.asarray(x, dtype=np.int64)
+
+
+def test_native_library_is_loaded(K):
+    lib = K._lib.load()
+    assert lib.komb_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libkomb_accel.so" in f.read()
+
+
+def test_golden_from_edges(K, golden):
+    for g in golden:
+        with K.KombAccel() as a:
+            a.from_edges(g["nv"], _i64(g["raw"]).reshape(-1, 2))
+            assert (a.nv, a.ne) == (g["nv"], len(g["eu"])), g["name"]
+            rowptr, col = a.get_csr()
+            assert rowptr.tolist() == g["rowptr"] and col.tolist() == g["col"], g["name"]
+            deg, core = a.run_core()
+            assert deg.tolist() == g["degree"], g["name"]
+            assert core.tolist() == g["coreness"], g["name"]
+            eu, ev, tr, sup = a.run_truss(with_support=True)
+            assert eu.tolist() == g["eu"] and ev.tolist() == g["ev"], g["name"]
+            assert sup.tolist() == g["support"], g["name"]
+            assert tr.tolist() == g["trussness"], g["name"]
+            assert a.stats()["triangles"] == g["triangles"], g["name"]
+
+
+def test_golden_from_csr_and_maxcore_subgraph(K, golden):
+    """runTruss's composition: trussness of the max-core induced subgraph."""
+    for g in golden:
+        with K.KombAccel() as a:
+            a.from_csr(_i64(g["rowptr"]), np.asarray(g["col"], dtype=np.int32))
+            deg, core = a.run_core()
+            assert core.tolist() == g["coreness"], g["name"]
+            mask = (core == core.max()).astype(np.uint8) if g["nv"] else np.zeros(0, np.uint8)
+            assert mask.tolist() == g["maxcore_mask"], g["name"]
+            eu, ev, tr = a.run_truss(mask)
+            assert eu.tolist() == g["sub_eu"] and ev.tolist() == g["sub_ev"], g["name"]
+            assert tr.tolist() == g["sub_trussness"], g["name"]
+
+
+def test_golden_corea_reference_header(K, golden):
+    for g in golden:
+        if not g["nv"]:
+            continue
+        want = np.array([float.fromhex(h) for h in g["ref_corea_hex"]])
+        with K.KombAccel() as a:
+            got = a.get_anomaly_score(g["degree"], g["coreness"])
+        assert np.array_equal(got, want), g["name"]
+
+
+@pytest.mark.parametrize("nv,fac,alpha,seed", [
+    (64, 2.0, 2.6, 1), (1000, 2.5, 2.6, 2), (1000, 6.0, 2.2, 3), (20000, 2.5, 2.6, 4),
+    (50000, 3.3, 2.2, 5), (200000, 2.45, 2.6, 42),
+])
+def test_generated_graphs_vs_oracle(K, O, nv, fac, alpha, seed):
+    uv = K.gen_hug_edges(nv, int(fac * nv), alpha, seed)
+    o_rowptr, o_col = O.simplify(nv, uv)
+    with K.KombAccel() as a:
+        a.from_edges(nv, uv)
+        rowptr, col = a.get_csr()
+        assert np.array_equal(rowptr, o_rowptr) and np.array_equal(col, o_col)
+        deg, core = a.run_core()
+        assert np.array_equal(deg, O.degree(o_rowptr))
+        o_core = O.coreness(o_rowptr, o_col)
+        assert np.array_equal(core, o_core)
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        oeu, oev = O.edge_list(o_rowptr, o_col)
+        assert np.array_equal(eu, oeu) and np.array_equal(ev, oev)
+        osup, otri = O.support(o_rowptr, o_col)
+        assert np.array_equal(sup, osup) and a.stats()["triangles"] == otri
+        assert np.array_equal(tr, O.trussness(o_rowptr, o_col))
+        # runTruss-faithful variant: max-core induced subgraph
+        mask = (core == core.max()).astype(np.uint8)
+        seu, sev, stra = a.run_truss(mask)
+        weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
+        assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+        # CoreA
+        score = a.get_anomaly_score(deg, core)
+        assert np.array_equal(score, O.corea_scores(deg, core))
+        rd, rk = a.fractional_ranks(deg, core)
+        assert np.array_equal(rd, O.fractional_rank_fast(deg.astype(np.int64)))
+        assert np.array_equal(rk, O.fractional_rank_fast(core.astype(np.int64) * nv + deg))
+
+
+def test_random_dense_graphs_vs_oracle(K, O):
+    """Erdos-Renyi-like inputs with loops and duplicates: long oriented rows,
+    many triangles per edge, deep peel cascades."""
+    rng = np.random.default_rng(17)
+    for nv, ne in ((40, 600), (300, 9000), (2000, 60000)):
+        uv = rng.integers(0, nv, (ne, 2)).astype(np.int64)
+        o_rowptr, o_col = O.simplify(nv, uv)
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            deg, core = a.run_core()
+            assert np.array_equal(core, O.coreness(o_rowptr, o_col))
+            eu, ev, tr, sup = a.run_truss(with_support=True)
+            osup, _ = O.support(o_rowptr, o_col)
+            assert np.array_equal(sup, osup)
+            assert np.array_equal(tr, O.trussness(o_rowptr, o_col))
+
+
+def test_structured_cascades(K, O):
+    """Long paths / ladders force one vertex or edge per sub-round."""
+    n = 5000
+    path = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
+    # triangle strip: (i,i+1),(i,i+2): every inner edge in 2 triangles, peels from both ends
+    strip = np.concatenate([path, np.stack([np.arange(n - 2), np.arange(2, n)], axis=1)])
+    for uv in (path, strip):
+        uv = uv.astype(np.int64)
+        o_rowptr, o_col = O.simplify(n, uv)
+        with K.KombAccel() as a:
+            a.from_edges(n, uv)
+            deg, core = a.run_core()
+            assert np.array_equal(core, O.coreness(o_rowptr, o_col))
+            _, _, tr = a.run_truss()
+            assert np.array_equal(tr, O.trussness(o_rowptr, o_col))
+
+
+def test_edge_cases_and_errors(K):
+    with K.KombAccel() as a:
+        a.from_edges(0, np.zeros((0, 2), np.int64))
+        assert (a.nv, a.ne) == (0, 0)
+        deg, core = a.run_core()
+        assert len(deg) == 0 and len(core) == 0
+        eu, ev, tr = a.run_truss()
+        assert len(eu) == 0
+        a.from_edges(4, np.array([[1, 1], [2, 2]], np.int64))           # only loops
+        assert (a.nv, a.ne) == (4, 0)
+        deg, core = a.run_core()
+        assert deg.tolist() == [0, 0, 0, 0] and core.tolist() == [0, 0, 0, 0]
+        assert len(a.run_truss()[0]) == 0
+        with pytest.raises(K.KombError) as e:
+            a.from_edges(3, np.array([[0, 3]], np.int64))
+        assert e.value.code == K._lib.KOMB_ERR_ARG
+        with pytest.raises(K.KombError):                                 # graph was dropped by the failed load
+            a.core_run()
+        with pytest.raises(K.KombError):                                 # asymmetric CSR
+            a.from_csr(np.array([0, 1, 1], np.int64), np.array([1], np.int32))
+        a.from_edges(3, np.array([[0, 1], [1, 2], [0, 2]], np.int64))
+        with pytest.raises(K.KombError) as e:
+            a.truss_fetch()                                              # fetch before run
+        assert e.value.code == K._lib.KOMB_ERR_STATE
+        eu, ev, tr = a.run_truss(np.array([1, 1, 0], np.uint8))          # mask leaves one edge
+        assert (eu.tolist(), ev.tolist(), tr.tolist()) == ([0], [1], [2])
+        eu, ev, tr = a.run_truss(np.array([1, 0, 0], np.uint8))          # mask leaves no edge
+        assert len(eu) == 0
+        assert a.get_anomaly_score([], []).tolist() == []
+
+
+def test_repeat_runs_identical(K):
+    """Atomics reorder freely between runs; integer results must not move."""
+    uv = K.gen_hug_edges(30000, 80000, 2.4, 8)
+    with K.KombAccel() as a:
+        a.from_edges(30000, uv)
+        c1 = a.run_core()[1]
+        t1 = a.run_truss()[2]
+        for _ in range(3):
+            assert np.array_equal(a.run_core()[1], c1)
+            assert np.array_equal(a.run_truss()[2], t1)
+
+
+def test_full_size_c2_properties(K, O):
+    """BASELINE config C2 (|V|=1M, |E|~10M): k-core against the oracle (it takes ~1 s),
+    k-truss through size-independent properties."""
+    nv = 1_000_000
+    uv = K.gen_hug_edges(nv, 2_450_000, 2.6, 42)
+    with K.KombAccel() as a:
+        a.from_edges(nv, uv)
+        rowptr, col = a.get_csr()
+        deg, core = a.run_core()
+        assert np.array_equal(deg, np.diff(rowptr).astype(np.int32))
+        assert np.array_equal(core, O.coreness(rowptr, col))
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        st = a.stats()
+        assert len(eu) == a.ne and np.all(eu < ev)
+        key = eu.astype(np.int64) * nv + ev
+        assert np.all(np.diff(key) > 0)                                  # canonical order, no duplicates
+        assert int(sup.sum()) == 3 * st["triangles"]
+        assert np.all(tr >= 2) and np.all(tr <= sup + 2)
+        assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
+        assert np.all((sup == 0) == (tr == 2) | (sup > 0))
+        assert st["max_trussness"] == tr.max() and st["max_coreness"] == core.max()
+        # the top truss class is closed: every edge of the max-truss subgraph has
+        # >= tmax-2 triangles inside it (checked with the oracle on that small subgraph)
+        top = tr == tr.max()
+        vs = np.unique(np.concatenate([eu[top], ev[top]]))
+        remap = -np.ones(nv, np.int64); remap[vs] = np.arange(len(vs))
+        sub = np.stack([remap[eu[top]], remap[ev[top]]], axis=1)
+        s_rowptr, s_col = O.simplify(len(vs), sub)
+        s_sup, _ = O.support(s_rowptr, s_col)
+        assert s_sup.min() >= tr.max() - 2
