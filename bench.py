@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- peeled edges/sec of the k-truss hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the k-truss path (orientation, triangle support,
+incidence index, level-synchronous peel, canonical gather: komb_truss_run) over
+the synthetic power-law unitig graph, with the simple CSR already resident in
+HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+N=1 workload = BASELINE.json configs[2] (|V|=10M, |E|~100M, full k-truss, the
+configuration the metric is quoted on).  --config c2 selects configs[1]
+(|V|=1M, |E|~10M); the k-core time of the same graph is reported alongside.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+CONFIGS = {
+    # name: (nv, cliques, alpha, seed, description)
+    "c3": (10_000_000, 24_250_000, 2.6, 42, "C3: synthetic power-law unitig graph |V|=10M |E|~100M, full k-truss peel"),
+    "c2": (1_000_000, 2_450_000, 2.6, 42, "C2: synthetic power-law unitig graph |V|=1M |E|~10M, full k-truss peel"),
+    "tiny": (100_000, 245_000, 2.6, 42, "tiny: |V|=100k |E|~1M (debug)"),
+}
+CPU_SAMPLE = (300_000, 735_000, 2.6, 42)      # ~3M edges: 10-30 s of single-thread CPU work
+
+
+def algorithmic_bytes(st):
+    """Bytes each phase must move, per step (DESIGN.md 'Algorithmic bytes').
+    E = edges, T = triangles, O = sum over oriented edges of d+(a)+d+(b)."""
+    E, T, O = st["ne"], st["triangles"], st["oriented_items"]
+    tri_count = 12 * E + 4 * O + 24 * T                 # SURVEY 8(d) B_sup
+    tri_fill = 12 * E + 4 * O + 24 * T + 24 * T         # same reads, 3 cursor RMW + 3 pair stores per triangle
+    peel = 8 * E + 24 * T + 24 * T + 16 * T             # truss+stamp per edge; slice entries; two stamps per entry; 2 RMW per triangle
+    survey_peel = 8 * E + 4 * st["sum_deg_sq"] + 16 * T # SURVEY 8(d) B_peel (merge re-intersection; not what we do)
+    return {"tri_count": tri_count, "tri_fill": tri_fill, "peel": peel, "survey_peel": survey_peel}
+
+
+def cpu_baseline():
+    """The oracle's igraph-equivalent trussness (single thread) on a bounded sample."""
+    import numpy as np  # noqa: F401
+    import komb_amd
+    from oracle import oracle as O
+    nv, ncl, alpha, seed = CPU_SAMPLE
+    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
+    rowptr, col = O.simplify(nv, uv)
+    ne = len(col) // 2
+    t0 = time.perf_counter()
+    O.trussness(rowptr, col)
+    dt = time.perf_counter() - t0
+    return {"value": ne / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"oracle orc_trussness (support + bucket peel, 1 thread) on |V|={nv} |E|={ne} of the same generator: {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the komb_accel path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    import komb_amd
+
+    nv, ncl, alpha, seed, desc = CONFIGS[args.config]
+    t0 = time.perf_counter()
+    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
+    t_gen = time.perf_counter() - t0
+    acc = komb_amd.KombAccel(device=local_rank)
+    t0 = time.perf_counter()
+    acc.from_edges(nv, uv)                       # a1 on the device; CSR stays resident in HBM
+    t_build = time.perf_counter() - t0
+    del uv
+    ne = acc.ne
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        acc.truss_run()                          # replicas for now when world > 1 (see DESIGN.md section e)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync()
+    t0 = time.perf_counter()
+    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_tri_fill", "ms_peel", "ms_gather")}
+    for _ in range(args.steps):
+        step()
+        s = acc.stats()
+        for k in phase:
+            phase[k] += s[k]
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = acc.stats()
+    for k in phase:
+        phase[k] /= args.steps
+
+    # k-core of the same graph, reported alongside (BASELINE config C2's op)
+    acc.core_run()
+    core_ms = acc.stats()["ms_core"]
+    core_stats = acc.stats()
+
+    if rank == 0:
+        ab = algorithmic_bytes(st)
+        kernels = {
+            "k_triangles<count>": (phase["ms_tri_count"], 1, ab["tri_count"]),
+            "k_triangles<fill>": (phase["ms_tri_fill"], 1, ab["tri_fill"]),
+            "k_truss_step": (phase["ms_peel"], st["truss_subrounds"] + st["truss_scans"], ab["peel"]),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms, launches, nbytes = kernels[dom]
+        achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "launches_per_step": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
+            "algorithmic_bytes_per_step": nbytes,
+            "per_kernel": {k: {"ms_per_step": v[0], "launches": v[1], "alg_bytes": v[2],
+                               "GBps": (v[2] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in kernels.items()},
+            "survey_formula_peel_bytes": ab["survey_peel"],
+        }
+        out = {
+            "metric": "peeled edges/sec (k-truss)", "value": ne * world / dt * args.steps if world == 1 else ne * world * args.steps / dt,
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if world > 1 else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": desc, "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
+                       "max_degree": st["max_degree"], "max_trussness": st["max_trussness"],
+                       "max_coreness": core_stats["max_coreness"],
+                       "truss_levels": st["truss_levels"], "truss_subrounds": st["truss_subrounds"],
+                       "truss_scans": st["truss_scans"], "truss_launches": st["truss_launches"],
+                       "parallelism": "single" if world == 1 else f"replicas x{world}"},
+            "phases_ms": phase,
+            "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
+                      "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],
+                      "alg_bytes": 16 * nv + 24 * ne,
+                      "GBps": (16 * nv + 24 * ne) / (core_ms * 1e-3) / 1e9 if core_ms > 0 else None},
+            "setup_s": {"generate": t_gen, "graph_build_incl_h2d": t_build, "device_build_ms": st["ms_build"]},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    acc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

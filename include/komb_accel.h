@@ -51,8 +51,10 @@ typedef struct komb_stats {
     int64_t triangles;              /* T (sum of supports / 3), after komb_truss_run */
     int64_t sum_deg_sq;             /* sum_v d(v)^2 = sum_{(u,v) in E} d(u)+d(v)      */
     int64_t wedge_items;            /* sum_{(u,v) in E} min(d(u),d(v))                */
+    int64_t oriented_items;         /* sum_{(a->b)} d+(a)+d+(b), (degree,id) orientation */
     int32_t max_degree, max_coreness, max_trussness;
-    int32_t core_levels, core_launches;     /* populated levels; launches issued      */
+    int32_t core_levels, core_subrounds;    /* populated levels; PROCESS sub-rounds   */
+    int32_t core_launches, reserved0;       /* launches issued                        */
     int32_t truss_levels, truss_subrounds;  /* populated levels; PROCESS sub-rounds   */
     int32_t truss_scans, truss_launches;    /* SCAN launches; launches issued         */
     /* HIP-event times (ms), each measured on the stream the kernels run on */

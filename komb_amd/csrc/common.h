@@ -18,25 +18,26 @@ constexpr int32_t kAlive = 0x7FFFFFFF;      // stamp / core value of a live edge
 // Device-side control block of a peel loop.  One 128-byte record; the fields a
 // launch reads at entry are written only by the previous launch's last block.
 struct PeelCtrl {
-    // ---- stable during a launch (written by the finalising block only)
+    // ---- stable during a launch (written by the finalising workgroup only)
     int32_t  mode;          // 0 = SCAN, 1 = PROCESS
     int32_t  level;         // current peel level (degree k / support L)
     int32_t  round;         // sub-round id stamped on the current frontier
-    int32_t  done;          // 1 once every unit is peeled
-    uint32_t cur_count;     // entries in the current frontier queue
-    int32_t  cur_sel;       // which of the two queues is current
-    uint32_t remaining;     // units not yet peeled
+    int32_t  done;          // 1 once every unit is peeled (2 = inconsistent state)
+    uint32_t cur_light;     // entries in the current light queue (unit ids)
+    uint32_t cur_heavy;     // entries in the current heavy queue ((unit, chunk) pairs)
+    int32_t  cur_sel;       // which of the two queue pairs is current
+    uint32_t remaining;     // units that have not entered a frontier yet
     int32_t  n_levels;      // stats: populated levels
-    int32_t  n_rounds;      // stats: PROCESS launches that had work
+    int32_t  n_rounds;      // stats: PROCESS launches
     int32_t  n_scans;       // stats: SCAN launches
     int32_t  max_level;     // stats: highest populated level
-    int32_t  pad0;
     // ---- modified with atomics during a launch
-    uint32_t tail[2];       // append cursors of the two queues
+    uint32_t tail_l[2];     // append cursors of the light queues
+    uint32_t tail_h[2];     // append cursors of the heavy queues
     int32_t  next_min;      // min live key above the scanned level
-    uint32_t blocks_done;   // finalisation ticket
-    uint32_t acc;           // units peeled in this launch without passing through a queue
-    uint32_t pad1[15];
+    uint32_t blocks_done;   // second-level arrival ticket
+    uint32_t acc;           // units that entered a frontier in this launch
+    uint32_t pad1[13];
 };
 static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
 
@@ -128,7 +129,8 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
 int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);
 void graph_free(komb_ctx *ctx);
 void truss_free(komb_ctx *ctx);
-void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t units);
+void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units);
+int peel_grid(int64_t units);
 
 // Issue `launch()` in batches until the device control block reports done.
 // The host never decides what a launch does: every launch reads the control

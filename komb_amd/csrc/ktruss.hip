@@ -148,90 +148,54 @@ __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t 
     }
 }
 
-// ------------------------------------------------------------------ peel step
-__global__ __launch_bounds__(kBlock) void k_truss_step(PeelCtrl *ctrl, const uint32_t *__restrict__ off,
-                                                       const int2 *__restrict__ inc, int32_t *sup, int32_t *stamp,
-                                                       int32_t *truss, int32_t *q0, int32_t *q1, int64_t m)
-{
-    __shared__ CtrlView sh_cv;
-    __shared__ uint32_t sh_end[kBlock / kWave][kWave];
-    __shared__ uint32_t sh_beg[kBlock / kWave][kWave];
-    __shared__ int32_t sh_edge[kBlock / kWave][kWave];
-    const CtrlView cv = load_ctrl(ctrl, &sh_cv);
-    if (cv.done) return;
-    const int L = cv.level, r = cv.round;
-    const int lane = lane_id();
-    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+// ------------------------------------------------------------------ the peel
+// peel_dev.h's engine with: unit = edge, key = live support, slice = the
+// edge's incidence slice (pairs of the other two edges of each triangle).
+// stamp[e] = kAlive while e is live, else the sub-round in which e is (to be)
+// peeled.  For a frontier edge `me` (stamp == round r) and a triangle {me,x,y}:
+//   - x or y peeled in an earlier sub-round (stamp < r): the triangle is gone.
+//   - otherwise the triangle is destroyed now; each of x,y that is not itself
+//     in this frontier loses one support -- by `me` alone if the other edge is
+//     live, or by the smaller edge id if two of the three are in the frontier
+//     -- so every triangle is destroyed exactly once.
+// A decrement that returns level+1 triggers the edge (trussness level+2).
+struct TrussProblem {
+    uint32_t units;
+    const uint32_t *off;
+    const int2 *inc;
+    int32_t *sup;
+    int32_t *stamp;
+    int32_t *truss;
 
-    if (cv.mode == MODE_SCAN) {
-        int32_t *q = cv.cur_sel ? q1 : q0;
-        int32_t lmin = 0x7FFFFFFF;
-        for (int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) - lane; base < m; base += nthreads) {
-            const int64_t e = base + lane;
-            bool hit = false;
-            if (e < m && stamp[e] == kAlive) {
-                const int32_t s = sup[e];
-                if (s <= L) { hit = true; stamp[e] = r; truss[e] = L + 2; }
-                else lmin = min(lmin, s);
-            }
-            wave_append(hit, (int32_t)e, q, &ctrl->tail[cv.cur_sel]);
-        }
-        lmin = wave_min(lmin);
-        if (lane == 0 && lmin != 0x7FFFFFFF) atomicMin(&ctrl->next_min, lmin);
-    } else {
-        const int32_t *q = cv.cur_sel ? q1 : q0;
-        int32_t *qn = cv.cur_sel ? q0 : q1;
-        uint32_t *tail_n = &ctrl->tail[cv.cur_sel ^ 1];
-        const int w = (int)(threadIdx.x >> 6);
-        uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w];
-        int32_t *s_edge = sh_edge[w];
-        const int64_t cnt = (int64_t)cv.cur_count;
-        for (int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) - lane; base < cnt; base += nthreads) {
-            // 64 frontier edges per wave: inclusive prefix sum of their slice lengths
-            const int64_t idx = base + lane;
-            int32_t ef = -1;
-            uint32_t beg = 0, len = 0;
-            if (idx < cnt) { ef = q[idx]; beg = off[ef]; len = off[ef + 1] - beg; }
-            uint32_t incl = len;
-            for (int o = 1; o < kWave; o <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-                if (lane >= o) incl += t;
-            }
-            const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
-            __builtin_amdgcn_wave_barrier();
-            s_end[lane] = incl; s_beg[lane] = beg; s_edge[lane] = ef;
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
-                const uint32_t it = it0 + (uint32_t)lane;
-                bool tx = false, ty = false;
-                int32_t x = -1, y = -1;
-                if (it < total) {
-                    int lo = 0, hi = kWave - 1;                 // smallest t with s_end[t] > it
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_end[mid] > it) hi = mid; else lo = mid + 1;
-                    }
-                    const uint32_t first = lo ? s_end[lo - 1] : 0u;
-                    const int32_t me = s_edge[lo];
-                    const int2 p = inc[s_beg[lo] + (it - first)];
-                    x = p.x; y = p.y;
-                    const int32_t sx = stamp[x], sy = stamp[y];
-                    if (sx >= r && sy >= r) {                   // both other edges still present
-                        const bool xin = (sx == r), yin = (sy == r);
-                        const bool decx = !xin && (!yin || me < y);
-                        const bool decy = !yin && (!xin || me < x);
-                        if (decx && atomicSub(&sup[x], 1) == L + 1) { tx = true; stamp[x] = r + 1; truss[x] = L + 2; }
-                        if (decy && atomicSub(&sup[y], 1) == L + 1) { ty = true; stamp[y] = r + 1; truss[y] = L + 2; }
-                    }
-                }
-                wave_append(tx, x, qn, tail_n);
-                wave_append(ty, y, qn, tail_n);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+    __device__ __forceinline__ bool live_below(uint32_t e, int L, int32_t &key) const
+    {
+        if (stamp[e] != kAlive) { key = 0x7FFFFFFF; return false; }
+        key = sup[e];
+        return key <= L;
     }
-    finalize_launch(ctrl, cv);
-}
+    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const
+    {
+        stamp[e] = cv.round;
+        truss[e] = cv.level + 2;
+    }
+    __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
+    {
+        b = off[e];
+        len = off[e + 1] - b;
+    }
+    __device__ __forceinline__ void item(int32_t me, uint32_t pos, const CtrlView &cv, int32_t &t0, int32_t &t1) const
+    {
+        const int2 p = inc[pos];
+        const int32_t x = p.x, y = p.y, r = cv.round, L = cv.level;
+        const int32_t sx = stamp[x], sy = stamp[y];
+        if (sx < r || sy < r) return;                   // an edge of the triangle is already gone
+        const bool xin = (sx == r), yin = (sy == r);
+        const bool decx = !xin && (!yin || me < y);
+        const bool decy = !yin && (!xin || me < x);
+        if (decx && atomicSub(&sup[x], 1) == L + 1) { stamp[x] = r + 1; truss[x] = L + 2; t0 = x; }
+        if (decy && atomicSub(&sup[y], 1) == L + 1) { stamp[y] = r + 1; truss[y] = L + 2; t1 = y; }
+    }
+};
 
 // -------------------------------------------------------------- result gather
 // One wavefront per row of the working CSR; upper slots (u < v) in row order
@@ -282,9 +246,10 @@ __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__r
 __global__ __launch_bounds__(kBlock) void k_graph_moments(const int32_t *__restrict__ deg, int64_t nv,
                                                           const int32_t *__restrict__ osrc, const int32_t *__restrict__ ocol,
                                                           int64_t m, const uint32_t *__restrict__ cnt,
-                                                          unsigned long long *out /*[4]: sum d^2, sum min, max d, sum cnt*/)
+                                                          const uint32_t *__restrict__ orow,
+                                                          unsigned long long *out /*[5]: sum d^2, sum min, max d, sum cnt, sum d+ + d+*/)
 {
-    unsigned long long s2 = 0, smin = 0, mx = 0, sc = 0;
+    unsigned long long s2 = 0, smin = 0, mx = 0, sc = 0, so = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
         const unsigned long long d = (unsigned long long)deg[i];
         s2 += d * d;
@@ -292,18 +257,20 @@ __global__ __launch_bounds__(kBlock) void k_graph_moments(const int32_t *__restr
     }
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock)
     {
-        smin += (unsigned long long)min(deg[osrc[e]], deg[ocol[e]]);
+        const int32_t a = osrc[e], b = ocol[e];
+        smin += (unsigned long long)min(deg[a], deg[b]);
         sc += (unsigned long long)cnt[e];
+        so += (unsigned long long)(orow[a + 1] - orow[a]) + (unsigned long long)(orow[b + 1] - orow[b]);
     }
     for (int o = 32; o > 0; o >>= 1) {
-        s2 += __shfl_xor(s2, o); smin += __shfl_xor(smin, o); sc += __shfl_xor(sc, o);
+        s2 += __shfl_xor(s2, o); smin += __shfl_xor(smin, o); sc += __shfl_xor(sc, o); so += __shfl_xor(so, o);
         const unsigned long long t = __shfl_xor(mx, o); mx = t > mx ? t : mx;
     }
-    if (lane_id() == 0) { atomicAdd(&out[0], s2); atomicAdd(&out[1], smin); atomicMax(&out[2], mx); atomicAdd(&out[3], sc); }
+    if (lane_id() == 0) { atomicAdd(&out[0], s2); atomicAdd(&out[1], smin); atomicMax(&out[2], mx); atomicAdd(&out[3], sc); atomicAdd(&out[4], so); }
 }
 
 struct DevBufs {                                    // frees everything it still owns
-    static constexpr int kMax = 32;
+    static constexpr int kMax = 48;
     void *p[kMax]; int n = 0;
     template <class T> hipError_t alloc(T **out, size_t count)
     {
@@ -415,13 +382,13 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     // the 32-bit slice offsets must not wrap: take the 64-bit total first
     {
         unsigned long long *d_mom = nullptr;
-        KOMB_HIP(ctx, bufs.alloc(&d_mom, 4));
-        KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 4 * sizeof(unsigned long long), s));
-        k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_cnt, d_mom);
-        unsigned long long mom[4];
+        KOMB_HIP(ctx, bufs.alloc(&d_mom, 5));
+        KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 5 * sizeof(unsigned long long), s));
+        k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_cnt, d_orow, d_mom);
+        unsigned long long mom[5];
         KOMB_HIP(ctx, d2h(ctx, mom, d_mom, sizeof(mom)));
         st.sum_deg_sq = (int64_t)mom[0]; st.wedge_items = (int64_t)mom[1]; st.max_degree = (int32_t)mom[2];
-        st.triangles = (int64_t)(mom[3] / 3);
+        st.triangles = (int64_t)(mom[3] / 3); st.oriented_items = (int64_t)mom[4];
         bufs.release(d_mom);
         if (mom[3] > 0xFFFFFFF0ull)
             KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %llu triangles; the incidence index is limited to 2^32-16 entries (3 per triangle)",
@@ -440,21 +407,27 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     bufs.release(d_cnt);
 
     // ---- peel
-    int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr, *d_q0 = nullptr, *d_q1 = nullptr;
-    PeelCtrl *d_ctrl = nullptr;
+    int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
+    PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
+    PeelQueues Q{{nullptr, nullptr}, {nullptr, nullptr}};
+    const size_t heavy_cap = (size_t)total / 48 + 64;
     KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
-    KOMB_HIP(ctx, bufs.alloc(&d_q0, (size_t)m));
-    KOMB_HIP(ctx, bufs.alloc(&d_q1, (size_t)m));
+    for (int i = 0; i < 2; ++i) {
+        KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&Q.heavy[i], heavy_cap));
+    }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kMaxGroups));
+    TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
     ctx->timer.start(s);
     k_peel_init<<<ge, kBlock, 0, s>>>(m, d_off, d_sup, d_stamp);
-    peel_ctrl_init(s, d_ctrl, (uint32_t)m);
-    const int gp = grid_for(m, kBlock, 2048);
+    peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m);
+    const int gp = peel_grid(m);
     int launches = 0;
     int rc = drive_peel(ctx, d_ctrl, m, [&]() {
-        k_truss_step<<<gp, kBlock, 0, s>>>(d_ctrl, d_off, d_inc, d_sup, d_stamp, d_truss, d_q0, d_q1, m);
+        k_peel_step<TrussProblem><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
     }, &launches);
     st.ms_peel = ctx->timer.stop(s);
     KOMB_TRY(rc);
@@ -464,7 +437,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     st.truss_launches = launches;
     st.truss_scans = ctx->h_ctrl[0].n_scans;
     st.max_trussness = ctx->h_ctrl[0].max_level + 2;
-    bufs.release(d_q0); bufs.release(d_q1); bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc);
+    for (int i = 0; i < 2; ++i) { bufs.release(Q.light[i]); bufs.release(Q.heavy[i]); }
+    bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc);
 
     // ---- canonical-order results with original vertex ids
     uint32_t *d_ucnt = nullptr, *d_ebase = nullptr;

@@ -1,4 +1,28 @@
-// peel_dev.h -- device-side helpers shared by the k-core and k-truss peels.
+// peel_dev.h -- the level-synchronous peel engine shared by k-core and k-truss.
+//
+// A peel problem P has `units` (vertices / edges), each with a live integer key
+// (degree / support) and a slice of `items` (CSR row / triangle incidence
+// slice).  Peeling a unit walks its slice; each item may decrement other
+// units' keys, and the decrement that lands a unit exactly on the current
+// level "triggers" it into the next sub-round's frontier.
+//
+// One kernel, k_peel_step<P>, is launched over and over; what a launch does is
+// decided on the device from the control block its predecessor finalised:
+//   SCAN    : two passes over all units.  Pass A counts, per wave, the live
+//             units with key <= level; one atomic per WORKGROUP reserves queue
+//             space; pass B re-evaluates the same predicate and writes the
+//             queue entries at wave-private offsets (no append atomics at all).
+//   PROCESS : the frontier lives in two queues.  "Light" units (<= kLight
+//             items) are taken 64 per wavefront and their slices flattened
+//             across the lanes (prefix sum in LDS + binary search), so lanes
+//             stay busy on power-law slices; "heavy" units are pre-split into
+//             kChunk-item chunks, each its own queue entry, so a hub row or a
+//             hub edge's 10^4 triangles spread over hundreds of wavefronts
+//             instead of serialising one.  Triggered units are staged in a
+//             per-wave LDS buffer and flushed with one atomic per ~100 entries.
+// The last workgroup to finish (two-level arrival ticket: 32 workgroups per
+// group counter, then one top counter, so no word sees more than ~32 serial
+// atomics) rewrites the control block for the next launch.
 #pragma once
 
 #include "common.h"
@@ -7,101 +31,348 @@ namespace komb {
 
 enum : int32_t { MODE_SCAN = 0, MODE_PROCESS = 1 };
 
-struct CtrlView {                       // what one launch needs from the control block
+constexpr int kPeelBlock = 1024;               // 16 wave64 per workgroup
+constexpr int kPeelWaves = kPeelBlock / kWave;
+constexpr int kLight = 64;                     // units with <= kLight items are flattened 64 per wave
+constexpr int kChunk = 256;                    // heavy units: one queue entry per kChunk items
+constexpr int kStage = 192;                    // per-wave LDS staging of triggered light units
+constexpr int kGroup = 32;                     // workgroups per first-level arrival counter
+constexpr int kMaxGroups = 64;                 // grid <= kGroup * kMaxGroups
+
+struct CtrlView {                              // launch-stable part of the control block
     int32_t mode, level, round, done, cur_sel;
-    uint32_t cur_count;
+    uint32_t cur_light, cur_heavy;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-
-__device__ __forceinline__ uint64_t lanemask_lt()
-{
-    return (1ull << lane_id()) - 1ull;
-}
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // Coherent read of a word other workgroups update with atomics in this launch.
 __device__ __forceinline__ uint32_t coherent_load(uint32_t *p) { return atomicAdd(p, 0u); }
 __device__ __forceinline__ int32_t coherent_load(int32_t *p) { return atomicAdd(p, 0); }
-
-// Every workgroup loads the launch-stable fields once.
-__device__ __forceinline__ CtrlView load_ctrl(const PeelCtrl *ctrl, CtrlView *sh)
-{
-    if (threadIdx.x == 0) {
-        sh->mode = ctrl->mode; sh->level = ctrl->level; sh->round = ctrl->round;
-        sh->done = ctrl->done; sh->cur_sel = ctrl->cur_sel; sh->cur_count = ctrl->cur_count;
-    }
-    __syncthreads();
-    return *sh;
-}
-
-// Wave-aggregated append of `val` (for lanes with `pred`) to queue `q` whose
-// cursor is `tail`: one atomic per wave, order inside the wave preserved.
-// Must be reached by all 64 lanes.
-__device__ __forceinline__ void wave_append(bool pred, int32_t val, int32_t *q, uint32_t *tail)
-{
-    const uint64_t m = __ballot(pred);
-    if (m == 0) return;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane_id() == leader) base = atomicAdd(tail, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader);
-    if (pred) q[base + (uint32_t)__popcll(m & lanemask_lt())] = val;
-}
 
 __device__ __forceinline__ int32_t wave_min(int32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
     return v;
 }
-
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
     return v;
 }
-
-// The last workgroup to finish a launch rewrites the control block for the
-// next launch.  remaining counts units that have not entered a frontier yet:
-// SCAN subtracts what it collected, PROCESS subtracts what it triggered (the
-// next queue's length plus ctrl->acc, the units a wave peeled on the spot).
-__device__ __forceinline__ void finalize_launch(PeelCtrl *ctrl, const CtrlView &cv)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
+    const int lane = lane_id();
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+struct PeelQueues {
+    int32_t *light[2];       // unit ids
+    int2 *heavy[2];          // (unit id, chunk index)
+};
+
+// ---------------------------------------------------------------- appenders
+// All of these must be reached by all 64 lanes of the wave.
+
+// `pred` lanes append `val` at wave-private position base + running offset (SCAN pass B).
+__device__ __forceinline__ void wave_write_ordered(bool pred, int32_t val, int32_t *q, uint32_t base, uint32_t &run)
+{
+    const uint64_t m = __ballot(pred);
+    if (pred) q[base + run + (uint32_t)__popcll(m & lanemask_lt())] = val;
+    run += (uint32_t)__popcll(m);
+}
+
+// heavy units of `pred` lanes: every chunk becomes one (unit, chunk) entry, written by the whole wave
+__device__ __forceinline__ void wave_write_chunks(bool pred, int32_t unit, uint32_t nchunks, int2 *q, uint32_t base, uint32_t &run)
+{
+    uint64_t m = __ballot(pred);
+    const int lane = lane_id();
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int32_t u = __shfl(unit, src);
+        const uint32_t n = (uint32_t)__shfl((int)nchunks, src);
+        for (uint32_t c = (uint32_t)lane; c < n; c += kWave) q[base + run + c] = make_int2(u, (int)c);
+        run += n;
+    }
+}
+
+// PROCESS: staged append of triggered units.  Light units collect in the wave's LDS buffer.
+struct WaveStage {
+    int32_t *buf;            // [kStage] in LDS, private to the wave
+    uint32_t n;              // wave-uniform fill
+};
+__device__ __forceinline__ void stage_flush(WaveStage &st, int32_t *q, uint32_t *tail)
+{
+    if (st.n == 0) return;
+    const int lane = lane_id();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(tail, st.n);
+    base = (uint32_t)__shfl((int)base, 0);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = (uint32_t)lane; i < st.n; i += kWave) q[base + i] = st.buf[i];
+    __builtin_amdgcn_wave_barrier();
+    st.n = 0;
+}
+__device__ __forceinline__ void stage_push(WaveStage &st, bool pred, int32_t val, int32_t *q, uint32_t *tail)
+{
+    const uint64_t m = __ballot(pred);
+    if (m == 0) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (st.n + cnt > (uint32_t)kStage) stage_flush(st, q, tail);
+    if (pred) st.buf[st.n + (uint32_t)__popcll(m & lanemask_lt())] = val;
+    st.n += cnt;
+}
+__device__ __forceinline__ void heavy_push(bool pred, int32_t unit, uint32_t nchunks, int2 *q, uint32_t *tail)
+{
+    uint64_t m = __ballot(pred);
+    const int lane = lane_id();
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int32_t u = __shfl(unit, src);
+        const uint32_t n = (uint32_t)__shfl((int)nchunks, src);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(tail, n);
+        base = (uint32_t)__shfl((int)base, 0);
+        for (uint32_t c = (uint32_t)lane; c < n; c += kWave) q[base + c] = make_int2(u, (int)c);
+    }
+}
+
+// ------------------------------------------------------------ the step kernel
+// Problem concept (all __device__):
+//   uint32_t units;
+//   bool live_below(u, L, int32_t &key)  true when unit u is live and its key <= L; key is set
+//                                        (to 0x7FFFFFFF for a dead unit) so the caller can track the minimum
+//   void mark_scanned(u, cv)             unit enters the frontier through SCAN
+//   void slice(u, uint32_t &begin, uint32_t &len)
+//   void item(unit, pos, cv, int32_t &t0, int32_t &t1)   process one item; ids of triggered units or -1
+template <class P>
+__global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p)
+{
+    __shared__ CtrlView sh_cv;
+    __shared__ uint32_t sh_w[kPeelWaves][4];           // per-wave counts / bases
+    __shared__ uint32_t sh_base[2];
+    __shared__ int32_t sh_min[kPeelWaves];
+    __shared__ uint32_t sh_end[kPeelWaves][kWave];
+    __shared__ uint32_t sh_beg[kPeelWaves][kWave];
+    __shared__ int32_t sh_unit[kPeelWaves][kWave];
+    __shared__ int32_t sh_stage[kPeelWaves][kStage];
+
+    if (threadIdx.x == 0) {
+        sh_cv.mode = ctrl->mode; sh_cv.level = ctrl->level; sh_cv.round = ctrl->round; sh_cv.done = ctrl->done;
+        sh_cv.cur_sel = ctrl->cur_sel; sh_cv.cur_light = ctrl->cur_light; sh_cv.cur_heavy = ctrl->cur_heavy;
+    }
+    __syncthreads();
+    const CtrlView cv = sh_cv;
+    if (cv.done) return;
+
+    // workgroups that take part in this launch (the rest leave without touching the ticket)
+    uint32_t nblk = gridDim.x;
+    if (cv.mode == MODE_PROCESS) {
+        const uint64_t wave_jobs = ((uint64_t)cv.cur_light + kWave - 1) / kWave + (uint64_t)cv.cur_heavy;
+        const uint64_t need = (wave_jobs + kPeelWaves - 1) / kPeelWaves;
+        nblk = (uint32_t)(need < 1 ? 1 : (need > gridDim.x ? gridDim.x : need));
+    }
+    if (blockIdx.x >= nblk) return;
+
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    const int L = cv.level;
+    const int sel = cv.cur_sel;
+
+    if (cv.mode == MODE_SCAN) {
+        // ---- pass A: count this wave's light hits, its heavy units' chunks, and all hits
+        uint32_t n_light = 0, n_chunks = 0, n_hits = 0;    // n_light / n_hits wave-uniform, n_chunks per lane
+        int32_t lmin = 0x7FFFFFFF;
+        const uint32_t units = p.units;
+        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < units; base += (uint64_t)nblk * kPeelBlock) {
+            const uint64_t u = base + (uint64_t)lane;
+            bool hit = false, light = false;
+            if (u < units) {
+                int32_t key;
+                if (p.live_below((uint32_t)u, L, key)) {
+                    hit = true;
+                    uint32_t b, len;
+                    p.slice((uint32_t)u, b, len);
+                    if (len <= (uint32_t)kLight) light = len > 0;
+                    else n_chunks += (len + kChunk - 1) / kChunk;
+                } else lmin = min(lmin, key);
+            }
+            n_light += (uint32_t)__popcll(__ballot(light));
+            n_hits += (uint32_t)__popcll(__ballot(hit));
+        }
+        n_chunks = wave_sum(n_chunks);
+        lmin = wave_min(lmin);
+        if (lane == 0) { sh_w[w][0] = n_light; sh_w[w][1] = n_chunks; sh_w[w][2] = n_hits; sh_min[w] = lmin; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tl = 0, th = 0, hits = 0;
+            int32_t bmin = 0x7FFFFFFF;
+            for (int i = 0; i < kPeelWaves; ++i) {
+                const uint32_t a = sh_w[i][0], b = sh_w[i][1];
+                sh_w[i][0] = tl; sh_w[i][1] = th;          // exclusive offsets inside the workgroup's reservation
+                tl += a; th += b; hits += sh_w[i][2];
+                bmin = min(bmin, sh_min[i]);
+            }
+            sh_base[0] = tl ? atomicAdd(&ctrl->tail_l[sel], tl) : 0u;
+            sh_base[1] = th ? atomicAdd(&ctrl->tail_h[sel], th) : 0u;
+            if (hits) atomicAdd(&ctrl->acc, hits);
+            if (bmin != 0x7FFFFFFF) atomicMin(&ctrl->next_min, bmin);
+        }
+        __syncthreads();
+        // ---- pass B: same predicate on unchanged state, write the entries
+        const uint32_t base_l = sh_base[0] + sh_w[w][0], base_h = sh_base[1] + sh_w[w][1];
+        uint32_t run_l = 0, run_h = 0;
+        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < units; base += (uint64_t)nblk * kPeelBlock) {
+            const uint64_t u = base + (uint64_t)lane;
+            bool light = false, heavy = false;
+            uint32_t nch = 0;
+            if (u < units) {
+                int32_t key;
+                if (p.live_below((uint32_t)u, L, key)) {
+                    uint32_t b, len;
+                    p.slice((uint32_t)u, b, len);
+                    if (len <= (uint32_t)kLight) light = len > 0;
+                    else { heavy = true; nch = (len + kChunk - 1) / kChunk; }
+                    p.mark_scanned((uint32_t)u, cv);
+                }
+            }
+            wave_write_ordered(light, (int32_t)u, Q.light[sel], base_l, run_l);
+            if (__ballot(heavy)) wave_write_chunks(heavy, (int32_t)u, nch, Q.heavy[sel], base_h, run_h);
+        }
+    } else {
+        // ---- PROCESS
+        int32_t *qn_l = Q.light[sel ^ 1];
+        int2 *qn_h = Q.heavy[sel ^ 1];
+        uint32_t *tail_nl = &ctrl->tail_l[sel ^ 1], *tail_nh = &ctrl->tail_h[sel ^ 1];
+        WaveStage st{sh_stage[w], 0u};
+        uint32_t n_trig = 0;                                // wave-uniform
+        const uint64_t gw = (uint64_t)blockIdx.x * kPeelWaves + (uint64_t)w;
+        const uint64_t nw = (uint64_t)nblk * kPeelWaves;
+
+        auto run_item = [&](bool active, int32_t unit, uint32_t pos) {
+            int32_t t0 = -1, t1 = -1;
+            if (active) p.item(unit, pos, cv, t0, t1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int32_t t = k ? t1 : t0;
+                const bool trig = t >= 0;
+                const uint64_t m = __ballot(trig);
+                if (m == 0) continue;
+                n_trig += (uint32_t)__popcll(m);
+                uint32_t b = 0, len = 0;
+                if (trig) p.slice((uint32_t)t, b, len);
+                const bool is_light = trig && len <= (uint32_t)kLight;
+                const bool is_heavy = trig && len > (uint32_t)kLight;
+                stage_push(st, is_light, t, qn_l, tail_nl);
+                if (__ballot(is_heavy)) heavy_push(is_heavy, t, (len + kChunk - 1) / kChunk, qn_h, tail_nh);
+            }
+        };
+
+        // light units: 64 per wave, slices flattened over the lanes
+        const uint64_t n_batches = ((uint64_t)cv.cur_light + kWave - 1) / kWave;
+        uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w];
+        int32_t *s_unit = sh_unit[w];
+        for (uint64_t bt = gw; bt < n_batches; bt += nw) {
+            const uint64_t idx = bt * kWave + (uint64_t)lane;
+            int32_t unit = -1;
+            uint32_t beg = 0, len = 0;
+            if (idx < cv.cur_light) { unit = Q.light[sel][idx]; p.slice((uint32_t)unit, beg, len); }
+            const uint32_t incl = wave_incl_scan(len);
+            const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+            __builtin_amdgcn_wave_barrier();
+            s_end[lane] = incl; s_beg[lane] = beg; s_unit[lane] = unit;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
+                const uint32_t it = it0 + (uint32_t)lane;
+                const bool active = it < total;
+                int32_t me = -1;
+                uint32_t pos = 0;
+                if (active) {
+                    int lo = 0, hi = kWave - 1;             // smallest t with s_end[t] > it
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_end[mid] > it) hi = mid; else lo = mid + 1;
+                    }
+                    const uint32_t first = lo ? s_end[lo - 1] : 0u;
+                    me = s_unit[lo];
+                    pos = s_beg[lo] + (it - first);
+                }
+                run_item(active, me, pos);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // heavy chunks: one entry per wave visit, kChunk items each
+        for (uint64_t h = gw; h < (uint64_t)cv.cur_heavy; h += nw) {
+            const int2 ent = Q.heavy[sel][h];
+            uint32_t beg, len;
+            p.slice((uint32_t)ent.x, beg, len);
+            const uint32_t c0 = (uint32_t)ent.y * kChunk;
+            const uint32_t c1 = min(len, c0 + (uint32_t)kChunk);
+            for (uint32_t it0 = c0; it0 < c1; it0 += kWave) {
+                const uint32_t it = it0 + (uint32_t)lane;
+                run_item(it < c1, ent.x, beg + it);
+            }
+        }
+        stage_flush(st, qn_l, tail_nl);
+        if (lane == 0) sh_w[w][3] = n_trig;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int i = 0; i < kPeelWaves; ++i) t += sh_w[i][3];
+            if (t) atomicAdd(&ctrl->acc, t);
+        }
+    }
+
+    // ---- arrival ticket (two levels) and control-block rewrite by the last workgroup
     __syncthreads();
     if (threadIdx.x != 0) return;
     __threadfence();
-    const uint32_t ticket = atomicAdd(&ctrl->blocks_done, 1u);
-    if (ticket != gridDim.x - 1) return;
+    const uint32_t grp = blockIdx.x / kGroup;
+    const uint32_t ngrp = (nblk + kGroup - 1) / kGroup;
+    const uint32_t grp_size = (grp == ngrp - 1) ? (nblk - grp * kGroup) : (uint32_t)kGroup;
+    if (atomicAdd(&grp_done[grp], 1u) != grp_size - 1) return;
+    atomicExch(&grp_done[grp], 0u);
     __threadfence();
-    int32_t mode = cv.mode, level = cv.level, round = cv.round, done = 0, sel = cv.cur_sel;
-    uint32_t cur = cv.cur_count, remaining = ctrl->remaining;
+    if (atomicAdd(&ctrl->blocks_done, 1u) != ngrp - 1) return;
+    atomicExch(&ctrl->blocks_done, 0u);
+    __threadfence();
+
+    int32_t mode = cv.mode, level = cv.level, round = cv.round, done = 0, nsel = sel;
+    uint32_t cur_l = 0, cur_h = 0, remaining = ctrl->remaining;
+    const uint32_t acc = atomicExch(&ctrl->acc, 0u);
+    remaining -= acc;
     if (mode == MODE_SCAN) {
         ctrl->n_scans += 1;
-        const uint32_t cnt = coherent_load(&ctrl->tail[sel]);
-        if (cnt > 0) {
-            mode = MODE_PROCESS; cur = cnt; remaining -= cnt;
-            ctrl->n_levels += 1; ctrl->max_level = level;
-        } else if (remaining == 0) {
-            done = 1;
-        } else {
-            level = coherent_load(&ctrl->next_min);        // first populated level above
-            if (level == 0x7FFFFFFF) done = 2;             // live units but no live key: inconsistent state
-        }
-        atomicExch(&ctrl->next_min, 0x7FFFFFFF);
+        cur_l = coherent_load(&ctrl->tail_l[sel]);
+        cur_h = coherent_load(&ctrl->tail_h[sel]);
+        const int32_t nmin = atomicExch(&ctrl->next_min, 0x7FFFFFFF);
+        if (acc > 0) { ctrl->n_levels += 1; ctrl->max_level = level; }
+        if (cur_l + cur_h > 0) mode = MODE_PROCESS;
+        else if (remaining == 0) done = 1;
+        else if (acc > 0) level += 1;                       // only item-less units at this level
+        else if (nmin == 0x7FFFFFFF) done = 2;              // live units but no live key: inconsistent
+        else level = nmin;                                  // jump to the first populated level
     } else {
         ctrl->n_rounds += 1;
-        const uint32_t ncnt = coherent_load(&ctrl->tail[sel ^ 1]);
-        remaining -= coherent_load(&ctrl->acc) + ncnt;
-        atomicExch(&ctrl->acc, 0u);
-        atomicExch(&ctrl->tail[sel], 0u);
-        sel ^= 1; cur = ncnt; round += 1;
-        if (ncnt == 0) {
+        cur_l = coherent_load(&ctrl->tail_l[sel ^ 1]);
+        cur_h = coherent_load(&ctrl->tail_h[sel ^ 1]);
+        atomicExch(&ctrl->tail_l[sel], 0u);
+        atomicExch(&ctrl->tail_h[sel], 0u);
+        nsel = sel ^ 1; round += 1;
+        if (cur_l + cur_h == 0) {
             if (remaining == 0) done = 1;
             else { level += 1; mode = MODE_SCAN; }
         }
     }
     ctrl->mode = mode; ctrl->level = level; ctrl->round = round; ctrl->done = done;
-    ctrl->cur_sel = sel; ctrl->cur_count = cur; ctrl->remaining = remaining;
-    atomicExch(&ctrl->blocks_done, 0u);
+    ctrl->cur_sel = nsel; ctrl->cur_light = cur_l; ctrl->cur_heavy = cur_h; ctrl->remaining = remaining;
     __threadfence();
 }
 
