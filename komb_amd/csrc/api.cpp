@@ -67,6 +67,7 @@ void komb_destroy(komb_ctx *ctx)
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->device);
         graph_free(ctx);
+        ctx->pool.clear();
         ctx->timer.destroy();
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
     }

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "komb_accel.h"
 
@@ -58,8 +59,51 @@ struct Timer {                               // HIP-event stopwatch on one strea
 
 } // namespace komb
 
+// Caching device allocator: a step's scratch buffers are returned to the pool,
+// not to the driver, so steady-state steps perform no hipMalloc / hipFree.
+struct DevPool {
+    struct Block { void *p; size_t bytes; bool used; };
+    std::vector<Block> blocks;
+    hipError_t get(void **out, size_t bytes)
+    {
+        if (bytes == 0) bytes = 16;
+        int best = -1;
+        for (int i = 0; i < (int)blocks.size(); ++i)
+            if (!blocks[i].used && blocks[i].bytes >= bytes && blocks[i].bytes <= bytes + bytes / 4 + 4096 &&
+                (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = i;
+        if (best >= 0) { blocks[best].used = true; *out = blocks[best].p; return hipSuccess; }
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) {                       // give cached blocks back and retry once
+            trim();
+            e = hipMalloc(&q, bytes);
+            if (e != hipSuccess) return e;
+        }
+        blocks.push_back({q, bytes, true});
+        *out = q;
+        return hipSuccess;
+    }
+    void put(void *p)
+    {
+        if (!p) return;
+        for (auto &b : blocks) if (b.p == p) { b.used = false; return; }
+    }
+    void trim()                                      // free every unused block
+    {
+        std::vector<Block> keep;
+        for (auto &b : blocks) { if (b.used) keep.push_back(b); else (void)hipFree(b.p); }
+        blocks.swap(keep);
+    }
+    void clear()
+    {
+        for (auto &b : blocks) (void)hipFree(b.p);
+        blocks.clear();
+    }
+};
+
 struct komb_ctx {
     komb_opts opts{};
+    DevPool pool;
     std::string err;
     bool device_ok = false;
     int device = 0;

@@ -101,6 +101,7 @@ void graph_free(komb_ctx *ctx)
     ctx->d_rowptr = nullptr; ctx->d_col = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
     truss_free(ctx);
+    ctx->pool.clear();                                   // scratch sized for the old graph
 }
 
 int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv)

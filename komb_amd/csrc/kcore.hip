@@ -99,14 +99,14 @@ int core_run(komb_ctx *ctx)
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
     PeelQueues Q{{nullptr, nullptr}, {nullptr, nullptr}};
     auto cleanup = [&]() {
-        if (d_degw) (void)hipFree(d_degw); if (d_ctrl) (void)hipFree(d_ctrl); if (d_grp) (void)hipFree(d_grp);
-        for (int i = 0; i < 2; ++i) { if (Q.light[i]) (void)hipFree(Q.light[i]); if (Q.heavy[i]) (void)hipFree(Q.heavy[i]); }
+        ctx->pool.put(d_degw); ctx->pool.put(d_ctrl); ctx->pool.put(d_grp);
+        for (int i = 0; i < 2; ++i) { ctx->pool.put(Q.light[i]); ctx->pool.put(Q.heavy[i]); }
     };
-    hipError_t e = hipMalloc(&d_degw, (size_t)nv * sizeof(int32_t));
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&Q.light[i], (size_t)nv * sizeof(int32_t));
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&Q.heavy[i], heavy_cap * sizeof(int2));
-    if (e == hipSuccess) e = hipMalloc(&d_ctrl, sizeof(PeelCtrl));
-    if (e == hipSuccess) e = hipMalloc(&d_grp, kMaxGroups * sizeof(uint32_t));
+    hipError_t e = ctx->pool.get((void **)&d_degw, (size_t)nv * sizeof(int32_t));
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.light[i], (size_t)nv * sizeof(int32_t));
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.heavy[i], heavy_cap * sizeof(int2));
+    if (e == hipSuccess) e = ctx->pool.get((void **)&d_ctrl, sizeof(PeelCtrl));
+    if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, kMaxGroups * sizeof(uint32_t));
     if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
 
     int64_t g = (nv + kBlock - 1) / kBlock;

@@ -94,49 +94,148 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 }
 
 // ------------------------------------------------------ triangle enumeration
-// One thread per oriented edge e = (a -> b): sorted merge of N+(a) and N+(b).
-// A common out-neighbour w at slots i (row a) and j (row b) is the triangle
-// {e, i, j} in internal edge ids.  FILL=false: count supports.  FILL=true:
-// write each edge's (other, other) pair at its cursor.
+// Every triangle {a,b,w}, a -> b -> w in (degree,id) order, is found exactly
+// once, from its oriented edge e = (a->b), as a common out-neighbour w of a and
+// b.  With i = slot of w in row a and j = slot of w in row b the triangle is
+// {e, i, j} in internal edge ids.
+//
+// One wavefront owns kTriV consecutive source vertices.  Their oriented rows
+// are one contiguous range [S0,S1) of ocol, staged in LDS together with one
+// counter per slot.  The probe items -- every element of N+(b) for every owned
+// edge (a->b) -- are flattened over the 64 lanes (prefix sum + binary search in
+// LDS); each item is looked up in the staged row of a by binary search in LDS.
+// Of a triangle's three edges, e and i belong to the owned rows, so their
+// counts / write cursors are LDS atomics private to the wave; only j needs a
+// global atomic.  FILL=false counts supports (own[] by plain stores, other[] by
+// atomics); FILL=true writes each edge's incidence pairs: own-role entries at
+// off[x] + LDS cursor, j-role entries at the global cursor (initialised to
+// off[x] + own[x]).  Tasks whose rows exceed the LDS budget fall back to global
+// binary search and global atomics for all three roles.
+constexpr int kTriV = 16;
+constexpr int kTriCap = 512;
+constexpr int kTriWaves = kBlock / kWave;
+
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
-                                                      const int32_t *__restrict__ osrc, int64_t m,
-                                                      uint32_t *sup_or_cursor, int2 *__restrict__ inc)
+                                                      int64_t nv, uint32_t *__restrict__ own, uint32_t *other_or_cursor,
+                                                      const uint32_t *__restrict__ off, int2 *__restrict__ inc)
 {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
-        const int32_t a = osrc[e], b = ocol[e];
-        uint32_t i = orow[a], j = orow[b];
-        const uint32_t ie = orow[a + 1], je = orow[b + 1];
-        if (i == ie || j == je) continue;
-        uint32_t cnt = 0;
-        int32_t x = ocol[i], y = ocol[j];
-        for (;;) {
-            if (x == y) {
-                if (FILL) {
-                    const uint32_t pe = atomicAdd(&sup_or_cursor[e], 1u);
-                    const uint32_t pi = atomicAdd(&sup_or_cursor[i], 1u);
-                    const uint32_t pj = atomicAdd(&sup_or_cursor[j], 1u);
-                    inc[pe] = make_int2((int)i, (int)j);
-                    inc[pi] = make_int2((int)e, (int)j);
-                    inc[pj] = make_int2((int)e, (int)i);
-                } else {
-                    ++cnt;
-                    atomicAdd(&sup_or_cursor[i], 1u);
-                    atomicAdd(&sup_or_cursor[j], 1u);
+    __shared__ int32_t sh_col[kTriWaves][kTriCap];
+    __shared__ uint32_t sh_cnt[kTriWaves][kTriCap];
+    __shared__ uint32_t sh_orow[kTriWaves][kTriV + 1];
+    __shared__ uint32_t sh_pref[kTriWaves][kWave];
+    __shared__ uint32_t sh_rb0[kTriWaves][kWave];
+    __shared__ uint32_t sh_ra0[kTriWaves][kWave];
+    __shared__ uint32_t sh_ra1[kTriWaves][kWave];
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    int32_t *s_col = sh_col[w];
+    uint32_t *s_cnt = sh_cnt[w], *s_orow = sh_orow[w], *s_pref = sh_pref[w];
+    uint32_t *s_rb0 = sh_rb0[w], *s_ra0 = sh_ra0[w], *s_ra1 = sh_ra1[w];
+    const int64_t ntasks = (nv + kTriV - 1) / kTriV;
+    const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+
+    for (int64_t task = gw; task < ntasks; task += nw) {
+        const int64_t v0 = task * kTriV;
+        const int nvt = (int)min((int64_t)kTriV, nv - v0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane <= nvt) s_orow[lane] = orow[v0 + lane];
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t S0 = s_orow[0], S1 = s_orow[nvt];
+        const uint32_t E = S1 - S0;
+        if (E == 0) continue;
+        const bool staged = E <= (uint32_t)kTriCap;
+        if (staged)
+            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { s_col[k] = ocol[S0 + k]; s_cnt[k] = 0u; }
+        __builtin_amdgcn_wave_barrier();
+
+        for (uint32_t p0 = 0; p0 < E; p0 += kWave) {
+            // lane <-> owned edge e = S0 + p0 + lane
+            const uint32_t rel = p0 + (uint32_t)lane;
+            const bool valid = rel < E;
+            uint32_t rb0 = 0, lenb = 0, ra0 = 0, ra1 = 0;
+            if (valid) {
+                int lo = 0, hi = nvt - 1;                     // source vertex: last idx with s_orow[idx] <= S0+rel
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_orow[mid] <= S0 + rel) lo = mid; else hi = mid - 1;
                 }
-                ++i; ++j;
-                if (i == ie || j == je) break;
-                x = ocol[i]; y = ocol[j];
-            } else if (x < y) {
-                if (++i == ie) break;
-                x = ocol[i];
-            } else {
-                if (++j == je) break;
-                y = ocol[j];
+                ra0 = s_orow[lo] - S0; ra1 = s_orow[lo + 1] - S0;
+                const int32_t b = staged ? s_col[rel] : ocol[S0 + rel];
+                rb0 = orow[b];
+                lenb = orow[b + 1] - rb0;
             }
+            const uint32_t incl = wave_incl_scan(lenb);
+            const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+            __builtin_amdgcn_wave_barrier();
+            s_pref[lane] = incl; s_rb0[lane] = rb0; s_ra0[lane] = ra0; s_ra1[lane] = ra1;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
+                const uint32_t it = it0 + (uint32_t)lane;
+                if (it < total) {
+                    int lo = 0, hi = kWave - 1;               // owner: smallest t with s_pref[t] > it
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pref[mid] > it) hi = mid; else lo = mid + 1;
+                    }
+                    const int t = lo;
+                    const uint32_t first = t ? s_pref[t - 1] : 0u;
+                    const uint32_t j = s_rb0[t] + (it - first);           // slot of w in row b
+                    const int32_t wv = ocol[j];
+                    uint32_t l = s_ra0[t], h = s_ra1[t];
+                    const uint32_t rend = h;
+                    bool found;
+                    if (staged) {
+                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (s_col[mid] < wv) l = mid + 1; else h = mid; }
+                        found = l < rend && s_col[l] == wv;
+                    } else {
+                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wv) l = mid + 1; else h = mid; }
+                        found = l < rend && ocol[S0 + l] == wv;
+                    }
+                    if (found) {
+                        const uint32_t e_rel = p0 + (uint32_t)t, i_rel = l;
+                        const uint32_t e = S0 + e_rel, i = S0 + i_rel;
+                        if (!FILL) {
+                            if (staged) { atomicAdd(&s_cnt[e_rel], 1u); atomicAdd(&s_cnt[i_rel], 1u); }
+                            else { atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); }
+                            atomicAdd(&other_or_cursor[j], 1u);
+                        } else {
+                            uint32_t pe, pi;
+                            if (staged) {
+                                pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
+                                pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
+                            } else {
+                                pe = atomicAdd(&other_or_cursor[e], 1u);
+                                pi = atomicAdd(&other_or_cursor[i], 1u);
+                            }
+                            const uint32_t pj = atomicAdd(&other_or_cursor[j], 1u);
+                            inc[pe] = make_int2((int)i, (int)j);
+                            inc[pi] = make_int2((int)e, (int)j);
+                            inc[pj] = make_int2((int)e, (int)i);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (!FILL && cnt) atomicAdd(&sup_or_cursor[e], cnt);
+        if (!FILL && staged) {
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) own[S0 + k] = s_cnt[k];
+        }
     }
+}
+
+// sup = own + other; cursor (reusing other) = where j-role entries of the slice start
+__global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ own, const uint32_t *__restrict__ other,
+                                                       int64_t m1, uint32_t *__restrict__ sum)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m1; e += (int64_t)gridDim.x * kBlock) sum[e] = own[e] + other[e];
+}
+__global__ __launch_bounds__(kBlock) void k_init_cursor(const uint32_t *__restrict__ off, const uint32_t *__restrict__ own,
+                                                        int64_t m, uint32_t *__restrict__ cursor)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) cursor[e] = off[e] + own[e];
 }
 
 __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t *__restrict__ off,
@@ -269,19 +368,21 @@ __global__ __launch_bounds__(kBlock) void k_graph_moments(const int32_t *__restr
     if (lane_id() == 0) { atomicAdd(&out[0], s2); atomicAdd(&out[1], smin); atomicMax(&out[2], mx); atomicAdd(&out[3], sc); atomicAdd(&out[4], so); }
 }
 
-struct DevBufs {                                    // frees everything it still owns
+struct DevBufs {                                    // returns everything it still owns to the context's pool
     static constexpr int kMax = 48;
+    komb_ctx *ctx;
     void *p[kMax]; int n = 0;
+    explicit DevBufs(komb_ctx *c) : ctx(c) {}
     template <class T> hipError_t alloc(T **out, size_t count)
     {
         void *q = nullptr;
-        hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        hipError_t e = ctx->pool.get(&q, (count ? count : 1) * sizeof(T));
         if (e == hipSuccess) { p[n++] = q; *out = (T *)q; }
         return e;
     }
-    void release(void *q) { for (int i = 0; i < n; ++i) if (p[i] == q) { (void)hipFree(q); p[i] = nullptr; } }
+    void release(void *q) { for (int i = 0; i < n; ++i) if (p[i] == q) { ctx->pool.put(q); p[i] = nullptr; } }
     void disown(void *q) { for (int i = 0; i < n; ++i) if (p[i] == q) p[i] = nullptr; }
-    ~DevBufs() { for (int i = 0; i < n; ++i) if (p[i]) (void)hipFree(p[i]); }
+    ~DevBufs() { for (int i = 0; i < n; ++i) if (p[i]) ctx->pool.put(p[i]); }
 };
 
 // small blocking device-to-host read, ordered on the context's stream
@@ -295,10 +396,10 @@ inline hipError_t d2h(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
 
 void truss_free(komb_ctx *ctx)
 {
-    if (ctx->d_t_eu) (void)hipFree(ctx->d_t_eu);
-    if (ctx->d_t_ev) (void)hipFree(ctx->d_t_ev);
-    if (ctx->d_t_truss) (void)hipFree(ctx->d_t_truss);
-    if (ctx->d_t_sup) (void)hipFree(ctx->d_t_sup);
+    ctx->pool.put(ctx->d_t_eu);
+    ctx->pool.put(ctx->d_t_ev);
+    ctx->pool.put(ctx->d_t_truss);
+    ctx->pool.put(ctx->d_t_sup);
     ctx->d_t_eu = ctx->d_t_ev = ctx->d_t_truss = ctx->d_t_sup = nullptr;
     ctx->t_ne = -1; ctx->truss_done = false;
 }
@@ -314,12 +415,12 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = 0.0;
     st.truss_scans = 0;
     if (nv == 0 || ctx->ne == 0) {
-        KOMB_HIP(ctx, hipMalloc(&ctx->d_t_eu, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_ev, 4));
-        KOMB_HIP(ctx, hipMalloc(&ctx->d_t_truss, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_sup, 4));
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, 4));
         ctx->t_ne = 0; ctx->truss_done = true;
         return KOMB_OK;
     }
-    DevBufs bufs;
+    DevBufs bufs(ctx);
     const int gv_wave = grid_for(nv, kBlock / kWave);          // one wave per vertex
     const int gv = grid_for(nv);
 
@@ -343,8 +444,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
         w_rowptr = d_rp; w_col = d_c;
         if (ns_sub == 0) {
             KOMB_HIP(ctx, hipStreamSynchronize(s));
-            KOMB_HIP(ctx, hipMalloc(&ctx->d_t_eu, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_ev, 4));
-            KOMB_HIP(ctx, hipMalloc(&ctx->d_t_truss, 4)); KOMB_HIP(ctx, hipMalloc(&ctx->d_t_sup, 4));
+            KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
+            KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, 4));
             ctx->t_ne = 0; ctx->truss_done = true;
             return KOMB_OK;
         }
@@ -372,13 +473,18 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
 
     // ---- support (pass 1), slice offsets, incidence lists (pass 2)
     const int ge = grid_for(m);
-    uint32_t *d_cnt = nullptr, *d_off = nullptr;
+    const int gt = grid_for((nv + kTriV - 1) / kTriV, kTriWaves);
+    uint32_t *d_own = nullptr, *d_other = nullptr, *d_cnt = nullptr, *d_off = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_own, (size_t)m + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_other, (size_t)m + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)m + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
-    KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
+    KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
+    KOMB_HIP(ctx, hipMemsetAsync(d_other, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
     ctx->timer.start(s);
-    k_triangles<false><<<ge, kBlock, 0, s>>>(d_orow, d_ocol, d_osrc, m, d_cnt, nullptr);
+    k_triangles<false><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, d_own, d_other, nullptr, nullptr);
     st.ms_tri_count = ctx->timer.stop(s);
+    k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt);
     // the 32-bit slice offsets must not wrap: take the 64-bit total first
     {
         unsigned long long *d_mom = nullptr;
@@ -399,12 +505,12 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
     int2 *d_inc = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
-    KOMB_HIP(ctx, hipMemcpyAsync(d_cnt, d_off, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // cursors
+    k_init_cursor<<<ge, kBlock, 0, s>>>(d_off, d_own, m, d_other);        // d_other becomes the j-role cursor
     ctx->timer.start(s);
-    k_triangles<true><<<ge, kBlock, 0, s>>>(d_orow, d_ocol, d_osrc, m, d_cnt, d_inc);
+    k_triangles<true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, nullptr, d_other, d_off, d_inc);
     st.ms_tri_fill = ctx->timer.stop(s);
     st.ms_support = st.ms_tri_count + st.ms_tri_fill;
-    bufs.release(d_cnt);
+    bufs.release(d_cnt); bufs.release(d_own); bufs.release(d_other);
 
     // ---- peel
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
@@ -448,10 +554,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
     k_row_filter<PredUpper, false><<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, PredUpper{}, d_ucnt, nullptr, nullptr, nullptr);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
     k_gather_canonical<<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_deg, d_ebase, d_orow, d_ocol, d_off, d_truss,
                                                   ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);

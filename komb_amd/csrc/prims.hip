@@ -9,9 +9,12 @@
 namespace komb {
 
 namespace {
-struct TempBuf {
+struct TempBuf {                             // scratch from the context's caching pool
+    komb_ctx *ctx;
     void *p = nullptr;
-    ~TempBuf() { if (p) (void)hipFree(p); }
+    explicit TempBuf(komb_ctx *c) : ctx(c) {}
+    hipError_t get(size_t bytes) { return ctx->pool.get(&p, bytes ? bytes : 16); }
+    ~TempBuf() { if (p) ctx->pool.put(p); }
 };
 } // namespace
 
@@ -21,8 +24,8 @@ int prim_sort_u64(komb_ctx *ctx, uint64_t *keys, uint64_t *tmp_keys, int64_t n, 
     hipcub::DoubleBuffer<uint64_t> db(keys, tmp_keys);
     size_t bytes = 0;
     KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, db, (int)n, 0, end_bit, ctx->stream));
-    TempBuf t;
-    KOMB_HIP(ctx, hipMalloc(&t.p, bytes ? bytes : 16));
+    TempBuf t(ctx);
+    KOMB_HIP(ctx, t.get(bytes));
     KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(t.p, bytes, db, (int)n, 0, end_bit, ctx->stream));
     KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *sorted = db.Current();
@@ -36,8 +39,8 @@ int prim_unique_u64(komb_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n,
     KOMB_HIP(ctx, hipMalloc(&d_num, sizeof(int)));
     size_t bytes = 0;
     hipError_t e = hipcub::DeviceSelect::Unique(nullptr, bytes, in, out, d_num, (int)n, ctx->stream);
-    TempBuf t;
-    if (e == hipSuccess) e = hipMalloc(&t.p, bytes ? bytes : 16);
+    TempBuf t(ctx);
+    if (e == hipSuccess) e = t.get(bytes);
     if (e == hipSuccess) e = hipcub::DeviceSelect::Unique(t.p, bytes, in, out, d_num, (int)n, ctx->stream);
     int h = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h, d_num, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
@@ -54,8 +57,8 @@ int prim_exclusive_sum_u32(komb_ctx *ctx, const uint32_t *in, uint32_t *out, int
     if (n == 0) return KOMB_OK;
     size_t bytes = 0;
     KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
-    TempBuf t;
-    KOMB_HIP(ctx, hipMalloc(&t.p, bytes ? bytes : 16));
+    TempBuf t(ctx);
+    KOMB_HIP(ctx, t.get(bytes));
     KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(t.p, bytes, in, out, (int)n, ctx->stream));
     KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KOMB_OK;
@@ -70,8 +73,8 @@ int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, ui
     hipcub::DoubleBuffer<uint32_t> dv(vals, vals_tmp);
     size_t bytes = 0;
     KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, dk, dv, (int)n, 0, end_bit, ctx->stream));
-    TempBuf t;
-    KOMB_HIP(ctx, hipMalloc(&t.p, bytes ? bytes : 16));
+    TempBuf t(ctx);
+    KOMB_HIP(ctx, t.get(bytes));
     KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(t.p, bytes, dk, dv, (int)n, 0, end_bit, ctx->stream));
     KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *sorted_keys = (int64_t *)dk.Current();
