@@ -32,13 +32,17 @@ struct PeelCtrl {
     int32_t  n_rounds;      // stats: PROCESS launches
     int32_t  n_scans;       // stats: SCAN launches
     int32_t  max_level;     // stats: highest populated level
+    uint32_t live_count;    // entries of the compacted live list (live_mode 1)
+    int32_t  live_sel;      // which live-list buffer is current
+    int32_t  live_mode;     // 0: SCAN sweeps all units; 1: SCAN sweeps the live list
+    uint32_t live_tail;     // (atomic) survivors appended by the running SCAN
     // ---- modified with atomics during a launch
     uint32_t tail_l[2];     // append cursors of the light queues
     uint32_t tail_h[2];     // append cursors of the heavy queues
     int32_t  next_min;      // min live key above the scanned level
     uint32_t blocks_done;   // second-level arrival ticket
     uint32_t acc;           // units that entered a frontier in this launch
-    uint32_t pad1[13];
+    uint32_t pad1[9];
 };
 static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
 

@@ -8,10 +8,12 @@
 //
 // One kernel, k_peel_step<P>, is launched over and over; what a launch does is
 // decided on the device from the control block its predecessor finalised:
-//   SCAN    : two passes over all units.  Pass A counts, per wave, the live
-//             units with key <= level; one atomic per WORKGROUP reserves queue
-//             space; pass B re-evaluates the same predicate and writes the
-//             queue entries at wave-private offsets (no append atomics at all).
+//   SCAN    : two passes over all units (later: over the compacted list of live
+//             units, rewritten by every SCAN once <= 1/4 of the units is left).
+//             Pass A counts, per wave, the live units with key <= level; one
+//             atomic per WORKGROUP reserves queue space; pass B re-evaluates the
+//             same predicate and writes the queue entries at wave-private
+//             offsets (no append atomics at all).
 //   PROCESS : the frontier lives in two queues.  "Light" units (<= kLight
 //             items) are taken 64 per wavefront and their slices flattened
 //             across the lanes (prefix sum in LDS + binary search), so lanes
@@ -41,7 +43,9 @@ constexpr int kMaxGroups = 64;                 // grid <= kGroup * kMaxGroups
 
 struct CtrlView {                              // launch-stable part of the control block
     int32_t mode, level, round, done, cur_sel;
-    uint32_t cur_light, cur_heavy;
+    uint32_t cur_light, cur_heavy, remaining;
+    uint32_t live_count;
+    int32_t live_sel, live_mode;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -74,6 +78,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 struct PeelQueues {
     int32_t *light[2];       // unit ids
     int2 *heavy[2];          // (unit id, chunk index)
+    int32_t *live[2];        // compacted ids of the units still live (SCAN's input once it pays off)
 };
 
 // ---------------------------------------------------------------- appenders
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
 {
     __shared__ CtrlView sh_cv;
     __shared__ uint32_t sh_w[kPeelWaves][4];           // per-wave counts / bases
-    __shared__ uint32_t sh_base[2];
+    __shared__ uint32_t sh_base[3];
     __shared__ int32_t sh_min[kPeelWaves];
     __shared__ uint32_t sh_end[kPeelWaves][kWave];
     __shared__ uint32_t sh_beg[kPeelWaves][kWave];
@@ -167,15 +172,24 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
     if (threadIdx.x == 0) {
         sh_cv.mode = ctrl->mode; sh_cv.level = ctrl->level; sh_cv.round = ctrl->round; sh_cv.done = ctrl->done;
         sh_cv.cur_sel = ctrl->cur_sel; sh_cv.cur_light = ctrl->cur_light; sh_cv.cur_heavy = ctrl->cur_heavy;
+        sh_cv.remaining = ctrl->remaining; sh_cv.live_count = ctrl->live_count;
+        sh_cv.live_sel = ctrl->live_sel; sh_cv.live_mode = ctrl->live_mode;
     }
     __syncthreads();
     const CtrlView cv = sh_cv;
     if (cv.done) return;
 
     // workgroups that take part in this launch (the rest leave without touching the ticket)
+    // light units per wave batch: 64 when the frontier is large, fewer (>= 4) when it would
+    // otherwise leave most of the grid's wavefronts without work
+    uint32_t bsz = kWave;
+    {
+        const uint64_t grid_waves = (uint64_t)gridDim.x * kPeelWaves;
+        while (bsz > 4 && (uint64_t)cv.cur_light < grid_waves * (bsz / 2)) bsz >>= 1;
+    }
     uint32_t nblk = gridDim.x;
     if (cv.mode == MODE_PROCESS) {
-        const uint64_t wave_jobs = ((uint64_t)cv.cur_light + kWave - 1) / kWave + (uint64_t)cv.cur_heavy;
+        const uint64_t wave_jobs = ((uint64_t)cv.cur_light + bsz - 1) / bsz + (uint64_t)cv.cur_heavy;
         const uint64_t need = (wave_jobs + kPeelWaves - 1) / kPeelWaves;
         nblk = (uint32_t)(need < 1 ? 1 : (need > gridDim.x ? gridDim.x : need));
     }
@@ -187,64 +201,75 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
     const int sel = cv.cur_sel;
 
     if (cv.mode == MODE_SCAN) {
-        // ---- pass A: count this wave's light hits, its heavy units' chunks, and all hits
-        uint32_t n_light = 0, n_chunks = 0, n_hits = 0;    // n_light / n_hits wave-uniform, n_chunks per lane
+        // ---- input: every unit, or the compacted live list; survivors are compacted into the
+        // other live buffer once at most a quarter of the units is left
+        const bool from_list = cv.live_mode != 0;
+        const bool emit = from_list || cv.remaining <= p.units / 4;
+        const uint32_t n_in = from_list ? cv.live_count : p.units;
+        const int32_t *live_in = Q.live[cv.live_sel];
+        int32_t *live_out = Q.live[cv.live_sel ^ 1];
+        // ---- pass A: count this wave's light hits, its heavy units' chunks, all hits, survivors
+        uint32_t n_light = 0, n_chunks = 0, n_hits = 0, n_surv = 0;   // n_chunks per lane, others wave-uniform
         int32_t lmin = 0x7FFFFFFF;
-        const uint32_t units = p.units;
-        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < units; base += (uint64_t)nblk * kPeelBlock) {
-            const uint64_t u = base + (uint64_t)lane;
-            bool hit = false, light = false;
-            if (u < units) {
+        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * kPeelBlock) {
+            const uint64_t idx = base + (uint64_t)lane;
+            bool hit = false, light = false, surv = false;
+            if (idx < n_in) {
+                const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
                 int32_t key;
-                if (p.live_below((uint32_t)u, L, key)) {
+                if (p.live_below(u, L, key)) {
                     hit = true;
                     uint32_t b, len;
-                    p.slice((uint32_t)u, b, len);
+                    p.slice(u, b, len);
                     if (len <= (uint32_t)kLight) light = len > 0;
                     else n_chunks += (len + kChunk - 1) / kChunk;
-                } else lmin = min(lmin, key);
+                } else if (key != 0x7FFFFFFF) { lmin = min(lmin, key); surv = true; }
             }
             n_light += (uint32_t)__popcll(__ballot(light));
             n_hits += (uint32_t)__popcll(__ballot(hit));
+            if (emit) n_surv += (uint32_t)__popcll(__ballot(surv));
         }
         n_chunks = wave_sum(n_chunks);
         lmin = wave_min(lmin);
-        if (lane == 0) { sh_w[w][0] = n_light; sh_w[w][1] = n_chunks; sh_w[w][2] = n_hits; sh_min[w] = lmin; }
+        if (lane == 0) { sh_w[w][0] = n_light; sh_w[w][1] = n_chunks; sh_w[w][2] = n_hits; sh_w[w][3] = n_surv; sh_min[w] = lmin; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t tl = 0, th = 0, hits = 0;
+            uint32_t tl = 0, th = 0, ts = 0, hits = 0;
             int32_t bmin = 0x7FFFFFFF;
             for (int i = 0; i < kPeelWaves; ++i) {
-                const uint32_t a = sh_w[i][0], b = sh_w[i][1];
-                sh_w[i][0] = tl; sh_w[i][1] = th;          // exclusive offsets inside the workgroup's reservation
-                tl += a; th += b; hits += sh_w[i][2];
+                const uint32_t a = sh_w[i][0], b = sh_w[i][1], c = sh_w[i][3];
+                sh_w[i][0] = tl; sh_w[i][1] = th; sh_w[i][3] = ts;   // exclusive offsets inside the workgroup's reservations
+                tl += a; th += b; ts += c; hits += sh_w[i][2];
                 bmin = min(bmin, sh_min[i]);
             }
             sh_base[0] = tl ? atomicAdd(&ctrl->tail_l[sel], tl) : 0u;
             sh_base[1] = th ? atomicAdd(&ctrl->tail_h[sel], th) : 0u;
+            sh_base[2] = ts ? atomicAdd(&ctrl->live_tail, ts) : 0u;
             if (hits) atomicAdd(&ctrl->acc, hits);
             if (bmin != 0x7FFFFFFF) atomicMin(&ctrl->next_min, bmin);
         }
         __syncthreads();
         // ---- pass B: same predicate on unchanged state, write the entries
-        const uint32_t base_l = sh_base[0] + sh_w[w][0], base_h = sh_base[1] + sh_w[w][1];
-        uint32_t run_l = 0, run_h = 0;
-        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < units; base += (uint64_t)nblk * kPeelBlock) {
-            const uint64_t u = base + (uint64_t)lane;
-            bool light = false, heavy = false;
-            uint32_t nch = 0;
-            if (u < units) {
+        const uint32_t base_l = sh_base[0] + sh_w[w][0], base_h = sh_base[1] + sh_w[w][1], base_s = sh_base[2] + sh_w[w][3];
+        uint32_t run_l = 0, run_h = 0, run_s = 0;
+        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * kPeelBlock) {
+            const uint64_t idx = base + (uint64_t)lane;
+            bool light = false, heavy = false, surv = false;
+            uint32_t nch = 0, u = 0;
+            if (idx < n_in) {
+                u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
                 int32_t key;
-                if (p.live_below((uint32_t)u, L, key)) {
+                if (p.live_below(u, L, key)) {
                     uint32_t b, len;
-                    p.slice((uint32_t)u, b, len);
+                    p.slice(u, b, len);
                     if (len <= (uint32_t)kLight) light = len > 0;
                     else { heavy = true; nch = (len + kChunk - 1) / kChunk; }
-                    p.mark_scanned((uint32_t)u, cv);
-                }
+                    p.mark_scanned(u, cv);
+                } else surv = key != 0x7FFFFFFF;
             }
             wave_write_ordered(light, (int32_t)u, Q.light[sel], base_l, run_l);
             if (__ballot(heavy)) wave_write_chunks(heavy, (int32_t)u, nch, Q.heavy[sel], base_h, run_h);
+            if (emit) wave_write_ordered(surv, (int32_t)u, live_out, base_s, run_s);
         }
     } else {
         // ---- PROCESS
@@ -276,14 +301,14 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         };
 
         // light units: 64 per wave, slices flattened over the lanes
-        const uint64_t n_batches = ((uint64_t)cv.cur_light + kWave - 1) / kWave;
+        const uint64_t n_batches = ((uint64_t)cv.cur_light + bsz - 1) / bsz;
         uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w];
         int32_t *s_unit = sh_unit[w];
         for (uint64_t bt = gw; bt < n_batches; bt += nw) {
-            const uint64_t idx = bt * kWave + (uint64_t)lane;
+            const uint64_t idx = bt * bsz + (uint64_t)lane;
             int32_t unit = -1;
             uint32_t beg = 0, len = 0;
-            if (idx < cv.cur_light) { unit = Q.light[sel][idx]; p.slice((uint32_t)unit, beg, len); }
+            if ((uint32_t)lane < bsz && idx < cv.cur_light) { unit = Q.light[sel][idx]; p.slice((uint32_t)unit, beg, len); }
             const uint32_t incl = wave_incl_scan(len);
             const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
             __builtin_amdgcn_wave_barrier();
@@ -353,6 +378,11 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         cur_l = coherent_load(&ctrl->tail_l[sel]);
         cur_h = coherent_load(&ctrl->tail_h[sel]);
         const int32_t nmin = atomicExch(&ctrl->next_min, 0x7FFFFFFF);
+        if (cv.live_mode != 0 || cv.remaining <= p.units / 4) {           // this SCAN compacted the survivors
+            ctrl->live_count = atomicExch(&ctrl->live_tail, 0u);
+            ctrl->live_sel = cv.live_sel ^ 1;
+            ctrl->live_mode = 1;
+        }
         if (acc > 0) { ctrl->n_levels += 1; ctrl->max_level = level; }
         if (cur_l + cur_h > 0) mode = MODE_PROCESS;
         else if (remaining == 0) done = 1;
