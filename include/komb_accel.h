@@ -42,8 +42,7 @@ typedef struct komb_ctx komb_ctx;
 typedef struct komb_opts {
     int32_t device;        /* HIP device ordinal (LOCAL_RANK for one process per GPU) */
     int32_t verbosity;     /* 0 silent, 1 progress on stderr                          */
-    int32_t rank;          /* edge-partition rank  (0 for a single GPU)               */
-    int32_t world;         /* edge-partition count (1 for a single GPU)               */
+    int32_t reserved[2];
 } komb_opts;
 
 typedef struct komb_stats {
@@ -64,6 +63,7 @@ typedef struct komb_stats {
     double  ms_tri_count;           /* truss: triangle enumeration, support counting  */
     double  ms_tri_fill;            /* truss: triangle enumeration, incidence fill    */
     double  ms_support;             /* = ms_tri_count + ms_tri_fill                   */
+    double  ms_allreduce;           /* truss: support all-reduce callback (sharded)   */
     double  ms_peel;                /* truss: all peel launches (SCAN + PROCESS)      */
     double  ms_gather;              /* truss: canonical-order result gather           */
     double  ms_corea;               /* a9/a10: CoreA rank kernels                     */
@@ -112,6 +112,16 @@ int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness);
  * komb_truss_run computes on the device (timed region); komb_truss_fetch
  * copies (eu,ev,truss)[ne_sub] out.  Trussness of a triangle-free edge is 2. */
 int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
+/* One process per GPU, every rank holding the same graph: the triangle-support
+ * phase is sharded by source-vertex range [rank/world) and the partial support
+ * vectors are summed across ranks by `allreduce` -- an in-place SUM all-reduce
+ * over uint32[count] in device memory, ordered after all work already queued
+ * on the device's default stream (the host implements it with RCCL; return 0 on
+ * success).  Incidence index, peel and gather then run on every rank; all
+ * ranks end with identical results.  world == 1 is komb_truss_run. */
+typedef int (*komb_allreduce_fn)(void *user, void *device_u32, int64_t count);
+int komb_truss_run_sharded(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world,
+                           komb_allreduce_fn allreduce, void *user);
 int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub);
 int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss);
 /* per-edge triangle counts the peel started from (canonical order) */

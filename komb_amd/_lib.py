@@ -18,7 +18,7 @@ KOMB_ERR_ARG, KOMB_ERR_DEVICE, KOMB_ERR_NOMEM, KOMB_ERR_LIMIT, KOMB_ERR_STATE = 
 
 class KombOpts(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("verbosity", ctypes.c_int32),
-                ("rank", ctypes.c_int32), ("world", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32 * 2)]
 
 
 class KombStats(ctypes.Structure):
@@ -32,6 +32,7 @@ class KombStats(ctypes.Structure):
         ("truss_scans", ctypes.c_int32), ("truss_launches", ctypes.c_int32),
         ("ms_build", ctypes.c_double), ("ms_core", ctypes.c_double), ("ms_orient", ctypes.c_double),
         ("ms_tri_count", ctypes.c_double), ("ms_tri_fill", ctypes.c_double), ("ms_support", ctypes.c_double),
+        ("ms_allreduce", ctypes.c_double),
         ("ms_peel", ctypes.c_double), ("ms_gather", ctypes.c_double), ("ms_corea", ctypes.c_double),
     ]
 
@@ -51,6 +52,7 @@ SIGNATURES = {
     "komb_core_fetch": (_i32, [_vp, _vp, _vp]),
     "komb_degree_coreness": (_i32, [_vp, _vp, _vp]),
     "komb_truss_run": (_i32, [_vp, _vp]),
+    "komb_truss_run_sharded": (_i32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp]),
     "komb_truss_count": (_i32, [_vp, ctypes.POINTER(_i64)]),
     "komb_truss_fetch": (_i32, [_vp, _vp, _vp, _vp]),
     "komb_truss_fetch_support": (_i32, [_vp, _vp]),
@@ -60,6 +62,8 @@ SIGNATURES = {
     "komb_get_stats": (_i32, [_vp, ctypes.POINTER(KombStats)]),
     "komb_gen_hug_edges": (_i64, [_i64, _i64, ctypes.c_double, ctypes.c_uint64, _vp]),
 }
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 
 _LIB = None
 

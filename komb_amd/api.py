@@ -36,10 +36,11 @@ def gen_hug_edges(nv, n_cliques, alpha=2.6, seed=42):
 class KombAccel:
     def __init__(self, device=0, verbosity=0):
         self._lib = _lib.load()
-        opts = KombOpts(device=device, verbosity=verbosity, rank=0, world=1)
+        opts = KombOpts(device=device, verbosity=verbosity)
         self._ctx = self._lib.komb_create(ctypes.byref(opts))
         if not self._ctx:
             raise MemoryError("komb_create failed")
+        self.device = device
         self.nv = -1
         self.ne = 0
 

@@ -36,7 +36,6 @@ komb_ctx *komb_create(const komb_opts *opts)
     komb_ctx *ctx = new (std::nothrow) komb_ctx();
     if (!ctx) return nullptr;
     if (opts) ctx->opts = *opts;
-    if (ctx->opts.world <= 0) ctx->opts.world = 1;
     ctx->device = ctx->opts.device;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -135,7 +134,14 @@ int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness)
 int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask)
 {
     KOMB_TRY(require_device(ctx));
-    return truss_run(ctx, vmask);
+    return truss_run(ctx, vmask, 0, 1, nullptr, nullptr);
+}
+
+int komb_truss_run_sharded(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world,
+                           komb_allreduce_fn allreduce, void *user)
+{
+    KOMB_TRY(require_device(ctx));
+    return truss_run(ctx, vmask, rank, world, allreduce, user);
 }
 
 int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub)

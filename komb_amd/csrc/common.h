@@ -171,7 +171,7 @@ int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, ui
 
 // ---- stages (each in its own translation unit)
 int core_run(komb_ctx *ctx);
-int truss_run(komb_ctx *ctx, const uint8_t *vmask_host);
+int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, komb_allreduce_fn fn, void *user);
 int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t n, double *rank_deg, double *rank_key);
 int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv);
 int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);

@@ -117,7 +117,8 @@ constexpr int kTriWaves = kBlock / kWave;
 
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
-                                                      int64_t nv, uint32_t *__restrict__ own, uint32_t *other_or_cursor,
+                                                      int64_t nv, int64_t task_lo, int64_t task_hi,
+                                                      uint32_t *__restrict__ own, uint32_t *other_or_cursor,
                                                       const uint32_t *__restrict__ off, int2 *__restrict__ inc)
 {
     __shared__ int32_t sh_col[kTriWaves][kTriCap];
@@ -132,11 +133,10 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
     int32_t *s_col = sh_col[w];
     uint32_t *s_cnt = sh_cnt[w], *s_orow = sh_orow[w], *s_pref = sh_pref[w];
     uint32_t *s_rb0 = sh_rb0[w], *s_ra0 = sh_ra0[w], *s_ra1 = sh_ra1[w];
-    const int64_t ntasks = (nv + kTriV - 1) / kTriV;
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
 
-    for (int64_t task = gw; task < ntasks; task += nw) {
+    for (int64_t task = task_lo + gw; task < task_hi; task += nw) {
         const int64_t v0 = task * kTriV;
         const int nvt = (int)min((int64_t)kTriV, nv - v0);
         __builtin_amdgcn_wave_barrier();
@@ -404,15 +404,19 @@ void truss_free(komb_ctx *ctx)
     ctx->t_ne = -1; ctx->truss_done = false;
 }
 
-int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
+// rank/world/fn: support counting is sharded by source-vertex range; fn sums the
+// partial support vectors over the ranks (RCCL all-reduce on the host side).
+int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, komb_allreduce_fn fn, void *user)
 {
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn))
+        KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_truss_run_sharded: bad rank %d / world %d / callback", rank, world);
     if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_run: no graph loaded");
     truss_free(ctx);
     const int64_t nv = ctx->nv;
     hipStream_t s = ctx->stream;
     komb_stats &st = ctx->stats;
     st.triangles = 0; st.truss_levels = st.truss_subrounds = st.truss_launches = 0;
-    st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = 0.0;
+    st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = st.ms_allreduce = 0.0;
     st.truss_scans = 0;
     if (nv == 0 || ctx->ne == 0) {
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
@@ -475,15 +479,23 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     const int ge = grid_for(m);
     const int gt = grid_for((nv + kTriV - 1) / kTriV, kTriWaves);
     uint32_t *d_own = nullptr, *d_other = nullptr, *d_cnt = nullptr, *d_off = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_own, (size_t)m + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_other, (size_t)m + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_own, 2 * ((size_t)m + 1)));         // [own | other] contiguous: one all-reduce
+    d_other = d_own + ((size_t)m + 1);
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)m + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
-    KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
-    KOMB_HIP(ctx, hipMemsetAsync(d_other, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
+    KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s));
+    const int64_t ntasks = (nv + kTriV - 1) / kTriV;
+    const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
     ctx->timer.start(s);
-    k_triangles<false><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, d_own, d_other, nullptr, nullptr);
+    k_triangles<false><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr);
     st.ms_tri_count = ctx->timer.stop(s);
+    st.ms_allreduce = 0.0;
+    if (world > 1) {                                               // sum the partial support vectors over the ranks
+        ctx->timer.start(s);
+        if (fn(user, d_own, (int64_t)(2 * ((size_t)m + 1))) != 0)
+            KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
+        st.ms_allreduce = ctx->timer.stop(s);
+    }
     k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt);
     // the 32-bit slice offsets must not wrap: take the 64-bit total first
     {
@@ -507,10 +519,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host)
     KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
     k_init_cursor<<<ge, kBlock, 0, s>>>(d_off, d_own, m, d_other);        // d_other becomes the j-role cursor
     ctx->timer.start(s);
-    k_triangles<true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, nullptr, d_other, d_off, d_inc);
+    k_triangles<true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, nullptr, d_other, d_off, d_inc);
     st.ms_tri_fill = ctx->timer.stop(s);
     st.ms_support = st.ms_tri_count + st.ms_tri_fill;
-    bufs.release(d_cnt); bufs.release(d_own); bufs.release(d_other);
+    bufs.release(d_cnt); bufs.release(d_own);
 
     // ---- peel
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;

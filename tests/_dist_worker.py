@@ -1,0 +1,101 @@
+"""Worker for the world_size-2 tests (launched with torch.distributed.run).
+
+mode "cpu": gloo on CPU tensors -- each rank counts the triangle supports of its
+own source-vertex shard with a pure-Python restatement of the sharded kernel's
+role counting, the partial vectors are summed with komb_amd.distributed's
+all-reduce, and the sum must equal the single-rank count and the oracle.
+mode "gpu": the real komb_truss_run_sharded on the GPU box (ranks share GPU 0,
+gloo backend, all-reduce staged through the host), checked against the oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import komb_amd                                    # noqa: E402
+from komb_amd import distributed as kd             # noqa: E402
+from oracle import oracle as O                     # noqa: E402
+
+
+def oriented(rowptr, col):
+    nv = len(rowptr) - 1
+    deg = np.diff(rowptr)
+    rows = []
+    for a in range(nv):
+        nb = col[rowptr[a]:rowptr[a + 1]]
+        keep = [int(b) for b in nb if (deg[a], a) < (deg[b], b)]
+        rows.append(keep)
+    orow = np.zeros(nv + 1, dtype=np.int64)
+    orow[1:] = np.cumsum([len(r) for r in rows])
+    return orow, rows
+
+
+def partial_support(orow, rows, v_lo, v_hi):
+    """[own | other] role counts for source vertices [v_lo, v_hi), internal edge id = oriented slot."""
+    m = int(orow[-1])
+    own = np.zeros(m + 1, dtype=np.int32)
+    other = np.zeros(m + 1, dtype=np.int32)
+    for a in range(v_lo, v_hi):
+        ra = rows[a]
+        pos_a = {w: i for i, w in enumerate(ra)}
+        for ib, b in enumerate(ra):
+            for jw, w in enumerate(rows[b]):
+                if w in pos_a:
+                    own[orow[a] + ib] += 1
+                    own[orow[a] + pos_a[w]] += 1
+                    other[orow[b] + jw] += 1
+    return np.concatenate([own, other])
+
+
+def main():
+    mode = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nv = 3000 if mode == "cpu" else 60000
+    uv = komb_amd.gen_hug_edges(nv, int(2.6 * nv), 2.6, 11)
+    rowptr, col = O.simplify(nv, uv)
+    if mode == "cpu":
+        orow, rows = oriented(rowptr, col)
+        n_tasks = kd.n_support_tasks(nv)
+        lo, hi = kd.shard_range(n_tasks, rank, world)
+        part = partial_support(orow, rows, min(nv, lo * 16), min(nv, hi * 16))
+        t = torch.from_numpy(part.copy())
+        kd.allreduce_sum_(t)
+        full = partial_support(orow, rows, 0, nv)
+        assert np.array_equal(t.numpy(), full), "sum of shards != single-rank count"
+        m = int(orow[-1])
+        sup_internal = full[:m + 1] + full[m + 1:]
+        osup, otri = O.support(rowptr, col)
+        assert int(sup_internal.sum()) == 3 * otri
+        assert sorted(sup_internal[:m].tolist()) == sorted(osup.tolist())
+        # shards tile the task range exactly
+        spans = [kd.shard_range(n_tasks, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n_tasks and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    else:
+        with komb_amd.KombAccel(device=0) as a:
+            a.from_edges(nv, uv)
+            kd.truss_run_sharded(a)
+            eu, ev, tr, sup = a.truss_fetch(with_support=True)
+            osup, _ = O.support(rowptr, col)
+            assert np.array_equal(sup, osup), "sharded support mismatch"
+            assert np.array_equal(tr, O.trussness(rowptr, col)), "sharded trussness mismatch"
+            mask = (O.coreness(rowptr, col) >= 5).astype(np.uint8)
+            kd.truss_run_sharded(a, mask)
+            seu, sev, stra = a.truss_fetch()
+            weu, wev, wtr = O.trussness_induced(rowptr, col, mask)
+            assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+            st = a.stats()
+            assert st["ms_allreduce"] > 0
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK", mode, world)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

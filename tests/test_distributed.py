@@ -1,0 +1,39 @@
+"""N>1 path: world_size-2 runs (gloo).  CPU: shard arithmetic + all-reduce of the
+support vectors against a Python restatement of the sharded role counting.
+GPU box: the real komb_truss_run_sharded with two ranks sharing GPU 0."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(mode, nproc, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py"), mode]
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+
+
+def test_shard_ranges(built):
+    from komb_amd import distributed as kd
+    for n in (0, 1, 7, 625000):
+        for world in (1, 2, 3, 8):
+            spans = [kd.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_world2_gloo_cpu(built):
+    r = _launch("cpu", 2, 29611)
+    assert r.returncode == 0 and "DIST_OK cpu 2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_world2_sharded_on_gpu(built):
+    r = _launch("gpu", 2, 29612)
+    assert r.returncode == 0 and "DIST_OK gpu 2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
