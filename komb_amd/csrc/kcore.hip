@@ -46,11 +46,18 @@ struct CoreProblem {
         b = rowptr[v];
         len = rowptr[v + 1] - b;
     }
-    __device__ __forceinline__ void item(int32_t, uint32_t pos, const CtrlView &cv, int32_t &t0, int32_t &) const
+    struct Loaded { int32_t u, c; };
+    __device__ __forceinline__ Loaded item_load(int32_t, uint32_t pos, const CtrlView &) const
     {
-        const int32_t u = col[pos];
-        if (core[u] == kAlive) {                        // a stale "alive" only costs a no-op decrement
-            if (atomicSub(&degw[u], 1) == cv.level + 1) { core[u] = cv.level; t0 = u; }
+        Loaded ld;
+        ld.u = col[pos];
+        ld.c = core[ld.u];
+        return ld;
+    }
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &) const
+    {
+        if (ld.c == kAlive) {                           // a stale "alive" only costs a no-op decrement
+            if (atomicSub(&degw[ld.u], 1) == cv.level + 1) { core[ld.u] = cv.level; t0 = ld.u; }
         }
     }
 };

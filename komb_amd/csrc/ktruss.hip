@@ -56,34 +56,73 @@ struct PredUpper {                      // keep slot (a,b) when a < b: the canon
     __device__ bool operator()(int32_t a, int32_t b) const { return a < b; }
 };
 
-// One wavefront per row; ballot + prefix popcount keeps the row order.
+// One wavefront owns kRowsPerWave consecutive rows = one contiguous slot range of
+// the CSR, swept 64 slots at a time with all lanes busy; the row of a slot is
+// found by a binary search over the 17 staged row pointers.  Ballot + prefix
+// popcount keeps slot order, so the kept slots of the owned rows land
+// contiguously from out_rowptr[first owned row].
+constexpr int kRowsPerWave = 16;
+
+__device__ __forceinline__ int row_of_slot(const uint32_t *s_rp, int nrows, uint32_t j)
+{
+    int lo = 0, hi = nrows - 1;                       // last idx with s_rp[idx] <= j
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_rp[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 template <class Pred, bool FILL>
 __global__ __launch_bounds__(kBlock) void k_row_filter(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                        int64_t nv, Pred pred, uint32_t *__restrict__ out_count,
                                                        const uint32_t *__restrict__ out_rowptr, int32_t *__restrict__ out_col,
                                                        int32_t *__restrict__ out_src)
 {
+    __shared__ uint32_t sh_rp[kBlock / kWave][kRowsPerWave + 1];
+    __shared__ uint32_t sh_cnt[kBlock / kWave][kRowsPerWave];
     const int lane = lane_id();
+    uint32_t *s_rp = sh_rp[threadIdx.x >> 6], *s_cnt = sh_cnt[threadIdx.x >> 6];
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    for (int64_t v = wave; v < nv; v += nwaves) {
-        const uint32_t b = rowptr[v], e = rowptr[v + 1];
-        uint32_t cnt = 0;
-        const uint32_t obase = FILL ? out_rowptr[v] : 0u;
-        for (uint32_t j0 = b; j0 < e; j0 += kWave) {
+    const int64_t ntasks = (nv + kRowsPerWave - 1) / kRowsPerWave;
+    for (int64_t task = wave; task < ntasks; task += nwaves) {
+        const int64_t v0 = task * kRowsPerWave;
+        const int nvt = (int)min((int64_t)kRowsPerWave, nv - v0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane <= nvt) s_rp[lane] = rowptr[v0 + lane];
+        if (lane < kRowsPerWave) s_cnt[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t S0 = s_rp[0], S1 = s_rp[nvt];
+        const uint32_t obase = FILL ? out_rowptr[v0] : 0u;
+        uint32_t run = 0;
+        for (uint32_t j0 = S0; j0 < S1; j0 += kWave) {
             const uint32_t j = j0 + (uint32_t)lane;
-            int32_t c = 0;
+            int32_t c = 0, a = 0;
             bool keep = false;
-            if (j < e) { c = col[j]; keep = pred((int32_t)v, c); }
-            const uint64_t m = __ballot(keep);
-            if (FILL && keep) {
-                const uint32_t o = obase + cnt + (uint32_t)__popcll(m & lanemask_lt());
-                out_col[o] = c;
-                if (out_src) out_src[o] = (int32_t)v;
+            int r = 0;
+            if (j < S1) {
+                c = col[j];
+                r = row_of_slot(s_rp, nvt, j);
+                a = (int32_t)(v0 + r);
+                keep = pred(a, c);
             }
-            cnt += (uint32_t)__popcll(m);
+            const uint64_t m = __ballot(keep);
+            if (keep) {
+                if (FILL) {
+                    const uint32_t o = obase + run + (uint32_t)__popcll(m & lanemask_lt());
+                    out_col[o] = c;
+                    if (out_src) out_src[o] = a;
+                } else {
+                    atomicAdd(&s_cnt[r], 1u);
+                }
+            }
+            run += (uint32_t)__popcll(m);
         }
-        if (!FILL && lane == 0) out_count[v] = cnt;
+        if (!FILL) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nvt) out_count[v0 + lane] = s_cnt[lane];
+        }
     }
 }
 
@@ -113,6 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 // binary search and global atomics for all three roles.
 constexpr int kTriV = 16;
 constexpr int kTriCap = 512;
+constexpr int kTriU = 2;                       // probe items per lane per trip
 constexpr int kTriWaves = kBlock / kWave;
 
 template <bool FILL>
@@ -171,35 +211,50 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
             __builtin_amdgcn_wave_barrier();
             s_pref[lane] = incl; s_rb0[lane] = rb0; s_ra0[lane] = ra0; s_ra1[lane] = ra1;
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
-                const uint32_t it = it0 + (uint32_t)lane;
-                if (it < total) {
+            // kTriU items per lane per trip: the owner search, the gather of w and the row search of
+            // the items are independent chains, so their latencies overlap
+            for (uint32_t it0 = 0; it0 < total; it0 += kWave * kTriU) {
+                int t[kTriU];
+                uint32_t j[kTriU];
+                bool valid[kTriU];
+#pragma unroll
+                for (int k = 0; k < kTriU; ++k) {
+                    const uint32_t it = it0 + (uint32_t)(k * kWave + lane);
+                    valid[k] = it < total;
                     int lo = 0, hi = kWave - 1;               // owner: smallest t with s_pref[t] > it
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_pref[mid] > it) hi = mid; else lo = mid + 1;
+                    if (valid[k]) {
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_pref[mid] > it) hi = mid; else lo = mid + 1;
+                        }
                     }
-                    const int t = lo;
-                    const uint32_t first = t ? s_pref[t - 1] : 0u;
-                    const uint32_t j = s_rb0[t] + (it - first);           // slot of w in row b
-                    const int32_t wv = ocol[j];
-                    uint32_t l = s_ra0[t], h = s_ra1[t];
+                    t[k] = lo;
+                    const uint32_t first = lo ? s_pref[lo - 1] : 0u;
+                    j[k] = s_rb0[lo] + (it - first);          // slot of w in row b
+                }
+                int32_t wv[kTriU];
+#pragma unroll
+                for (int k = 0; k < kTriU; ++k) wv[k] = valid[k] ? ocol[j[k]] : 0;
+#pragma unroll
+                for (int k = 0; k < kTriU; ++k) {
+                    if (!valid[k]) continue;
+                    uint32_t l = s_ra0[t[k]], h = s_ra1[t[k]];
                     const uint32_t rend = h;
                     bool found;
                     if (staged) {
-                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (s_col[mid] < wv) l = mid + 1; else h = mid; }
-                        found = l < rend && s_col[l] == wv;
+                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (s_col[mid] < wv[k]) l = mid + 1; else h = mid; }
+                        found = l < rend && s_col[l] == wv[k];
                     } else {
-                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wv) l = mid + 1; else h = mid; }
-                        found = l < rend && ocol[S0 + l] == wv;
+                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wv[k]) l = mid + 1; else h = mid; }
+                        found = l < rend && ocol[S0 + l] == wv[k];
                     }
                     if (found) {
-                        const uint32_t e_rel = p0 + (uint32_t)t, i_rel = l;
-                        const uint32_t e = S0 + e_rel, i = S0 + i_rel;
+                        const uint32_t e_rel = p0 + (uint32_t)t[k], i_rel = l;
+                        const uint32_t e = S0 + e_rel, i = S0 + i_rel, jj = j[k];
                         if (!FILL) {
                             if (staged) { atomicAdd(&s_cnt[e_rel], 1u); atomicAdd(&s_cnt[i_rel], 1u); }
                             else { atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); }
-                            atomicAdd(&other_or_cursor[j], 1u);
+                            atomicAdd(&other_or_cursor[jj], 1u);
                         } else {
                             uint32_t pe, pi;
                             if (staged) {
@@ -209,9 +264,9 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
                                 pe = atomicAdd(&other_or_cursor[e], 1u);
                                 pi = atomicAdd(&other_or_cursor[i], 1u);
                             }
-                            const uint32_t pj = atomicAdd(&other_or_cursor[j], 1u);
-                            inc[pe] = make_int2((int)i, (int)j);
-                            inc[pi] = make_int2((int)e, (int)j);
+                            const uint32_t pj = atomicAdd(&other_or_cursor[jj], 1u);
+                            inc[pe] = make_int2((int)i, (int)jj);
+                            inc[pi] = make_int2((int)e, (int)jj);
                             inc[pj] = make_int2((int)e, (int)i);
                         }
                     }
@@ -282,24 +337,32 @@ struct TrussProblem {
         b = off[e];
         len = off[e + 1] - b;
     }
-    __device__ __forceinline__ void item(int32_t me, uint32_t pos, const CtrlView &cv, int32_t &t0, int32_t &t1) const
+    struct Loaded { int32_t me, x, y, sx, sy; };
+    __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
     {
+        Loaded ld;
         const int2 p = inc[pos];
-        const int32_t x = p.x, y = p.y, r = cv.round, L = cv.level;
-        const int32_t sx = stamp[x], sy = stamp[y];
-        if (sx < r || sy < r) return;                   // an edge of the triangle is already gone
-        const bool xin = (sx == r), yin = (sy == r);
-        const bool decx = !xin && (!yin || me < y);
-        const bool decy = !yin && (!xin || me < x);
-        if (decx && atomicSub(&sup[x], 1) == L + 1) { stamp[x] = r + 1; truss[x] = L + 2; t0 = x; }
-        if (decy && atomicSub(&sup[y], 1) == L + 1) { stamp[y] = r + 1; truss[y] = L + 2; t1 = y; }
+        ld.me = me; ld.x = p.x; ld.y = p.y;
+        ld.sx = stamp[p.x]; ld.sy = stamp[p.y];
+        return ld;
+    }
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &t1) const
+    {
+        const int32_t r = cv.round, L = cv.level;
+        if (ld.sx < r || ld.sy < r) return;             // an edge of the triangle is already gone
+        const bool xin = (ld.sx == r), yin = (ld.sy == r);
+        const bool decx = !xin && (!yin || ld.me < ld.y);
+        const bool decy = !yin && (!xin || ld.me < ld.x);
+        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; truss[ld.x] = L + 2; t0 = ld.x; }
+        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; truss[ld.y] = L + 2; t1 = ld.y; }
     }
 };
 
 // -------------------------------------------------------------- result gather
-// One wavefront per row of the working CSR; upper slots (u < v) in row order
-// are the canonical edge order.  The oriented slot of {u,v} is found by a
-// binary search of the tiny oriented row of the lower-(degree,id) endpoint.
+// One wavefront owns kRowsPerWave rows of the working CSR (see k_row_filter);
+// upper slots (u < v) in slot order are the canonical edge order.  The oriented
+// slot of {u,v} is found by a binary search of the tiny oriented row of the
+// lower-(degree,id) endpoint.
 __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                              int64_t nv, const int32_t *__restrict__ deg,
                                                              const uint32_t *__restrict__ ebase,
@@ -308,35 +371,46 @@ __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__r
                                                              int32_t *__restrict__ eu, int32_t *__restrict__ ev,
                                                              int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
+    __shared__ uint32_t sh_rp[kBlock / kWave][kRowsPerWave + 1];
     const int lane = lane_id();
+    uint32_t *s_rp = sh_rp[threadIdx.x >> 6];
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    for (int64_t u = wave; u < nv; u += nwaves) {
-        const uint32_t b = rowptr[u], e = rowptr[u + 1];
-        uint32_t cnt = 0;
-        const uint32_t obase = ebase[u];
-        const int32_t du = deg[u];
-        for (uint32_t j0 = b; j0 < e; j0 += kWave) {
+    const int64_t ntasks = (nv + kRowsPerWave - 1) / kRowsPerWave;
+    for (int64_t task = wave; task < ntasks; task += nwaves) {
+        const int64_t v0 = task * kRowsPerWave;
+        const int nvt = (int)min((int64_t)kRowsPerWave, nv - v0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane <= nvt) s_rp[lane] = rowptr[v0 + lane];
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t S0 = s_rp[0], S1 = s_rp[nvt];
+        const uint32_t obase = ebase[v0];
+        uint32_t run = 0;
+        for (uint32_t j0 = S0; j0 < S1; j0 += kWave) {
             const uint32_t j = j0 + (uint32_t)lane;
-            int32_t v = 0;
+            int32_t u = 0, v = 0;
             bool keep = false;
-            if (j < e) { v = col[j]; keep = v > (int32_t)u; }
+            if (j < S1) {
+                v = col[j];
+                u = (int32_t)(v0 + row_of_slot(s_rp, nvt, j));
+                keep = v > u;
+            }
             const uint64_t mk = __ballot(keep);
             if (keep) {
-                const uint32_t o = obase + cnt + (uint32_t)__popcll(mk & lanemask_lt());
-                const int32_t dv = deg[v];
-                const bool u_first = du < dv || (du == dv && (int32_t)u < v);
-                const int32_t a = u_first ? (int32_t)u : v, t = u_first ? v : (int32_t)u;
+                const uint32_t o = obase + run + (uint32_t)__popcll(mk & lanemask_lt());
+                const int32_t du = deg[u], dv = deg[v];
+                const bool u_first = du < dv || (du == dv && u < v);
+                const int32_t a = u_first ? u : v, t = u_first ? v : u;
                 uint32_t lo = orow[a], hi = orow[a + 1];
                 while (lo < hi) {                                   // t is present by construction
                     const uint32_t mid = lo + ((hi - lo) >> 1);
                     if (ocol[mid] < t) lo = mid + 1; else hi = mid;
                 }
-                eu[o] = (int32_t)u; ev[o] = v;
+                eu[o] = u; ev[o] = v;
                 tr_out[o] = truss[lo];
                 sup_out[o] = (int32_t)(off[lo + 1] - off[lo]);
             }
-            cnt += (uint32_t)__popcll(mk);
+            run += (uint32_t)__popcll(mk);
         }
     }
 }
@@ -425,7 +499,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         return KOMB_OK;
     }
     DevBufs bufs(ctx);
-    const int gv_wave = grid_for(nv, kBlock / kWave);          // one wave per vertex
+    const int gv_wave = grid_for((nv + kRowsPerWave - 1) / kRowsPerWave, kBlock / kWave);   // one wave per 16 rows
     const int gv = grid_for(nv);
 
     // ---- a5: working CSR = whole graph, or the subgraph induced by vmask

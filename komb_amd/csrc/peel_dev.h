@@ -37,6 +37,7 @@ constexpr int kPeelBlock = 1024;               // 16 wave64 per workgroup
 constexpr int kPeelWaves = kPeelBlock / kWave;
 constexpr int kLight = 64;                     // units with <= kLight items are flattened 64 per wave
 constexpr int kChunk = 256;                    // heavy units: one queue entry per kChunk items
+constexpr int kItemU = 2;                      // items per lane per trip in PROCESS
 constexpr int kStage = 192;                    // per-wave LDS staging of triggered light units
 constexpr int kGroup = 32;                     // workgroups per first-level arrival counter
 constexpr int kMaxGroups = 64;                 // grid <= kGroup * kMaxGroups
@@ -156,7 +157,9 @@ __device__ __forceinline__ void heavy_push(bool pred, int32_t unit, uint32_t nch
 //                                        (to 0x7FFFFFFF for a dead unit) so the caller can track the minimum
 //   void mark_scanned(u, cv)             unit enters the frontier through SCAN
 //   void slice(u, uint32_t &begin, uint32_t &len)
-//   void item(unit, pos, cv, int32_t &t0, int32_t &t1)   process one item; ids of triggered units or -1
+//   Loaded item_load(unit, pos, cv)      the item's loads (no side effects)
+//   void item_apply(ld, cv, int32_t &t0, int32_t &t1)    decrements; ids of triggered units or -1
+// (load and apply are split so that the loads of several items are in flight together)
 template <class P>
 __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p)
 {
@@ -281,26 +284,35 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         const uint64_t gw = (uint64_t)blockIdx.x * kPeelWaves + (uint64_t)w;
         const uint64_t nw = (uint64_t)nblk * kPeelWaves;
 
-        auto run_item = [&](bool active, int32_t unit, uint32_t pos) {
-            int32_t t0 = -1, t1 = -1;
-            if (active) p.item(unit, pos, cv, t0, t1);
+        auto push_trigger = [&](int32_t t) {
+            const bool trig = t >= 0;
+            const uint64_t m = __ballot(trig);
+            if (m == 0) return;
+            n_trig += (uint32_t)__popcll(m);
+            uint32_t b = 0, len = 0;
+            if (trig) p.slice((uint32_t)t, b, len);
+            const bool is_light = trig && len <= (uint32_t)kLight;
+            const bool is_heavy = trig && len > (uint32_t)kLight;
+            stage_push(st, is_light, t, qn_l, tail_nl);
+            if (__ballot(is_heavy)) heavy_push(is_heavy, t, (len + kChunk - 1) / kChunk, qn_h, tail_nh);
+        };
+        // kItemU items per lane per trip: all loads first, then the decrements
+        auto run_items = [&](const bool (&active)[kItemU], const int32_t (&unit)[kItemU], const uint32_t (&pos)[kItemU]) {
+            typename P::Loaded ld[kItemU];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int32_t t = k ? t1 : t0;
-                const bool trig = t >= 0;
-                const uint64_t m = __ballot(trig);
-                if (m == 0) continue;
-                n_trig += (uint32_t)__popcll(m);
-                uint32_t b = 0, len = 0;
-                if (trig) p.slice((uint32_t)t, b, len);
-                const bool is_light = trig && len <= (uint32_t)kLight;
-                const bool is_heavy = trig && len > (uint32_t)kLight;
-                stage_push(st, is_light, t, qn_l, tail_nl);
-                if (__ballot(is_heavy)) heavy_push(is_heavy, t, (len + kChunk - 1) / kChunk, qn_h, tail_nh);
+            for (int k = 0; k < kItemU; ++k)
+                if (active[k]) ld[k] = p.item_load(unit[k], pos[k], cv);
+            int32_t trg[2 * kItemU];
+#pragma unroll
+            for (int k = 0; k < kItemU; ++k) {
+                trg[2 * k] = -1; trg[2 * k + 1] = -1;
+                if (active[k]) p.item_apply(ld[k], cv, trg[2 * k], trg[2 * k + 1]);
             }
+#pragma unroll
+            for (int k = 0; k < 2 * kItemU; ++k) push_trigger(trg[k]);
         };
 
-        // light units: 64 per wave, slices flattened over the lanes
+        // light units: bsz per wave, slices flattened over the lanes
         const uint64_t n_batches = ((uint64_t)cv.cur_light + bsz - 1) / bsz;
         uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w];
         int32_t *s_unit = sh_unit[w];
@@ -314,22 +326,27 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             __builtin_amdgcn_wave_barrier();
             s_end[lane] = incl; s_beg[lane] = beg; s_unit[lane] = unit;
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
-                const uint32_t it = it0 + (uint32_t)lane;
-                const bool active = it < total;
-                int32_t me = -1;
-                uint32_t pos = 0;
-                if (active) {
-                    int lo = 0, hi = kWave - 1;             // smallest t with s_end[t] > it
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_end[mid] > it) hi = mid; else lo = mid + 1;
+            for (uint32_t it0 = 0; it0 < total; it0 += kWave * kItemU) {
+                bool active[kItemU];
+                int32_t me[kItemU];
+                uint32_t pos[kItemU];
+#pragma unroll
+                for (int k = 0; k < kItemU; ++k) {
+                    const uint32_t it = it0 + (uint32_t)(k * kWave + lane);
+                    active[k] = it < total;
+                    me[k] = -1; pos[k] = 0;
+                    if (active[k]) {
+                        int lo = 0, hi = kWave - 1;         // smallest t with s_end[t] > it
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_end[mid] > it) hi = mid; else lo = mid + 1;
+                        }
+                        const uint32_t first = lo ? s_end[lo - 1] : 0u;
+                        me[k] = s_unit[lo];
+                        pos[k] = s_beg[lo] + (it - first);
                     }
-                    const uint32_t first = lo ? s_end[lo - 1] : 0u;
-                    me = s_unit[lo];
-                    pos = s_beg[lo] + (it - first);
                 }
-                run_item(active, me, pos);
+                run_items(active, me, pos);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -340,9 +357,16 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             p.slice((uint32_t)ent.x, beg, len);
             const uint32_t c0 = (uint32_t)ent.y * kChunk;
             const uint32_t c1 = min(len, c0 + (uint32_t)kChunk);
-            for (uint32_t it0 = c0; it0 < c1; it0 += kWave) {
-                const uint32_t it = it0 + (uint32_t)lane;
-                run_item(it < c1, ent.x, beg + it);
+            for (uint32_t it0 = c0; it0 < c1; it0 += kWave * kItemU) {
+                bool active[kItemU];
+                int32_t me[kItemU];
+                uint32_t pos[kItemU];
+#pragma unroll
+                for (int k = 0; k < kItemU; ++k) {
+                    const uint32_t it = it0 + (uint32_t)(k * kWave + lane);
+                    active[k] = it < c1; me[k] = ent.x; pos[k] = beg + it;
+                }
+                run_items(active, me, pos);
             }
         }
         stage_flush(st, qn_l, tail_nl);
