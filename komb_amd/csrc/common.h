@@ -118,6 +118,7 @@ struct komb_ctx {
     int64_t nv = -1, ne = 0;
     uint32_t *d_rowptr = nullptr;            // [nv+1]
     int32_t  *d_col = nullptr;               // [2*ne]
+    int32_t  *d_src = nullptr;               // [2*ne] row of every slot
 
     // ---- k-core results
     int32_t *d_deg = nullptr;                // [nv] degree (a2)

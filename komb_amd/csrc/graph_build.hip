@@ -33,12 +33,14 @@ __global__ __launch_bounds__(kBlock) void k_make_keys(const int64_t *__restrict_
 
 // uniq[0..ns) sorted by (src,dst): col[j] = dst, rowptr[v] = first slot with src >= v
 __global__ __launch_bounds__(kBlock) void k_keys_to_csr(const uint64_t *__restrict__ uniq, int64_t ns, int64_t nv,
-                                                        uint32_t *__restrict__ rowptr, int32_t *__restrict__ col)
+                                                        uint32_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                        int32_t *__restrict__ src)
 {
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
         const uint64_t k = uniq[j];
         const int64_t s = (int64_t)(k >> 32);
         col[j] = (int32_t)(k & 0xFFFFFFFFu);
+        src[j] = (int32_t)s;
         const int64_t p = (j == 0) ? -1 : (int64_t)(uniq[j - 1] >> 32);
         for (int64_t v = p + 1; v <= s; ++v) rowptr[v] = (uint32_t)j;
         if (j == ns - 1)
@@ -82,6 +84,16 @@ __global__ __launch_bounds__(kBlock) void k_validate_csr(const uint32_t *__restr
     }
 }
 
+// src[j] = row of slot j, for a caller-supplied CSR (one wavefront per row, once per graph)
+__global__ __launch_bounds__(kBlock) void k_fill_src(const uint32_t *__restrict__ rowptr, int64_t nv, int32_t *__restrict__ src)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t v = wave; v < nv; v += nwaves)
+        for (uint32_t j = rowptr[v] + (uint32_t)lane; j < rowptr[v + 1]; j += 64) src[j] = (int32_t)v;
+}
+
 inline int grid_for(int64_t n)
 {
     int64_t g = (n + kBlock - 1) / kBlock;
@@ -96,9 +108,10 @@ void graph_free(komb_ctx *ctx)
 {
     if (ctx->d_rowptr) (void)hipFree(ctx->d_rowptr);
     if (ctx->d_col) (void)hipFree(ctx->d_col);
+    if (ctx->d_src) (void)hipFree(ctx->d_src);
     if (ctx->d_deg) (void)hipFree(ctx->d_deg);
     if (ctx->d_core) (void)hipFree(ctx->d_core);
-    ctx->d_rowptr = nullptr; ctx->d_col = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
+    ctx->d_rowptr = nullptr; ctx->d_col = nullptr; ctx->d_src = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
     truss_free(ctx);
     ctx->pool.clear();                                   // scratch sized for the old graph
@@ -152,14 +165,16 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
         if (ns > 0xFFFFFFF0ll) { cleanup(); KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld slots; limit is 2^32-16", (long long)ns); }
         if (ns / 2 > INT32_MAX - 16) { cleanup(); KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld edges; limit is 2^31-16", (long long)(ns / 2)); }
         e = hipMalloc(&ctx->d_col, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_src, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
         if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
-        if (ns > 0) k_keys_to_csr<<<grid_for(ns), kBlock, 0, s>>>(other, ns, nv, ctx->d_rowptr, ctx->d_col);
+        if (ns > 0) k_keys_to_csr<<<grid_for(ns), kBlock, 0, s>>>(other, ns, nv, ctx->d_rowptr, ctx->d_col, ctx->d_src);
         else k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_rowptr, nv + 1, 0u);
         e = hipStreamSynchronize(s);
         cleanup();
         KOMB_HIP(ctx, e);
     } else {
         KOMB_HIP(ctx, hipMalloc(&ctx->d_col, sizeof(int32_t)));
+        KOMB_HIP(ctx, hipMalloc(&ctx->d_src, sizeof(int32_t)));
         k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_rowptr, nv + 1, 0u);
         KOMB_HIP(ctx, hipStreamSynchronize(s));
     }
@@ -186,6 +201,7 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
     int64_t *d_rp64 = nullptr; int *d_bad = nullptr;
     KOMB_HIP(ctx, hipMalloc(&ctx->d_rowptr, (size_t)(nv + 1) * sizeof(uint32_t)));
     KOMB_HIP(ctx, hipMalloc(&ctx->d_col, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t)));
+    KOMB_HIP(ctx, hipMalloc(&ctx->d_src, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t)));
     hipError_t e = hipMalloc(&d_rp64, (size_t)(nv + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
@@ -198,6 +214,7 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
     if (e == hipSuccess && !bad && nv > 0) {                     // rowptr is sane: rows can be walked safely
+        k_fill_src<<<grid_for(nv * 16), kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_src);
         k_validate_csr<<<grid_for(nv), kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, nv, d_bad);
         e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);

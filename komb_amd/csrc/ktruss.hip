@@ -52,77 +52,98 @@ struct PredOrient {                     // keep slot (a,b) when a precedes b in 
         return da < db || (da == db && a < b);
     }
 };
-struct PredUpper {                      // keep slot (a,b) when a < b: the canonical copy of the edge
-    __device__ bool operator()(int32_t a, int32_t b) const { return a < b; }
-};
 
-// One wavefront owns kRowsPerWave consecutive rows = one contiguous slot range of
-// the CSR, swept 64 slots at a time with all lanes busy; the row of a slot is
-// found by a binary search over the 17 staged row pointers.  Ballot + prefix
-// popcount keeps slot order, so the kept slots of the owned rows land
-// contiguously from out_rowptr[first owned row].
-constexpr int kRowsPerWave = 16;
-
-__device__ __forceinline__ int row_of_slot(const uint32_t *s_rp, int nrows, uint32_t j)
-{
-    int lo = 0, hi = nrows - 1;                       // last idx with s_rp[idx] <= j
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (s_rp[mid] <= j) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
+// ------------------------------------------------------- slot-parallel filters
+// A row filter (induced subgraph, orientation) keeps a subset of the CSR slots
+// in slot order: a global ordered stream compaction.  Every slot knows its row
+// through src[], so work is split by SLOTS, not rows -- a 134k-slot hub row is
+// shared by dozens of workgroups instead of serialising one wavefront.
+// Pass 1 counts the kept slots of each workgroup's chunk; an exclusive scan of
+// the per-chunk counts gives chunk bases; pass 2 recomputes the predicate and
+// writes (col, src) at base + block-local ordered prefix (ballot + popcount per
+// wave, wave totals through LDS).  Row pointers of the result follow from the
+// (sorted) src of the kept slots.
+constexpr int kSlotsPerThread = 16;
+constexpr int kChunkSlots = kBlock * kSlotsPerThread;          // slots per workgroup
 
 template <class Pred, bool FILL>
-__global__ __launch_bounds__(kBlock) void k_row_filter(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                       int64_t nv, Pred pred, uint32_t *__restrict__ out_count,
-                                                       const uint32_t *__restrict__ out_rowptr, int32_t *__restrict__ out_col,
-                                                       int32_t *__restrict__ out_src)
+__global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restrict__ src, const int32_t *__restrict__ col,
+                                                        int64_t ns, Pred pred, uint32_t *__restrict__ chunk_count,
+                                                        const uint32_t *__restrict__ chunk_base,
+                                                        int32_t *__restrict__ out_col, int32_t *__restrict__ out_src)
 {
-    __shared__ uint32_t sh_rp[kBlock / kWave][kRowsPerWave + 1];
-    __shared__ uint32_t sh_cnt[kBlock / kWave][kRowsPerWave];
+    __shared__ uint32_t sh_wave[kBlock / kWave];
     const int lane = lane_id();
-    uint32_t *s_rp = sh_rp[threadIdx.x >> 6], *s_cnt = sh_cnt[threadIdx.x >> 6];
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    const int64_t ntasks = (nv + kRowsPerWave - 1) / kRowsPerWave;
-    for (int64_t task = wave; task < ntasks; task += nwaves) {
-        const int64_t v0 = task * kRowsPerWave;
-        const int nvt = (int)min((int64_t)kRowsPerWave, nv - v0);
-        __builtin_amdgcn_wave_barrier();
-        if (lane <= nvt) s_rp[lane] = rowptr[v0 + lane];
-        if (lane < kRowsPerWave) s_cnt[lane] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t S0 = s_rp[0], S1 = s_rp[nvt];
-        const uint32_t obase = FILL ? out_rowptr[v0] : 0u;
-        uint32_t run = 0;
-        for (uint32_t j0 = S0; j0 < S1; j0 += kWave) {
-            const uint32_t j = j0 + (uint32_t)lane;
-            int32_t c = 0, a = 0;
+    const int w = (int)(threadIdx.x >> 6);
+    const int64_t nchunks = (ns + kChunkSlots - 1) / kChunkSlots;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t c0 = chunk * kChunkSlots;
+        uint32_t run = FILL ? chunk_base[chunk] : 0u;          // kept slots before the current 256-slot row of the chunk
+        uint32_t total = 0;
+        for (int r = 0; r < kSlotsPerThread; ++r) {
+            const int64_t j = c0 + (int64_t)r * kBlock + threadIdx.x;
+            int32_t a = 0, c = 0;
             bool keep = false;
-            int r = 0;
-            if (j < S1) {
-                c = col[j];
-                r = row_of_slot(s_rp, nvt, j);
-                a = (int32_t)(v0 + r);
-                keep = pred(a, c);
-            }
+            if (j < ns) { a = src[j]; c = col[j]; keep = pred(a, c); }
             const uint64_t m = __ballot(keep);
+            const uint32_t wcnt = (uint32_t)__popcll(m);
+            if (!FILL) { total += wcnt; continue; }
+            __syncthreads();
+            if (lane == 0) sh_wave[w] = wcnt;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int i = 0; i < kBlock / kWave; ++i) { const uint32_t x = sh_wave[i]; if (i < w) before += x; all += x; }
             if (keep) {
-                if (FILL) {
-                    const uint32_t o = obase + run + (uint32_t)__popcll(m & lanemask_lt());
-                    out_col[o] = c;
-                    if (out_src) out_src[o] = a;
-                } else {
-                    atomicAdd(&s_cnt[r], 1u);
-                }
+                const uint32_t o = run + before + (uint32_t)__popcll(m & lanemask_lt());
+                out_col[o] = c;
+                out_src[o] = a;
             }
-            run += (uint32_t)__popcll(m);
+            run += all;
         }
-        if (!FILL) {
-            __builtin_amdgcn_wave_barrier();
-            if (lane < nvt) out_count[v0 + lane] = s_cnt[lane];
+        if (!FILL) {                                            // per-wave totals -> chunk count
+            __syncthreads();
+            if (lane == 0) sh_wave[w] = total;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t t = 0;
+                for (int i = 0; i < kBlock / kWave; ++i) t += sh_wave[i];
+                chunk_count[chunk] = t;
+            }
         }
+    }
+}
+
+// row pointers of a CSR from the ascending src[] of its slots (gaps = empty rows)
+__global__ __launch_bounds__(kBlock) void k_rowptr_from_src(const int32_t *__restrict__ src, int64_t ns, int64_t nv,
+                                                            uint32_t *__restrict__ rowptr)
+{
+    if (ns == 0) {
+        for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) rowptr[v] = 0u;
+        return;
+    }
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t a = src[j];
+        const int64_t p = (j == 0) ? -1 : (int64_t)src[j - 1];
+        for (int64_t v = p + 1; v <= a; ++v) rowptr[v] = (uint32_t)j;
+        if (j == ns - 1)
+            for (int64_t v = a + 1; v <= nv; ++v) rowptr[v] = (uint32_t)ns;
+    }
+}
+
+// number of upper slots (col > row id) of every row: rows are ascending, so it is a suffix
+__global__ __launch_bounds__(kBlock) void k_upper_count(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        int64_t nv, uint32_t *__restrict__ ucnt)
+{
+    for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < nv; u += (int64_t)gridDim.x * kBlock) {
+        uint32_t lo = rowptr[u];
+        const uint32_t end = rowptr[u + 1];
+        uint32_t hi = end;
+        while (lo < hi) {                                       // first slot with col > u
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (col[mid] > (int32_t)u) hi = mid; else lo = mid + 1;
+        }
+        ucnt[u] = end - lo;
     }
 }
 
@@ -359,59 +380,36 @@ struct TrussProblem {
 };
 
 // -------------------------------------------------------------- result gather
-// One wavefront owns kRowsPerWave rows of the working CSR (see k_row_filter);
-// upper slots (u < v) in slot order are the canonical edge order.  The oriented
-// slot of {u,v} is found by a binary search of the tiny oriented row of the
-// lower-(degree,id) endpoint.
-__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                             int64_t nv, const int32_t *__restrict__ deg,
-                                                             const uint32_t *__restrict__ ebase,
+// One thread per slot of the working CSR.  Upper slots (u < v) are the canonical
+// copies of the edges; they are the suffix of their (ascending) row, so the
+// canonical id is ebase[u] + (j - first upper slot of u) with no compaction.
+// The oriented slot of {u,v} -- where trussness and support live -- is found by
+// a binary search of the tiny oriented row of the lower-(degree,id) endpoint.
+__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
+                                                             const int32_t *__restrict__ col, int64_t ns,
+                                                             const int32_t *__restrict__ deg, const uint32_t *__restrict__ ebase,
                                                              const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                              const uint32_t *__restrict__ off, const int32_t *__restrict__ truss,
                                                              int32_t *__restrict__ eu, int32_t *__restrict__ ev,
                                                              int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
-    __shared__ uint32_t sh_rp[kBlock / kWave][kRowsPerWave + 1];
-    const int lane = lane_id();
-    uint32_t *s_rp = sh_rp[threadIdx.x >> 6];
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    const int64_t ntasks = (nv + kRowsPerWave - 1) / kRowsPerWave;
-    for (int64_t task = wave; task < ntasks; task += nwaves) {
-        const int64_t v0 = task * kRowsPerWave;
-        const int nvt = (int)min((int64_t)kRowsPerWave, nv - v0);
-        __builtin_amdgcn_wave_barrier();
-        if (lane <= nvt) s_rp[lane] = rowptr[v0 + lane];
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t S0 = s_rp[0], S1 = s_rp[nvt];
-        const uint32_t obase = ebase[v0];
-        uint32_t run = 0;
-        for (uint32_t j0 = S0; j0 < S1; j0 += kWave) {
-            const uint32_t j = j0 + (uint32_t)lane;
-            int32_t u = 0, v = 0;
-            bool keep = false;
-            if (j < S1) {
-                v = col[j];
-                u = (int32_t)(v0 + row_of_slot(s_rp, nvt, j));
-                keep = v > u;
-            }
-            const uint64_t mk = __ballot(keep);
-            if (keep) {
-                const uint32_t o = obase + run + (uint32_t)__popcll(mk & lanemask_lt());
-                const int32_t du = deg[u], dv = deg[v];
-                const bool u_first = du < dv || (du == dv && u < v);
-                const int32_t a = u_first ? u : v, t = u_first ? v : u;
-                uint32_t lo = orow[a], hi = orow[a + 1];
-                while (lo < hi) {                                   // t is present by construction
-                    const uint32_t mid = lo + ((hi - lo) >> 1);
-                    if (ocol[mid] < t) lo = mid + 1; else hi = mid;
-                }
-                eu[o] = u; ev[o] = v;
-                tr_out[o] = truss[lo];
-                sup_out[o] = (int32_t)(off[lo + 1] - off[lo]);
-            }
-            run += (uint32_t)__popcll(mk);
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
+        const int32_t u = src[j], v = col[j];
+        if (v <= u) continue;
+        const uint32_t eb = ebase[u];
+        const uint32_t first_upper = rowptr[u + 1] - (ebase[u + 1] - eb);
+        const uint32_t o = eb + ((uint32_t)j - first_upper);
+        const int32_t du = deg[u], dv = deg[v];
+        const bool u_first = du < dv || (du == dv && u < v);
+        const int32_t a = u_first ? u : v, t = u_first ? v : u;
+        uint32_t lo = orow[a], hi = orow[a + 1];
+        while (lo < hi) {                                       // t is present by construction
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (ocol[mid] < t) lo = mid + 1; else hi = mid;
         }
+        eu[o] = u; ev[o] = v;
+        tr_out[o] = truss[lo];
+        sup_out[o] = (int32_t)(off[lo + 1] - off[lo]);
     }
 }
 
@@ -478,6 +476,31 @@ void truss_free(komb_ctx *ctx)
     ctx->t_ne = -1; ctx->truss_done = false;
 }
 
+// ordered compaction of the CSR slots (src,col)[ns] that satisfy pred -> (out_src,out_col)[n_out] + out_rowptr
+template <class Pred>
+static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const int32_t *col, int64_t ns, int64_t nv, Pred pred,
+                         uint32_t *out_rowptr, int32_t **out_col, int32_t **out_src, int64_t *n_out)
+{
+    hipStream_t s = ctx->stream;
+    const int64_t nchunks = (ns + kChunkSlots - 1) / kChunkSlots;
+    uint32_t *d_cc = nullptr, *d_cb = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_cc, (size_t)nchunks + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_cb, (size_t)nchunks + 1));
+    KOMB_HIP(ctx, hipMemsetAsync(d_cc, 0, ((size_t)nchunks + 1) * sizeof(uint32_t), s));
+    const int g = grid_for(nchunks, 1, 256 * 32);
+    k_slot_filter<Pred, false><<<g, kBlock, 0, s>>>(src, col, ns, pred, d_cc, nullptr, nullptr, nullptr);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cc, d_cb, nchunks + 1));
+    uint32_t kept = 0;
+    KOMB_HIP(ctx, d2h(ctx, &kept, d_cb + nchunks, sizeof(uint32_t)));
+    KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept));
+    KOMB_HIP(ctx, bufs.alloc(out_src, (size_t)kept));
+    k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src);
+    k_rowptr_from_src<<<grid_for(kept > 0 ? kept : nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
+    bufs.release(d_cc); bufs.release(d_cb);
+    *n_out = (int64_t)kept;
+    return KOMB_OK;
+}
+
 // rank/world/fn: support counting is sharded by source-vertex range; fn sums the
 // partial support vectors over the ranks (RCCL all-reduce on the host side).
 int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, komb_allreduce_fn fn, void *user)
@@ -499,27 +522,21 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         return KOMB_OK;
     }
     DevBufs bufs(ctx);
-    const int gv_wave = grid_for((nv + kRowsPerWave - 1) / kRowsPerWave, kBlock / kWave);   // one wave per 16 rows
     const int gv = grid_for(nv);
 
-    // ---- a5: working CSR = whole graph, or the subgraph induced by vmask
+    // ---- a5: working CSR = whole graph, or the subgraph induced by vmask (original ids kept)
     const uint32_t *w_rowptr = ctx->d_rowptr;
-    const int32_t *w_col = ctx->d_col;
+    const int32_t *w_col = ctx->d_col, *w_src = ctx->d_src;
+    int64_t w_ns = 2 * ctx->ne;
     if (vmask_host) {
-        uint8_t *d_mask = nullptr; uint32_t *d_cnt = nullptr, *d_rp = nullptr; int32_t *d_c = nullptr;
+        uint8_t *d_mask = nullptr; uint32_t *d_rp = nullptr; int32_t *d_c = nullptr, *d_s = nullptr;
         KOMB_HIP(ctx, bufs.alloc(&d_mask, (size_t)nv));
-        KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)nv + 1));
         KOMB_HIP(ctx, bufs.alloc(&d_rp, (size_t)nv + 1));
         KOMB_HIP(ctx, hipMemcpyAsync(d_mask, vmask_host, (size_t)nv, hipMemcpyHostToDevice, s));
-        KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
-        k_row_filter<PredMask, false><<<gv_wave, kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, nv, PredMask{d_mask}, d_cnt, nullptr, nullptr, nullptr);
-        KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_rp, nv + 1));
-        uint32_t ns_sub = 0;
-        KOMB_HIP(ctx, d2h(ctx, &ns_sub, d_rp + nv, sizeof(uint32_t)));
-        KOMB_HIP(ctx, bufs.alloc(&d_c, (size_t)ns_sub));
-        k_row_filter<PredMask, true><<<gv_wave, kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, nv, PredMask{d_mask}, nullptr, d_rp, d_c, nullptr);
-        bufs.release(d_mask); bufs.release(d_cnt);
-        w_rowptr = d_rp; w_col = d_c;
+        int64_t ns_sub = 0;
+        KOMB_TRY(compact_slots(ctx, bufs, ctx->d_src, ctx->d_col, w_ns, nv, PredMask{d_mask}, d_rp, &d_c, &d_s, &ns_sub));
+        bufs.release(d_mask);
+        w_rowptr = d_rp; w_col = d_c; w_src = d_s; w_ns = ns_sub;
         if (ns_sub == 0) {
             KOMB_HIP(ctx, hipStreamSynchronize(s));
             KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
@@ -530,23 +547,14 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
 
     // ---- orientation: oriented CSR, internal edge id = oriented slot
-    int32_t *d_deg = nullptr; uint32_t *d_ocnt = nullptr, *d_orow = nullptr;
+    int32_t *d_deg = nullptr; uint32_t *d_orow = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_deg, (size_t)nv));
-    KOMB_HIP(ctx, bufs.alloc(&d_ocnt, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_orow, (size_t)nv + 1));
     ctx->timer.start(s);
     k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg);
-    KOMB_HIP(ctx, hipMemsetAsync(d_ocnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
-    k_row_filter<PredOrient, false><<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, PredOrient{d_deg}, d_ocnt, nullptr, nullptr, nullptr);
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ocnt, d_orow, nv + 1));
-    uint32_t m32 = 0;
-    KOMB_HIP(ctx, d2h(ctx, &m32, d_orow + nv, sizeof(uint32_t)));
-    const int64_t m = (int64_t)m32;
-    bufs.release(d_ocnt);
     int32_t *d_ocol = nullptr, *d_osrc = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_ocol, (size_t)m));
-    KOMB_HIP(ctx, bufs.alloc(&d_osrc, (size_t)m));
-    k_row_filter<PredOrient, true><<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, PredOrient{d_deg}, nullptr, d_orow, d_ocol, d_osrc);
+    int64_t m = 0;
+    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg}, d_orow, &d_ocol, &d_osrc, &m));
     st.ms_orient = ctx->timer.stop(s);
 
     // ---- support (pass 1), slice offsets, incidence lists (pass 2)
@@ -639,14 +647,14 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
     KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
-    k_row_filter<PredUpper, false><<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, PredUpper{}, d_ucnt, nullptr, nullptr, nullptr);
+    k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-    k_gather_canonical<<<gv_wave, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_deg, d_ebase, d_orow, d_ocol, d_off, d_truss,
-                                                  ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
+    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_deg, d_ebase, d_orow, d_ocol, d_off, d_truss,
+                                                        ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
     ctx->t_ne = m;
     ctx->truss_done = true;
