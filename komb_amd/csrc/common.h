@@ -124,6 +124,7 @@ struct komb_ctx {
     int32_t *d_deg = nullptr;                // [nv] degree (a2)
     int32_t *d_core = nullptr;               // [nv] coreness (a3)
     bool core_done = false;
+    bool moments_valid = false;              // komb_stats graph moments computed for the resident graph
 
     // ---- k-truss results (internal edge id = oriented slot)
     int64_t t_ne = -1;                       // edges of the (sub)graph last run

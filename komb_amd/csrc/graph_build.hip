@@ -112,7 +112,7 @@ void graph_free(komb_ctx *ctx)
     if (ctx->d_deg) (void)hipFree(ctx->d_deg);
     if (ctx->d_core) (void)hipFree(ctx->d_core);
     ctx->d_rowptr = nullptr; ctx->d_col = nullptr; ctx->d_src = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
-    ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
+    ctx->nv = -1; ctx->ne = 0; ctx->core_done = false; ctx->moments_valid = false;
     truss_free(ctx);
     ctx->pool.clear();                                   // scratch sized for the old graph
 }

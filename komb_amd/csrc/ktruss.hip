@@ -304,9 +304,16 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
 
 // sup = own + other; cursor (reusing other) = where j-role entries of the slice start
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ own, const uint32_t *__restrict__ other,
-                                                       int64_t m1, uint32_t *__restrict__ sum)
+                                                       int64_t m1, uint32_t *__restrict__ sum, unsigned long long *__restrict__ total)
 {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m1; e += (int64_t)gridDim.x * kBlock) sum[e] = own[e] + other[e];
+    unsigned long long t = 0;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m1; e += (int64_t)gridDim.x * kBlock) {
+        const uint32_t c = own[e] + other[e];
+        sum[e] = c;
+        t += c;
+    }
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane_id() == 0 && t) atomicAdd(total, t);               // 64-bit: the 32-bit slice offsets must not wrap
 }
 __global__ __launch_bounds__(kBlock) void k_init_cursor(const uint32_t *__restrict__ off, const uint32_t *__restrict__ own,
                                                         int64_t m, uint32_t *__restrict__ cursor)
@@ -578,21 +585,27 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
         st.ms_allreduce = ctx->timer.stop(s);
     }
-    k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt);
-    // the 32-bit slice offsets must not wrap: take the 64-bit total first
+    unsigned long long *d_mom = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_mom, 6));
+    KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 6 * sizeof(unsigned long long), s));
+    k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt, d_mom + 5);
+    // graph statistics for the roofline model (sum d^2, sum min(d,d), max d, sum d+ + d+): properties of
+    // the graph, not results of the path -- computed on the first whole-graph run and on every subgraph run
+    const bool want_moments = vmask_host != nullptr || !ctx->moments_valid;
+    if (want_moments) k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_cnt, d_orow, d_mom);
     {
-        unsigned long long *d_mom = nullptr;
-        KOMB_HIP(ctx, bufs.alloc(&d_mom, 5));
-        KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 5 * sizeof(unsigned long long), s));
-        k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_cnt, d_orow, d_mom);
-        unsigned long long mom[5];
+        unsigned long long mom[6];
         KOMB_HIP(ctx, d2h(ctx, mom, d_mom, sizeof(mom)));
-        st.sum_deg_sq = (int64_t)mom[0]; st.wedge_items = (int64_t)mom[1]; st.max_degree = (int32_t)mom[2];
-        st.triangles = (int64_t)(mom[3] / 3); st.oriented_items = (int64_t)mom[4];
+        if (want_moments) {
+            st.sum_deg_sq = (int64_t)mom[0]; st.wedge_items = (int64_t)mom[1]; st.max_degree = (int32_t)mom[2];
+            st.oriented_items = (int64_t)mom[4];
+            ctx->moments_valid = vmask_host == nullptr;
+        }
+        st.triangles = (int64_t)(mom[5] / 3);
         bufs.release(d_mom);
-        if (mom[3] > 0xFFFFFFF0ull)
+        if (mom[5] > 0xFFFFFFF0ull)
             KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %llu triangles; the incidence index is limited to 2^32-16 entries (3 per triangle)",
-                      mom[3] / 3);
+                      mom[5] / 3);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_off, m + 1));
     uint32_t total = 0;

@@ -150,6 +150,85 @@ __device__ __forceinline__ void heavy_push(bool pred, int32_t unit, uint32_t nch
     }
 }
 
+// ------------------------------------------------------- step planning / finalisation
+constexpr uint32_t kSmallScan = 16384;          // a live list this short is scanned by one workgroup
+constexpr uint32_t kSmallLight = 64;            // a frontier this small (and <= kSmallHeavy chunks) is one workgroup's step
+constexpr uint32_t kSmallHeavy = 4;
+constexpr uint32_t kMaxInKernelSteps = 8192;    // bound on steps one launch may chain
+
+// How many workgroups take part in the step described by cv, and the light batch width.
+__device__ __forceinline__ uint32_t plan_step(const CtrlView &cv, uint32_t grid, uint32_t &bsz)
+{
+    // light units per wave batch: 64 when the frontier is large, fewer (>= 4) when it would
+    // otherwise leave most of the grid's wavefronts without work
+    bsz = kWave;
+    const uint64_t grid_waves = (uint64_t)grid * kPeelWaves;
+    while (bsz > 4 && (uint64_t)cv.cur_light < grid_waves * (bsz / 2)) bsz >>= 1;
+    if (cv.mode == MODE_SCAN) return (cv.live_mode != 0 && cv.live_count <= kSmallScan) ? 1u : grid;
+    if (cv.cur_light <= kSmallLight && cv.cur_heavy <= kSmallHeavy) {
+        // small frontier: one workgroup (its 16 wavefronts share the units) -- cheaper than a
+        // grid-wide step, and it lets the workgroup chain the following steps in-kernel
+        bsz = 4;
+        while (bsz < (uint32_t)kWave && bsz * kPeelWaves < cv.cur_light) bsz <<= 1;
+        return 1u;
+    }
+    const uint64_t wave_jobs = ((uint64_t)cv.cur_light + bsz - 1) / bsz + (uint64_t)cv.cur_heavy;
+    const uint64_t need = (wave_jobs + kPeelWaves - 1) / kPeelWaves;
+    return (uint32_t)(need < 1 ? 1 : (need > grid ? grid : need));
+}
+
+// Rewrite the control block after a step.  Called by all 64 lanes of ONE wavefront once every
+// participating workgroup has arrived; the independent atomics are issued from different lanes
+// so they cost one round trip, not seven.  The new state is also left in *out (LDS) so that a
+// single workgroup can go on to the next step without re-reading global memory.
+__device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out)
+{
+    const int lane = lane_id();
+    const bool scan = cv.mode == MODE_SCAN;
+    const int sel = cv.cur_sel;
+    const bool emitted = scan && (cv.live_mode != 0 || cv.remaining <= units / 4);
+    const int next_q = scan ? sel : (sel ^ 1);
+    uint32_t v = 0;
+    if (lane == 0) v = atomicExch(&ctrl->acc, 0u);
+    else if (lane == 1) v = coherent_load(&ctrl->tail_l[next_q]);
+    else if (lane == 2) v = coherent_load(&ctrl->tail_h[next_q]);
+    else if (lane == 3) v = (uint32_t)atomicExch(&ctrl->next_min, 0x7FFFFFFF);
+    else if (lane == 4) v = emitted ? atomicExch(&ctrl->live_tail, 0u) : 0u;
+    else if (lane == 5) { if (!scan) atomicExch(&ctrl->tail_l[sel], 0u); }
+    else if (lane == 6) { if (!scan) atomicExch(&ctrl->tail_h[sel], 0u); }
+    else if (lane == 7) atomicAdd(scan ? &ctrl->n_scans : &ctrl->n_rounds, 1);
+    const uint32_t acc = (uint32_t)__shfl((int)v, 0);
+    const uint32_t cur_l = (uint32_t)__shfl((int)v, 1), cur_h = (uint32_t)__shfl((int)v, 2);
+    const int32_t nmin = __shfl((int)v, 3);
+    const uint32_t live_n = (uint32_t)__shfl((int)v, 4);
+    if (lane != 0) return;
+    int32_t mode = cv.mode, level = cv.level, round = cv.round, done = 0, nsel = sel;
+    int32_t live_sel = cv.live_sel, live_mode = cv.live_mode;
+    uint32_t live_count = cv.live_count;
+    const uint32_t remaining = cv.remaining - acc;
+    if (scan) {
+        if (emitted) { live_count = live_n; live_sel ^= 1; live_mode = 1; }
+        if (acc > 0) { atomicAdd(&ctrl->n_levels, 1); ctrl->max_level = level; }
+        if (cur_l + cur_h > 0) mode = MODE_PROCESS;
+        else if (remaining == 0) done = 1;
+        else if (acc > 0) level += 1;                       // only item-less units at this level
+        else if (nmin == 0x7FFFFFFF) done = 2;              // live units but no live key: inconsistent
+        else level = nmin;                                  // jump to the first populated level
+    } else {
+        nsel = sel ^ 1; round += 1;
+        if (cur_l + cur_h == 0) {
+            if (remaining == 0) done = 1;
+            else { level += 1; mode = MODE_SCAN; }
+        }
+    }
+    ctrl->mode = mode; ctrl->level = level; ctrl->round = round; ctrl->done = done;
+    ctrl->cur_sel = nsel; ctrl->cur_light = cur_l; ctrl->cur_heavy = cur_h; ctrl->remaining = remaining;
+    ctrl->live_count = live_count; ctrl->live_sel = live_sel; ctrl->live_mode = live_mode;
+    out->mode = mode; out->level = level; out->round = round; out->done = done;
+    out->cur_sel = nsel; out->cur_light = cur_l; out->cur_heavy = cur_h; out->remaining = remaining;
+    out->live_count = live_count; out->live_sel = live_sel; out->live_mode = live_mode;
+}
+
 // ------------------------------------------------------------ the step kernel
 // Problem concept (all __device__):
 //   uint32_t units;
@@ -179,27 +258,20 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         sh_cv.live_sel = ctrl->live_sel; sh_cv.live_mode = ctrl->live_mode;
     }
     __syncthreads();
-    const CtrlView cv = sh_cv;
+    CtrlView cv = sh_cv;
     if (cv.done) return;
-
-    // workgroups that take part in this launch (the rest leave without touching the ticket)
-    // light units per wave batch: 64 when the frontier is large, fewer (>= 4) when it would
-    // otherwise leave most of the grid's wavefronts without work
-    uint32_t bsz = kWave;
-    {
-        const uint64_t grid_waves = (uint64_t)gridDim.x * kPeelWaves;
-        while (bsz > 4 && (uint64_t)cv.cur_light < grid_waves * (bsz / 2)) bsz >>= 1;
-    }
-    uint32_t nblk = gridDim.x;
-    if (cv.mode == MODE_PROCESS) {
-        const uint64_t wave_jobs = ((uint64_t)cv.cur_light + bsz - 1) / bsz + (uint64_t)cv.cur_heavy;
-        const uint64_t need = (wave_jobs + kPeelWaves - 1) / kPeelWaves;
-        nblk = (uint32_t)(need < 1 ? 1 : (need > gridDim.x ? gridDim.x : need));
-    }
-    if (blockIdx.x >= nblk) return;
-
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
+
+    // A launch normally performs ONE step.  When the step fits a single workgroup, that
+    // workgroup finalises it locally and goes straight on to the next step for as long as the
+    // steps stay that small: the long tail of tiny sub-rounds costs no launches at all.
+    // (Inside one workgroup, __syncthreads() makes the plain stores of one step visible to the
+    // loads of the next: same CU, same L1.  State is carried in LDS, never re-read from global.)
+    for (uint32_t chained = 0;; ++chained) {
+    uint32_t bsz;
+    const uint32_t nblk = plan_step(cv, gridDim.x, bsz);   // workgroups that take part; the rest leave
+    if (blockIdx.x >= nblk) return;
     const int L = cv.level;
     const int sel = cv.cur_sel;
 
@@ -379,55 +451,39 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         }
     }
 
-    // ---- arrival ticket (two levels) and control-block rewrite by the last workgroup
+    // ---- end of step
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    __threadfence();
-    const uint32_t grp = blockIdx.x / kGroup;
-    const uint32_t ngrp = (nblk + kGroup - 1) / kGroup;
-    const uint32_t grp_size = (grp == ngrp - 1) ? (nblk - grp * kGroup) : (uint32_t)kGroup;
-    if (atomicAdd(&grp_done[grp], 1u) != grp_size - 1) return;
-    atomicExch(&grp_done[grp], 0u);
-    __threadfence();
-    if (atomicAdd(&ctrl->blocks_done, 1u) != ngrp - 1) return;
-    atomicExch(&ctrl->blocks_done, 0u);
-    __threadfence();
-
-    int32_t mode = cv.mode, level = cv.level, round = cv.round, done = 0, nsel = sel;
-    uint32_t cur_l = 0, cur_h = 0, remaining = ctrl->remaining;
-    const uint32_t acc = atomicExch(&ctrl->acc, 0u);
-    remaining -= acc;
-    if (mode == MODE_SCAN) {
-        ctrl->n_scans += 1;
-        cur_l = coherent_load(&ctrl->tail_l[sel]);
-        cur_h = coherent_load(&ctrl->tail_h[sel]);
-        const int32_t nmin = atomicExch(&ctrl->next_min, 0x7FFFFFFF);
-        if (cv.live_mode != 0 || cv.remaining <= p.units / 4) {           // this SCAN compacted the survivors
-            ctrl->live_count = atomicExch(&ctrl->live_tail, 0u);
-            ctrl->live_sel = cv.live_sel ^ 1;
-            ctrl->live_mode = 1;
+    if (nblk > 1) {
+        // several workgroups: two-level arrival ticket; the last one rewrites the control block
+        if (threadIdx.x >= kWave) return;
+        int last = 0;
+        if (lane == 0) {
+            __threadfence();
+            const uint32_t grp = blockIdx.x / kGroup;
+            const uint32_t ngrp = (nblk + kGroup - 1) / kGroup;
+            const uint32_t grp_size = (grp == ngrp - 1) ? (nblk - grp * kGroup) : (uint32_t)kGroup;
+            if (atomicAdd(&grp_done[grp], 1u) == grp_size - 1) {
+                atomicExch(&grp_done[grp], 0u);
+                __threadfence();
+                if (atomicAdd(&ctrl->blocks_done, 1u) == ngrp - 1) {
+                    atomicExch(&ctrl->blocks_done, 0u);
+                    __threadfence();
+                    last = 1;
+                }
+            }
         }
-        if (acc > 0) { ctrl->n_levels += 1; ctrl->max_level = level; }
-        if (cur_l + cur_h > 0) mode = MODE_PROCESS;
-        else if (remaining == 0) done = 1;
-        else if (acc > 0) level += 1;                       // only item-less units at this level
-        else if (nmin == 0x7FFFFFFF) done = 2;              // live units but no live key: inconsistent
-        else level = nmin;                                  // jump to the first populated level
-    } else {
-        ctrl->n_rounds += 1;
-        cur_l = coherent_load(&ctrl->tail_l[sel ^ 1]);
-        cur_h = coherent_load(&ctrl->tail_h[sel ^ 1]);
-        atomicExch(&ctrl->tail_l[sel], 0u);
-        atomicExch(&ctrl->tail_h[sel], 0u);
-        nsel = sel ^ 1; round += 1;
-        if (cur_l + cur_h == 0) {
-            if (remaining == 0) done = 1;
-            else { level += 1; mode = MODE_SCAN; }
-        }
+        last = __shfl(last, 0);
+        if (last) { finalize_step(ctrl, cv, p.units, &sh_cv); __threadfence(); }
+        return;
     }
-    ctrl->mode = mode; ctrl->level = level; ctrl->round = round; ctrl->done = done;
-    ctrl->cur_sel = nsel; ctrl->cur_light = cur_l; ctrl->cur_heavy = cur_h; ctrl->remaining = remaining;
-    __threadfence();
+    // one workgroup did the whole step: finalise locally, chain the next step if it is small too
+    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv);
+    __syncthreads();
+    cv = sh_cv;
+    if (cv.done || chained >= kMaxInKernelSteps) return;
+    uint32_t next_bsz;
+    if (plan_step(cv, gridDim.x, next_bsz) != 1u) return;
+    }   // for (chained)
 }
 
 } // namespace komb

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into the small summaries kept under profiles/.
+
+    python scripts/prof_summary.py <tag> <kernel_trace_dir> [<pmc_fetch_dir> <pmc_write_dir>]
+
+Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --stats), profiles/<tag>_kernels.json
+(per-kernel launches / total / average from the kernel trace) and, when the two PMC directories
+are given, profiles/<tag>_traffic.json: HBM bytes per launch from FETCH_SIZE and WRITE_SIZE
+(separate --pmc passes, kilobyte units; raw values -- the 2x FETCH_SIZE correction of
+MI355X_MICROARCH.md applies to 16 B/lane streaming reads, these kernels gather 4-8 B/lane).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    n = name.replace("komb::(anonymous namespace)::", "").replace("komb::", "").replace("void ", "")
+    if n.startswith("k_peel_step<"):
+        return "k_peel_step<Truss>" if "TrussProblem" in n else "k_peel_step<Core>"
+    for key in ("k_triangles<false>", "k_triangles<true>"):
+        if n.startswith(key):
+            return key.replace("false", "count").replace("true", "fill")
+    if n.startswith("k_slot_filter<"):
+        return n.split("(")[0].replace(" ", "")
+    if "rocprim" in n:
+        return "rocprim::" + ("radix_sort" if "radix_sort" in n else "scan" if "scan" in n else "partition" if "partition" in n else "other")
+    return n.split("(")[0]
+
+
+def main():
+    tag, trace_dir = sys.argv[1], sys.argv[2]
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = glob.glob(os.path.join(trace_dir, "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+    trace = glob.glob(os.path.join(trace_dir, "*", "*_kernel_trace.csv"))[0]
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        d[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    kernels = {k: {"launches": len(v), "total_ms": sum(v) / 1e3, "avg_us": sum(v) / len(v), "max_us": max(v)}
+               for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))}
+    json.dump(kernels, open(os.path.join(out, f"{tag}_kernels.json"), "w"), indent=1)
+    print(json.dumps(kernels, indent=1)[:1500])
+    if len(sys.argv) >= 5:
+        traffic = collections.defaultdict(lambda: {"launches": 0})
+        for ctr_dir in sys.argv[3:5]:
+            f = glob.glob(os.path.join(ctr_dir, "*", "*_counter_collection.csv"))[0]
+            seen = collections.Counter()
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                    continue
+                k = short(r["Kernel_Name"])
+                key = r["Counter_Name"].lower() + "_bytes"
+                traffic[k][key] = traffic[k].get(key, 0.0) + float(r["Counter_Value"]) * 1024.0
+                seen[k] += 1
+            for k, n in seen.items():
+                traffic[k]["launches"] = max(traffic[k]["launches"], n)
+        res = {}
+        for k, v in traffic.items():
+            tot = v.get("fetch_size_bytes", 0.0) + v.get("write_size_bytes", 0.0)
+            res[k] = {"launches_profiled": v["launches"], "fetch_bytes": v.get("fetch_size_bytes", 0.0),
+                      "write_bytes": v.get("write_size_bytes", 0.0), "hbm_bytes": tot,
+                      "hbm_bytes_per_launch": tot / max(v["launches"], 1)}
+        json.dump(res, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
+        print({k: round(v["hbm_bytes"] / 1e9, 2) for k, v in res.items() if v["hbm_bytes"] > 1e8})
+
+
+if __name__ == "__main__":
+    main()
