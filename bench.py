@@ -136,7 +136,7 @@ def main():
         step()
     barrier_sync()
     t0 = time.perf_counter()
-    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_peel", "ms_gather")}
+    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_compact", "ms_peel", "ms_gather")}
     for _ in range(args.steps):
         step()
         s = acc.stats()
@@ -159,11 +159,13 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(st)
-        kernels = {
-            "k_triangles<count>": (phase["ms_tri_count"], 1, ab["tri_count"]),
-            "k_triangles<fill>": (phase["ms_tri_fill"], 1, ab["tri_fill"]),
-            "k_truss_step": (phase["ms_peel"], st["truss_subrounds"] + st["truss_scans"], ab["peel"]),
-        }
+        kernels = {"k_truss_step": (phase["ms_peel"], st["truss_subrounds"] + st["truss_scans"], ab["peel"])}
+        if phase["ms_tri_count"] > 0:            # exact two-pass layout (sharded runs, or bounded index too large)
+            kernels["k_triangles<count>"] = (phase["ms_tri_count"], 1, ab["tri_count"])
+            kernels["k_triangles<fill>"] = (phase["ms_tri_fill"], 1, ab["tri_fill"])
+        else:                                    # single enumeration into bounded slices + dense compaction
+            kernels["k_triangles<single>"] = (phase["ms_tri_fill"], 1, ab["tri_fill"])
+            kernels["k_compact_inc"] = (phase["ms_compact"], 1, 16 * st["ne"] + 48 * st["triangles"])
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, nbytes = kernels[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

@@ -62,7 +62,8 @@ typedef struct komb_stats {
     double  ms_orient;              /* truss: degree order + oriented CSR             */
     double  ms_tri_count;           /* truss: triangle enumeration, support counting  */
     double  ms_tri_fill;            /* truss: triangle enumeration, incidence fill    */
-    double  ms_support;             /* = ms_tri_count + ms_tri_fill                   */
+    double  ms_compact;             /* truss: bounded slices -> dense index (1-pass)  */
+    double  ms_support;             /* = ms_tri_count + ms_tri_fill + ms_compact      */
     double  ms_allreduce;           /* truss: support all-reduce callback (sharded)   */
     double  ms_peel;                /* truss: all peel launches (SCAN + PROCESS)      */
     double  ms_gather;              /* truss: canonical-order result gather           */

@@ -31,7 +31,8 @@ class KombStats(ctypes.Structure):
         ("truss_levels", ctypes.c_int32), ("truss_subrounds", ctypes.c_int32),
         ("truss_scans", ctypes.c_int32), ("truss_launches", ctypes.c_int32),
         ("ms_build", ctypes.c_double), ("ms_core", ctypes.c_double), ("ms_orient", ctypes.c_double),
-        ("ms_tri_count", ctypes.c_double), ("ms_tri_fill", ctypes.c_double), ("ms_support", ctypes.c_double),
+        ("ms_tri_count", ctypes.c_double), ("ms_tri_fill", ctypes.c_double), ("ms_compact", ctypes.c_double),
+        ("ms_support", ctypes.c_double),
         ("ms_allreduce", ctypes.c_double),
         ("ms_peel", ctypes.c_double), ("ms_gather", ctypes.c_double), ("ms_corea", ctypes.c_double),
     ]

@@ -27,6 +27,8 @@
 //      ORIGINAL vertex ids -- the identity the C ABI promises.
 #include "peel_dev.h"
 
+#include <cstdlib>
+
 namespace komb {
 
 namespace {
@@ -176,10 +178,12 @@ constexpr int kTriCap = 512;
 constexpr int kTriU = 2;                       // probe items per lane per trip
 constexpr int kTriWaves = kBlock / kWave;
 
-template <bool FILL>
+enum : int { TRI_COUNT = 0, TRI_FILL = 1, TRI_SINGLE = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
-                                                      uint32_t *__restrict__ own, uint32_t *other_or_cursor,
+                                                      uint32_t *own, uint32_t *other_or_cursor,
                                                       const uint32_t *__restrict__ off, int2 *__restrict__ inc)
 {
     __shared__ int32_t sh_col[kTriWaves][kTriCap];
@@ -272,11 +276,11 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
                     if (found) {
                         const uint32_t e_rel = p0 + (uint32_t)t[k], i_rel = l;
                         const uint32_t e = S0 + e_rel, i = S0 + i_rel, jj = j[k];
-                        if (!FILL) {
+                        if (MODE == TRI_COUNT) {
                             if (staged) { atomicAdd(&s_cnt[e_rel], 1u); atomicAdd(&s_cnt[i_rel], 1u); }
                             else { atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); }
                             atomicAdd(&other_or_cursor[jj], 1u);
-                        } else {
+                        } else if (MODE == TRI_FILL) {
                             uint32_t pe, pi;
                             if (staged) {
                                 pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
@@ -289,13 +293,28 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
                             inc[pe] = make_int2((int)i, (int)jj);
                             inc[pi] = make_int2((int)e, (int)jj);
                             inc[pj] = make_int2((int)e, (int)i);
+                        } else {
+                            // single pass into capacity-bounded slices [off[x], off[x+1]): own-role entries
+                            // grow from the front, third-role entries from the back
+                            uint32_t pe, pi;
+                            if (staged) {
+                                pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
+                                pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
+                            } else {
+                                pe = off[e] + atomicAdd(&own[e], 1u);
+                                pi = off[i] + atomicAdd(&own[i], 1u);
+                            }
+                            const uint32_t pj = off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                            inc[pe] = make_int2((int)i, (int)jj);
+                            inc[pi] = make_int2((int)e, (int)jj);
+                            inc[pj] = make_int2((int)e, (int)i);
                         }
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (!FILL && staged) {
+        if (MODE != TRI_FILL && staged) {
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) own[S0 + k] = s_cnt[k];
         }
@@ -315,6 +334,64 @@ __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restric
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
     if (lane_id() == 0 && t) atomicAdd(total, t);               // 64-bit: the 32-bit slice offsets must not wrap
 }
+// capacity of edge (a->b)'s slice in the single-pass layout: |N(a) & N(b)| <= d(a) - 1, a being the
+// lower-(degree,id) endpoint.  total accumulates the 64-bit sum (the 32-bit offsets must not wrap).
+__global__ __launch_bounds__(kBlock) void k_slice_caps(const int32_t *__restrict__ osrc, const int32_t *__restrict__ deg, int64_t m,
+                                                       uint32_t *__restrict__ cap, unsigned long long *__restrict__ total)
+{
+    unsigned long long t = 0;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
+        const uint32_t c = (uint32_t)(deg[osrc[e]] - 1);
+        cap[e] = c;
+        t += c;
+    }
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane_id() == 0 && t) atomicAdd(total, t);
+}
+
+// Dense index from the bounded slices: 64 consecutive edges per wavefront, their entries flattened
+// over the lanes; the dense slices of consecutive edges are contiguous, so the writes are one
+// coalesced stream.  Entry k of edge x sits at offc[x]+k (k < own[x]) or offc[x+1]-1-(k-own[x]).
+__global__ __launch_bounds__(kBlock) void k_compact_inc(const uint32_t *__restrict__ offc, const uint32_t *__restrict__ own,
+                                                        const uint32_t *__restrict__ off, const int2 *__restrict__ sparse,
+                                                        int2 *__restrict__ dense, int64_t m)
+{
+    __shared__ uint32_t sh_end[kBlock / kWave][kWave];
+    const int lane = lane_id();
+    uint32_t *s_end = sh_end[threadIdx.x >> 6];
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t nbatches = (m + kWave - 1) / kWave;
+    for (int64_t bt = wave; bt < nbatches; bt += nwaves) {
+        const int64_t e = bt * kWave + lane;
+        uint32_t d0 = 0, len = 0, c0 = 0, c1 = 0, ow = 0;
+        if (e < m) { d0 = off[e]; len = off[e + 1] - d0; c0 = offc[e]; c1 = offc[e + 1]; ow = own[e]; }
+        const uint32_t incl = wave_incl_scan(len);
+        const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+        const uint32_t dbase = (uint32_t)__shfl((int)d0, 0);
+        __builtin_amdgcn_wave_barrier();
+        s_end[lane] = incl;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
+            const uint32_t it = it0 + (uint32_t)lane;
+            int t = 0;
+            if (it < total) {
+                int lo = 0, hi = kWave - 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_end[mid] > it) hi = mid; else lo = mid + 1; }
+                t = lo;
+            }
+            const uint32_t first = t ? s_end[t - 1] : 0u;
+            const uint32_t tc0 = (uint32_t)__shfl((int)c0, t), tc1 = (uint32_t)__shfl((int)c1, t), tow = (uint32_t)__shfl((int)ow, t);
+            if (it < total) {
+                const uint32_t k = it - first;
+                const uint32_t sp = k < tow ? tc0 + k : tc1 - 1u - (k - tow);
+                dense[dbase + it] = sparse[sp];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_init_cursor(const uint32_t *__restrict__ off, const uint32_t *__restrict__ own,
                                                         int64_t m, uint32_t *__restrict__ cursor)
 {
@@ -520,7 +597,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     hipStream_t s = ctx->stream;
     komb_stats &st = ctx->stats;
     st.triangles = 0; st.truss_levels = st.truss_subrounds = st.truss_launches = 0;
-    st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = st.ms_allreduce = 0.0;
+    st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = st.ms_allreduce = st.ms_compact = 0.0;
     st.truss_scans = 0;
     if (nv == 0 || ctx->ne == 0) {
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
@@ -564,30 +641,64 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg}, d_orow, &d_ocol, &d_osrc, &m));
     st.ms_orient = ctx->timer.stop(s);
 
-    // ---- support (pass 1), slice offsets, incidence lists (pass 2)
+    // ---- triangle support + incidence index
     const int ge = grid_for(m);
     const int gt = grid_for((nv + kTriV - 1) / kTriV, kTriWaves);
+    const int64_t ntasks = (nv + kTriV - 1) / kTriV;
     uint32_t *d_own = nullptr, *d_other = nullptr, *d_cnt = nullptr, *d_off = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_own, 2 * ((size_t)m + 1)));         // [own | other] contiguous: one all-reduce
     d_other = d_own + ((size_t)m + 1);
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)m + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
-    KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s));
-    const int64_t ntasks = (nv + kTriV - 1) / kTriV;
-    const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
-    ctx->timer.start(s);
-    k_triangles<false><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr);
-    st.ms_tri_count = ctx->timer.stop(s);
-    st.ms_allreduce = 0.0;
-    if (world > 1) {                                               // sum the partial support vectors over the ranks
-        ctx->timer.start(s);
-        if (fn(user, d_own, (int64_t)(2 * ((size_t)m + 1))) != 0)
-            KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
-        st.ms_allreduce = ctx->timer.stop(s);
-    }
     unsigned long long *d_mom = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_mom, 6));
-    KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 6 * sizeof(unsigned long long), s));
+    KOMB_HIP(ctx, bufs.alloc(&d_mom, 8));
+    KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 8 * sizeof(unsigned long long), s));
+    KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s));
+    st.ms_allreduce = 0.0;
+
+    // Single-pass layout (one enumeration instead of two): every edge gets a slice sized by the bound
+    // sup(a->b) <= d(a)-1; ~26 GB at |E|=100M, which the 288 GB of HBM afford.  Used on one GPU when the
+    // bounded index fits 32-bit offsets and memory; otherwise (and when the support phase is sharded over
+    // ranks, which needs the counts first) the exact two-pass layout is used.
+    uint32_t *d_cap = nullptr, *d_offc = nullptr;
+    int2 *d_sparse = nullptr;
+    bool single = (world == 1) && !getenv("KOMB_TWO_PASS");
+    if (single) {
+        KOMB_HIP(ctx, bufs.alloc(&d_cap, (size_t)m + 1));
+        KOMB_HIP(ctx, bufs.alloc(&d_offc, (size_t)m + 1));
+        KOMB_HIP(ctx, hipMemsetAsync(d_cap + m, 0, sizeof(uint32_t), s));
+        ctx->timer.start(s);
+        k_slice_caps<<<ge, kBlock, 0, s>>>(d_osrc, d_deg, m, d_cap, d_mom + 6);
+        unsigned long long cap_total = 0;
+        KOMB_HIP(ctx, d2h(ctx, &cap_total, d_mom + 6, sizeof(cap_total)));
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        if (cap_total > 0xFFFFFFF0ull || cap_total * sizeof(int2) > (unsigned long long)(free_b * 0.8)) single = false;
+        if (single) {
+            KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cap, d_offc, m + 1));
+            if (bufs.alloc(&d_sparse, (size_t)cap_total) != hipSuccess) { (void)hipGetLastError(); single = false; }
+        }
+        if (single) {
+            k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse);
+            st.ms_tri_fill = ctx->timer.stop(s);
+            st.ms_tri_count = 0.0;
+        } else {
+            (void)ctx->timer.stop(s);
+            bufs.release(d_cap); bufs.release(d_offc);
+        }
+    }
+    if (!single) {
+        const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
+        ctx->timer.start(s);
+        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr);
+        st.ms_tri_count = ctx->timer.stop(s);
+        if (world > 1) {                                               // sum the partial support vectors over the ranks
+            ctx->timer.start(s);
+            if (fn(user, d_own, (int64_t)(2 * ((size_t)m + 1))) != 0)
+                KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
+            st.ms_allreduce = ctx->timer.stop(s);
+        }
+    }
     k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt, d_mom + 5);
     // graph statistics for the roofline model (sum d^2, sum min(d,d), max d, sum d+ + d+): properties of
     // the graph, not results of the path -- computed on the first whole-graph run and on every subgraph run
@@ -612,11 +723,19 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
     int2 *d_inc = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
-    k_init_cursor<<<ge, kBlock, 0, s>>>(d_off, d_own, m, d_other);        // d_other becomes the j-role cursor
-    ctx->timer.start(s);
-    k_triangles<true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, nullptr, d_other, d_off, d_inc);
-    st.ms_tri_fill = ctx->timer.stop(s);
-    st.ms_support = st.ms_tri_count + st.ms_tri_fill;
+    st.ms_compact = 0.0;
+    if (single) {
+        ctx->timer.start(s);
+        k_compact_inc<<<grid_for((m + kWave - 1) / kWave, kBlock / kWave), kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_inc, m);
+        st.ms_compact = ctx->timer.stop(s);
+        bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc);
+    } else {
+        k_init_cursor<<<ge, kBlock, 0, s>>>(d_off, d_own, m, d_other);        // d_other becomes the j-role cursor
+        ctx->timer.start(s);
+        k_triangles<TRI_FILL><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, nullptr, d_other, d_off, d_inc);
+        st.ms_tri_fill = ctx->timer.stop(s);
+    }
+    st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;
     bufs.release(d_cnt); bufs.release(d_own);
 
     // ---- peel

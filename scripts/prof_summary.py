@@ -24,9 +24,10 @@ def short(name):
     n = name.replace("komb::(anonymous namespace)::", "").replace("komb::", "").replace("void ", "")
     if n.startswith("k_peel_step<"):
         return "k_peel_step<Truss>" if "TrussProblem" in n else "k_peel_step<Core>"
-    for key in ("k_triangles<false>", "k_triangles<true>"):
+    for key, nice in (("k_triangles<0>", "k_triangles<count>"), ("k_triangles<1>", "k_triangles<fill>"),
+                      ("k_triangles<2>", "k_triangles<single>")):
         if n.startswith(key):
-            return key.replace("false", "count").replace("true", "fill")
+            return nice
     if n.startswith("k_slot_filter<"):
         return n.split("(")[0].replace(" ", "")
     if "rocprim" in n:
