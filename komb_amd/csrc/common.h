@@ -179,6 +179,7 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
 int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);
 void graph_free(komb_ctx *ctx);
 void truss_free(komb_ctx *ctx);
+void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done);
 void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units);
 int peel_grid(int64_t units);
 

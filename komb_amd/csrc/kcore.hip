@@ -17,17 +17,30 @@ namespace komb {
 
 namespace {
 
+// degree (a2) + peel state.  Isolated vertices are peeled here (coreness 0); init[0] counts them and
+// init[1] receives the smallest positive degree = the first populated level.
 __global__ __launch_bounds__(kBlock) void k_core_init(const uint32_t *__restrict__ rowptr, int64_t nv,
                                                       int32_t *__restrict__ deg, int32_t *__restrict__ degw,
-                                                      int32_t *__restrict__ core)
+                                                      int32_t *__restrict__ core, uint32_t *__restrict__ init)
 {
+    uint32_t zeros = 0;
+    int32_t lmin = 0x7FFFFFFF;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
         const int32_t d = (int32_t)(rowptr[v + 1] - rowptr[v]);
-        deg[v] = d; degw[v] = d; core[v] = kAlive;
+        deg[v] = d; degw[v] = d;
+        if (d == 0) { core[v] = 0; ++zeros; }
+        else { core[v] = kAlive; lmin = min(lmin, d); }
+    }
+    zeros = wave_sum(zeros);
+    lmin = wave_min(lmin);
+    if (lane_id() == 0) {
+        if (zeros) atomicAdd(&init[0], zeros);
+        if (lmin != 0x7FFFFFFF) atomicMin((int32_t *)&init[1], lmin);
     }
 }
 
 struct CoreProblem {
+    static constexpr bool kChain = true;
     uint32_t units;
     const uint32_t *rowptr;
     const int32_t *col;
@@ -62,22 +75,35 @@ struct CoreProblem {
     }
 };
 
-__global__ void k_ctrl_init(PeelCtrl *ctrl, uint32_t *grp_done, uint32_t units)
+// grp_done[kMaxGroups] = #units peeled by the init kernel, grp_done[kMaxGroups+1] = min live key
+__global__ void k_ctrl_pre(uint32_t *grp_done)
 {
-    if (blockIdx.x == 0 && threadIdx.x < kMaxGroups) grp_done[threadIdx.x] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (threadIdx.x < kMaxGroups) grp_done[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) { grp_done[kMaxGroups] = 0u; grp_done[kMaxGroups + 1] = 0x7FFFFFFFu; }
+}
+__global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t units)
+{
+    if (threadIdx.x == 0) {
+        const uint32_t peeled = grp_done[kMaxGroups];
+        const int32_t first = (int32_t)grp_done[kMaxGroups + 1];
         PeelCtrl c{};
-        c.mode = MODE_SCAN; c.level = 0; c.round = 1; c.done = (units == 0) ? 1 : 0;
-        c.remaining = units; c.next_min = 0x7FFFFFFF;
+        c.mode = MODE_SCAN; c.round = 1;
+        c.remaining = units - peeled;
+        c.done = (c.remaining == 0) ? 1 : 0;
+        c.level = c.remaining ? first : 0;           // start at the first populated level
+        c.n_levels = peeled ? 1 : 0;                 // level 0 was populated by item-less units
+        c.next_min = 0x7FFFFFFF;
         *ctrl = c;
     }
 }
 
 } // namespace
 
+void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done) { k_ctrl_pre<<<1, 128, 0, s>>>(d_grp_done); }
+
 void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units)
 {
-    k_ctrl_init<<<1, kMaxGroups, 0, s>>>(d_ctrl, d_grp_done, units);
+    k_ctrl_init<<<1, 64, 0, s>>>(d_ctrl, d_grp_done, units);
 }
 
 int peel_grid(int64_t units)
@@ -114,15 +140,16 @@ int core_run(komb_ctx *ctx)
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.heavy[i], heavy_cap * sizeof(int2));
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.live[i], ((size_t)nv / 4 + 64) * sizeof(int32_t));
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_ctrl, sizeof(PeelCtrl));
-    if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, kMaxGroups * sizeof(uint32_t));
+    if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, (kMaxGroups + 2) * sizeof(uint32_t));
     if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
 
     int64_t g = (nv + kBlock - 1) / kBlock;
-    const int grid_init = (int)(g > 4096 ? 4096 : g);
+    const int grid_init = (int)(g > 1024 ? 1024 : g);
     const int grid = peel_grid(nv);
     CoreProblem P{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, d_degw, ctx->d_core};
     ctx->timer.start(s);
-    k_core_init<<<grid_init, kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_deg, d_degw, ctx->d_core);
+    peel_ctrl_pre(s, d_grp);
+    k_core_init<<<grid_init, kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_deg, d_degw, ctx->d_core, d_grp + kMaxGroups);
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)nv);
     int launches = 0;
     int st = drive_peel(ctx, d_ctrl, nv, [&]() {

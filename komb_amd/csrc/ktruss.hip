@@ -398,12 +398,25 @@ __global__ __launch_bounds__(kBlock) void k_init_cursor(const uint32_t *__restri
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) cursor[e] = off[e] + own[e];
 }
 
+// peel state from the slice lengths.  Triangle-free edges are peeled here (trussness 2); init[0]
+// counts them and init[1] receives the smallest positive support = the first populated level.
 __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t *__restrict__ off,
-                                                      int32_t *__restrict__ sup, int32_t *__restrict__ stamp)
+                                                      int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
+                                                      int32_t *__restrict__ truss, uint32_t *__restrict__ init)
 {
+    uint32_t zeros = 0;
+    int32_t lmin = 0x7FFFFFFF;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
-        sup[e] = (int32_t)(off[e + 1] - off[e]);
-        stamp[e] = kAlive;
+        const int32_t s0 = (int32_t)(off[e + 1] - off[e]);
+        sup[e] = s0;
+        if (s0 == 0) { stamp[e] = 0; truss[e] = 2; ++zeros; }       // round 0: gone before the first sub-round
+        else { stamp[e] = kAlive; lmin = min(lmin, s0); }
+    }
+    zeros = wave_sum(zeros);
+    lmin = wave_min(lmin);
+    if (lane_id() == 0) {
+        if (zeros) atomicAdd(&init[0], zeros);
+        if (lmin != 0x7FFFFFFF) atomicMin((int32_t *)&init[1], lmin);
     }
 }
 
@@ -419,6 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t 
 //     -- so every triangle is destroyed exactly once.
 // A decrement that returns level+1 triggers the edge (trussness level+2).
 struct TrussProblem {
+    static constexpr bool kChain = false;
     uint32_t units;
     const uint32_t *off;
     const int2 *inc;
@@ -752,10 +766,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&Q.live[i], (size_t)m / 4 + 64));
     }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kMaxGroups));
+    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kMaxGroups + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
     ctx->timer.start(s);
-    k_peel_init<<<ge, kBlock, 0, s>>>(m, d_off, d_sup, d_stamp);
+    peel_ctrl_pre(s, d_grp);
+    k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kMaxGroups);
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m);
     const int gp = peel_grid(m);
     int launches = 0;

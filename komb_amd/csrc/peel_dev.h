@@ -38,6 +38,7 @@ constexpr int kPeelWaves = kPeelBlock / kWave;
 constexpr int kLight = 64;                     // units with <= kLight items are flattened 64 per wave
 constexpr int kChunk = 256;                    // heavy units: one queue entry per kChunk items
 constexpr int kItemU = 2;                      // items per lane per trip in PROCESS
+constexpr int kChainBudget = 8;                // batches a wave may peel from its own triggers (chainable problems)
 constexpr int kStage = 192;                    // per-wave LDS staging of triggered light units
 constexpr int kGroup = 32;                     // workgroups per first-level arrival counter
 constexpr int kMaxGroups = 64;                 // grid <= kGroup * kMaxGroups
@@ -231,6 +232,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 
 // ------------------------------------------------------------ the step kernel
 // Problem concept (all __device__):
+//   static constexpr bool kChain;        triggered light units may be peeled in the same launch
 //   uint32_t units;
 //   bool live_below(u, L, int32_t &key)  true when unit u is live and its key <= L; key is set
 //                                        (to 0x7FFFFFFF for a dead unit) so the caller can track the minimum
@@ -388,11 +390,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         const uint64_t n_batches = ((uint64_t)cv.cur_light + bsz - 1) / bsz;
         uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w];
         int32_t *s_unit = sh_unit[w];
-        for (uint64_t bt = gw; bt < n_batches; bt += nw) {
-            const uint64_t idx = bt * bsz + (uint64_t)lane;
-            int32_t unit = -1;
-            uint32_t beg = 0, len = 0;
-            if ((uint32_t)lane < bsz && idx < cv.cur_light) { unit = Q.light[sel][idx]; p.slice((uint32_t)unit, beg, len); }
+        auto run_batch = [&](int32_t unit, uint32_t beg, uint32_t len) {
             const uint32_t incl = wave_incl_scan(len);
             const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
             __builtin_amdgcn_wave_barrier();
@@ -421,6 +419,13 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
                 run_items(active, me, pos);
             }
             __builtin_amdgcn_wave_barrier();
+        };
+        for (uint64_t bt = gw; bt < n_batches; bt += nw) {
+            const uint64_t idx = bt * bsz + (uint64_t)lane;
+            int32_t unit = -1;
+            uint32_t beg = 0, len = 0;
+            if ((uint32_t)lane < bsz && idx < cv.cur_light) { unit = Q.light[sel][idx]; p.slice((uint32_t)unit, beg, len); }
+            run_batch(unit, beg, len);
         }
         // heavy chunks: one entry per wave visit, kChunk items each
         for (uint64_t h = gw; h < (uint64_t)cv.cur_heavy; h += nw) {
@@ -439,6 +444,23 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
                     active[k] = it < c1; me[k] = ent.x; pos[k] = beg + it;
                 }
                 run_items(active, me, pos);
+            }
+        }
+        // Problems whose peel order is free (k-core: a decrement is owed per (peeled vertex, live
+        // neighbour) pair, whenever it happens) let the wave peel the light units it has just
+        // triggered itself, straight from its staging buffer, for a bounded number of batches:
+        // cascades advance several hops per launch.  (The truss peel needs the sub-round barrier
+        // for its tie-break, so it always defers to the next launch.)
+        if (P::kChain) {
+            for (int budget = kChainBudget; budget > 0 && st.n > 0; --budget) {
+                const uint32_t take = st.n < (uint32_t)kWave ? st.n : (uint32_t)kWave;
+                int32_t unit = -1;
+                uint32_t beg = 0, len = 0;
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < take) { unit = st.buf[st.n - take + (uint32_t)lane]; p.slice((uint32_t)unit, beg, len); }
+                __builtin_amdgcn_wave_barrier();
+                st.n -= take;
+                run_batch(unit, beg, len);
             }
         }
         stage_flush(st, qn_l, tail_nl);
