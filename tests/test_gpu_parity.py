@@ -213,3 +213,76 @@ def test_full_size_c2_properties(K, O):
         s_rowptr, s_col = O.simplify(len(vs), sub)
         s_sup, _ = O.support(s_rowptr, s_col)
         assert s_sup.min() >= tr.max() - 2
+
+
+def test_index_layouts_agree(K, O, monkeypatch):
+    """Single-pass (degree-bounded slices + compaction) and two-pass (exact slices) incidence
+    builds must give the same supports and trussness."""
+    uv = K.gen_hug_edges(40000, 110000, 2.3, 21)
+    with K.KombAccel() as a:
+        a.from_edges(40000, uv)
+        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+        r1 = a.run_truss(with_support=True)
+        monkeypatch.setenv("KOMB_TWO_PASS", "1")
+        r2 = a.run_truss(with_support=True)
+        assert a.stats()["ms_tri_count"] > 0
+        for x, y in zip(r1, r2):
+            assert np.array_equal(x, y)
+        rowptr, col = a.get_csr()
+        assert np.array_equal(r1[2], O.trussness(rowptr, col))
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_cliques_and_hubs(K, O, monkeypatch, two_pass):
+    """Complete graphs: long oriented rows (the LDS staging falls back to global search), every
+    edge a heavy unit (slices of n-2 > 64 items).  Star + clique: a hub row split into chunks."""
+    if two_pass:
+        monkeypatch.setenv("KOMB_TWO_PASS", "1")
+    else:
+        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+    for n in (70, 200, 320):
+        iu = np.triu_indices(n, 1)
+        uv = np.stack(iu, axis=1).astype(np.int64)
+        with K.KombAccel() as a:
+            a.from_edges(n, uv)
+            deg, core = a.run_core()
+            assert np.all(deg == n - 1) and np.all(core == n - 1)
+            eu, ev, tr, sup = a.run_truss(with_support=True)
+            assert np.all(sup == n - 2) and np.all(tr == n)
+            assert a.stats()["triangles"] == n * (n - 1) * (n - 2) // 6
+    # hub with 150k leaves, 2000 of them also forming a ring with chords through the hub
+    hub, leaves = 0, 150000
+    star = np.stack([np.zeros(leaves, np.int64), np.arange(1, leaves + 1)], axis=1)
+    ring = np.stack([np.arange(1, 2000), np.arange(2, 2001)], axis=1)
+    uv = np.concatenate([star, ring]).astype(np.int64)
+    o_rowptr, o_col = O.simplify(leaves + 1, uv)
+    with K.KombAccel() as a:
+        a.from_edges(leaves + 1, uv)
+        deg, core = a.run_core()
+        assert deg[hub] == leaves and np.array_equal(core, O.coreness(o_rowptr, o_col))
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        osup, _ = O.support(o_rowptr, o_col)
+        assert np.array_equal(sup, osup)
+        assert np.array_equal(tr, O.trussness(o_rowptr, o_col))
+
+
+def test_many_tiny_graphs_vs_bruteforce(K):
+    """Definitional checkers on 150 random graphs with 1..14 vertices (loops, duplicates, isolated vertices)."""
+    import bruteforce as bf
+    rng = np.random.default_rng(2024)
+    with K.KombAccel() as a:
+        for _ in range(150):
+            nv = int(rng.integers(1, 15))
+            ne = int(rng.integers(0, 4 * nv + 1))
+            uv = rng.integers(0, nv, (ne, 2)).astype(np.int64)
+            a.from_edges(nv, uv)
+            adj = bf.simplify(nv, uv.tolist())
+            edges = bf.edges_of(adj)
+            deg, core = a.run_core()
+            assert deg.tolist() == [len(x) for x in adj]
+            assert core.tolist() == bf.coreness(adj)
+            eu, ev, tr, sup = a.run_truss(with_support=True)
+            assert list(zip(eu.tolist(), ev.tolist())) == edges
+            want_sup, want_tr = bf.support(adj), bf.trussness(adj)
+            assert sup.tolist() == [want_sup[e] for e in edges]
+            assert tr.tolist() == [want_tr[e] for e in edges]
