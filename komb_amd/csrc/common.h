@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -192,6 +193,32 @@ template <typename F>
 int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *launches_out)
 {
     constexpr int kBatch = 24;
+    if (const char *tr = getenv("KOMB_PEEL_TRACE")) {
+        // debug: one launch at a time; append "mode level round light heavy live_mode live_count remaining us" per step
+        FILE *f = fopen(tr, "a");
+        hipEvent_t a, b;
+        KOMB_HIP(ctx, hipEventCreate(&a)); KOMB_HIP(ctx, hipEventCreate(&b));
+        int launches = 0;
+        if (f) fprintf(f, "# peel units=%lld\n", (long long)units);
+        for (int64_t i = 0; i < 4 * units + 4096; ++i) {
+            PeelCtrl before;
+            KOMB_HIP(ctx, hipMemcpy(&before, d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost));
+            if (before.done) break;
+            (void)hipEventRecord(a, ctx->stream);
+            launch(); ++launches;
+            (void)hipEventRecord(b, ctx->stream);
+            (void)hipEventSynchronize(b);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, a, b);
+            if (f) fprintf(f, "%d %d %d %u %u %d %u %u %.1f\n", before.mode, before.level, before.round, before.cur_light,
+                           before.cur_heavy, before.live_mode, before.live_count, before.remaining, ms * 1000.f);
+        }
+        if (f) fclose(f);
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (launches_out) *launches_out = launches;
+        KOMB_HIP(ctx, hipMemcpy(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost));
+        return KOMB_OK;
+    }
     hipEvent_t ev[2] = {nullptr, nullptr};
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));

@@ -476,26 +476,30 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
     // ---- end of step
     __syncthreads();
     if (nblk > 1) {
-        // several workgroups: two-level arrival ticket; the last one rewrites the control block
+        // several workgroups: two-level arrival ticket; the last one rewrites the control block.
+        // Only ATOMICS cross workgroups inside a launch (queue cursors, acc, next_min); every plain store
+        // (queue entries, stamps, results) is consumed by the NEXT launch, behind the kernel boundary.  So
+        // arrival needs no cache write-back / invalidate (a __threadfence() costs ~3.5 us here, and the
+        // path used to have four): the __syncthreads() above has drained every wave's memory operations
+        // (atomics are acknowledged after they execute at the memory side), and the arrival atomics
+        // themselves are ordered by their data dependence.
         if (threadIdx.x >= kWave) return;
         int last = 0;
         if (lane == 0) {
-            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t grp = blockIdx.x / kGroup;
             const uint32_t ngrp = (nblk + kGroup - 1) / kGroup;
             const uint32_t grp_size = (grp == ngrp - 1) ? (nblk - grp * kGroup) : (uint32_t)kGroup;
             if (atomicAdd(&grp_done[grp], 1u) == grp_size - 1) {
                 atomicExch(&grp_done[grp], 0u);
-                __threadfence();
                 if (atomicAdd(&ctrl->blocks_done, 1u) == ngrp - 1) {
                     atomicExch(&ctrl->blocks_done, 0u);
-                    __threadfence();
                     last = 1;
                 }
             }
         }
         last = __shfl(last, 0);
-        if (last) { finalize_step(ctrl, cv, p.units, &sh_cv); __threadfence(); }
+        if (last) finalize_step(ctrl, cv, p.units, &sh_cv);
         return;
     }
     // one workgroup did the whole step: finalise locally, chain the next step if it is small too
