@@ -128,7 +128,7 @@ int core_run(komb_ctx *ctx)
     ctx->stats.max_coreness = 0; ctx->stats.ms_core = 0.0;
     if (nv == 0) { ctx->core_done = true; return KOMB_OK; }
 
-    const size_t heavy_cap = (size_t)(2 * ctx->ne) / 48 + 64;
+    const size_t heavy_cap = (size_t)(2 * ctx->ne) / 32 + 64;    // sum over units with > kLight items of ceil(items / kChunk) <= 3/128 of all items
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
     PeelQueues Q{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     auto cleanup = [&]() {

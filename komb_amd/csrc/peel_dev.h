@@ -36,7 +36,7 @@ enum : int32_t { MODE_SCAN = 0, MODE_PROCESS = 1 };
 constexpr int kPeelBlock = 1024;               // 16 wave64 per workgroup
 constexpr int kPeelWaves = kPeelBlock / kWave;
 constexpr int kLight = 64;                     // units with <= kLight items are flattened 64 per wave
-constexpr int kChunk = 256;                    // heavy units: one queue entry per kChunk items
+constexpr int kChunk = 128;                    // heavy units: one queue entry per kChunk items (= one trip of a wavefront)
 constexpr int kItemU = 2;                      // items per lane per trip in PROCESS
 constexpr int kChainBudget = 8;                // batches a wave may peel from its own triggers (chainable problems)
 constexpr int kStage = 192;                    // per-wave LDS staging of triggered light units
