@@ -130,15 +130,16 @@ int core_run(komb_ctx *ctx)
 
     const size_t heavy_cap = (size_t)(2 * ctx->ne) / 32 + 64;    // sum over units with > kLight items of ceil(items / kChunk) <= 3/128 of all items
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
-    PeelQueues Q{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     auto cleanup = [&]() {
-        ctx->pool.put(d_degw); ctx->pool.put(d_ctrl); ctx->pool.put(d_grp);
+        ctx->pool.put(d_degw); ctx->pool.put(d_ctrl); ctx->pool.put(d_grp); ctx->pool.put(Q.code);
         for (int i = 0; i < 2; ++i) { ctx->pool.put(Q.light[i]); ctx->pool.put(Q.heavy[i]); ctx->pool.put(Q.live[i]); }
     };
     hipError_t e = ctx->pool.get((void **)&d_degw, (size_t)nv * sizeof(int32_t));
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.light[i], (size_t)nv * sizeof(int32_t));
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.heavy[i], heavy_cap * sizeof(int2));
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.live[i], ((size_t)nv / 4 + 64) * sizeof(int32_t));
+    if (e == hipSuccess) e = ctx->pool.get((void **)&Q.code, (size_t)nv);
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_ctrl, sizeof(PeelCtrl));
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, (kMaxGroups + 2) * sizeof(uint32_t));
     if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }

@@ -755,7 +755,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // ---- peel
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
     PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
-    PeelQueues Q{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     const size_t heavy_cap = (size_t)total / 32 + 64;             // see kcore.hip
     KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
@@ -766,6 +766,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&Q.live[i], (size_t)m / 4 + 64));
     }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
+    KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kMaxGroups + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
     ctx->timer.start(s);
@@ -786,6 +787,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.truss_scans = ctx->h_ctrl[0].n_scans;
     st.max_trussness = ctx->h_ctrl[0].max_level + 2;
     for (int i = 0; i < 2; ++i) { bufs.release(Q.light[i]); bufs.release(Q.heavy[i]); bufs.release(Q.live[i]); }
+    bufs.release(Q.code);
     bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc);
 
     // ---- canonical-order results with original vertex ids

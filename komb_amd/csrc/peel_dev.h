@@ -37,6 +37,7 @@ constexpr int kPeelBlock = 1024;               // 16 wave64 per workgroup
 constexpr int kPeelWaves = kPeelBlock / kWave;
 constexpr int kLight = 64;                     // units with <= kLight items are flattened 64 per wave
 constexpr int kChunk = 128;                    // heavy units: one queue entry per kChunk items (= one trip of a wavefront)
+constexpr int kScanU = 4;                      // units per thread per trip in SCAN
 constexpr int kItemU = 2;                      // items per lane per trip in PROCESS
 constexpr int kChainBudget = 8;                // batches a wave may peel from its own triggers (chainable problems)
 constexpr int kStage = 192;                    // per-wave LDS staging of triggered light units
@@ -77,7 +78,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
+enum : uint8_t { SC_NONE = 0, SC_LIGHT = 1, SC_HEAVY = 2, SC_EMPTY = 3, SC_SURVIVOR = 4 };   // SCAN pass A -> pass B
+
 struct PeelQueues {
+    uint8_t *code;           // one classification byte per SCAN input position
     int32_t *light[2];       // unit ids
     int2 *heavy[2];          // (unit id, chunk index)
     int32_t *live[2];        // compacted ids of the units still live (SCAN's input once it pays off)
@@ -285,26 +289,38 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         const uint32_t n_in = from_list ? cv.live_count : p.units;
         const int32_t *live_in = Q.live[cv.live_sel];
         int32_t *live_out = Q.live[cv.live_sel ^ 1];
-        // ---- pass A: count this wave's light hits, its heavy units' chunks, all hits, survivors
+        // ---- pass A: count this wave's light hits, its heavy units' chunks, all hits, survivors.
+        // kScanU units per thread per trip: the trips are independent, so their loads overlap
+        // (one unit per trip left the sweep bound by 2 x 380 sequential memory latencies).
         uint32_t n_light = 0, n_chunks = 0, n_hits = 0, n_surv = 0;   // n_chunks per lane, others wave-uniform
         int32_t lmin = 0x7FFFFFFF;
-        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * kPeelBlock) {
-            const uint64_t idx = base + (uint64_t)lane;
-            bool hit = false, light = false, surv = false;
-            if (idx < n_in) {
-                const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
-                int32_t key;
-                if (p.live_below(u, L, key)) {
-                    hit = true;
-                    uint32_t b, len;
-                    p.slice(u, b, len);
-                    if (len <= (uint32_t)kLight) light = len > 0;
-                    else n_chunks += (len + kChunk - 1) / kChunk;
-                } else if (key != 0x7FFFFFFF) { lmin = min(lmin, key); surv = true; }
+        const uint64_t tile = (uint64_t)kPeelBlock * kScanU;
+        for (uint64_t base = (uint64_t)blockIdx.x * tile + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * tile) {
+            uint8_t code[kScanU];
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
+                code[k] = SC_NONE;
+                if (idx < n_in) {
+                    const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
+                    int32_t key;
+                    if (p.live_below(u, L, key)) {
+                        uint32_t b, len;
+                        p.slice(u, b, len);
+                        if (len <= (uint32_t)kLight) code[k] = len > 0 ? SC_LIGHT : SC_EMPTY;
+                        else { n_chunks += (len + kChunk - 1) / kChunk; code[k] = SC_HEAVY; }
+                    } else if (key != 0x7FFFFFFF) { lmin = min(lmin, key); code[k] = SC_SURVIVOR; }
+                }
             }
-            n_light += (uint32_t)__popcll(__ballot(light));
-            n_hits += (uint32_t)__popcll(__ballot(hit));
-            if (emit) n_surv += (uint32_t)__popcll(__ballot(surv));
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
+                if (idx < n_in) Q.code[idx] = code[k];      // pass B reads this byte instead of the unit's state
+                const bool hit = code[k] == SC_LIGHT || code[k] == SC_HEAVY || code[k] == SC_EMPTY;
+                n_light += (uint32_t)__popcll(__ballot(code[k] == SC_LIGHT));
+                n_hits += (uint32_t)__popcll(__ballot(hit));
+                if (emit) n_surv += (uint32_t)__popcll(__ballot(code[k] == SC_SURVIVOR));
+            }
         }
         n_chunks = wave_sum(n_chunks);
         lmin = wave_min(lmin);
@@ -326,27 +342,33 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             if (bmin != 0x7FFFFFFF) atomicMin(&ctrl->next_min, bmin);
         }
         __syncthreads();
-        // ---- pass B: same predicate on unchanged state, write the entries
+        // ---- pass B: replay the classification bytes, write the entries
         const uint32_t base_l = sh_base[0] + sh_w[w][0], base_h = sh_base[1] + sh_w[w][1], base_s = sh_base[2] + sh_w[w][3];
         uint32_t run_l = 0, run_h = 0, run_s = 0;
-        for (uint64_t base = (uint64_t)blockIdx.x * kPeelBlock + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * kPeelBlock) {
-            const uint64_t idx = base + (uint64_t)lane;
-            bool light = false, heavy = false, surv = false;
-            uint32_t nch = 0, u = 0;
-            if (idx < n_in) {
-                u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
-                int32_t key;
-                if (p.live_below(u, L, key)) {
-                    uint32_t b, len;
-                    p.slice(u, b, len);
-                    if (len <= (uint32_t)kLight) light = len > 0;
-                    else { heavy = true; nch = (len + kChunk - 1) / kChunk; }
-                    p.mark_scanned(u, cv);
-                } else surv = key != 0x7FFFFFFF;
+        for (uint64_t base = (uint64_t)blockIdx.x * tile + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * tile) {
+            uint8_t code[kScanU];
+            uint32_t u[kScanU];
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
+                code[k] = idx < n_in ? Q.code[idx] : (uint8_t)SC_NONE;
             }
-            wave_write_ordered(light, (int32_t)u, Q.light[sel], base_l, run_l);
-            if (__ballot(heavy)) wave_write_chunks(heavy, (int32_t)u, nch, Q.heavy[sel], base_h, run_h);
-            if (emit) wave_write_ordered(surv, (int32_t)u, live_out, base_s, run_s);
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
+                u[k] = 0;
+                if (code[k] != SC_NONE) u[k] = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
+            }
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const bool light = code[k] == SC_LIGHT, heavy = code[k] == SC_HEAVY, surv = code[k] == SC_SURVIVOR;
+                uint32_t nch = 0;
+                if (heavy) { uint32_t b, len; p.slice(u[k], b, len); nch = (len + kChunk - 1) / kChunk; }
+                if (code[k] != SC_NONE && !surv) p.mark_scanned(u[k], cv);
+                wave_write_ordered(light, (int32_t)u[k], Q.light[sel], base_l, run_l);
+                if (__ballot(heavy)) wave_write_chunks(heavy, (int32_t)u[k], nch, Q.heavy[sel], base_h, run_h);
+                if (emit) wave_write_ordered(surv, (int32_t)u[k], live_out, base_s, run_s);
+            }
         }
     } else {
         // ---- PROCESS
