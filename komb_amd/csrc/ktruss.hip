@@ -72,8 +72,11 @@ template <class Pred, bool FILL>
 __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restrict__ src, const int32_t *__restrict__ col,
                                                         int64_t ns, Pred pred, uint32_t *__restrict__ chunk_count,
                                                         const uint32_t *__restrict__ chunk_base,
-                                                        int32_t *__restrict__ out_col, int32_t *__restrict__ out_src)
+                                                        int32_t *__restrict__ out_col, int32_t *__restrict__ out_src,
+                                                        unsigned long long *__restrict__ keep_bits)
 {
+    // keep_bits: one bit per slot (64-slot words = one wavefront ballot).  Pass 1 evaluates the predicate
+    // and records it; pass 2 only replays the bits (no second gather of the predicate's operands).
     __shared__ uint32_t sh_wave[kBlock / kWave];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
@@ -84,12 +87,19 @@ __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restric
         uint32_t total = 0;
         for (int r = 0; r < kSlotsPerThread; ++r) {
             const int64_t j = c0 + (int64_t)r * kBlock + threadIdx.x;
-            int32_t a = 0, c = 0;
+            const int64_t jw = j - lane;                        // first slot of this wave's 64 (multiple of 64)
             bool keep = false;
-            if (j < ns) { a = src[j]; c = col[j]; keep = pred(a, c); }
-            const uint64_t m = __ballot(keep);
+            if (!FILL) {
+                if (j < ns) keep = pred(src[j], col[j]);
+                const uint64_t m = __ballot(keep);
+                if (lane == 0 && jw < ns) keep_bits[jw >> 6] = m;
+                total += (uint32_t)__popcll(m);
+                continue;
+            }
+            uint64_t m = 0;
+            if (jw < ns) m = keep_bits[jw >> 6];
+            keep = (m >> lane) & 1ull;
             const uint32_t wcnt = (uint32_t)__popcll(m);
-            if (!FILL) { total += wcnt; continue; }
             __syncthreads();
             if (lane == 0) sh_wave[w] = wcnt;
             __syncthreads();
@@ -98,8 +108,8 @@ __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restric
             for (int i = 0; i < kBlock / kWave; ++i) { const uint32_t x = sh_wave[i]; if (i < w) before += x; all += x; }
             if (keep) {
                 const uint32_t o = run + before + (uint32_t)__popcll(m & lanemask_lt());
-                out_col[o] = c;
-                out_src[o] = a;
+                out_col[o] = col[j];
+                out_src[o] = src[j];
             }
             run += all;
         }
@@ -483,11 +493,19 @@ struct TrussProblem {
 // canonical id is ebase[u] + (j - first upper slot of u) with no compaction.
 // The oriented slot of {u,v} -- where trussness and support live -- is found by
 // a binary search of the tiny oriented row of the lower-(degree,id) endpoint.
+__global__ __launch_bounds__(kBlock) void k_pack_results(const int32_t *__restrict__ truss, const uint32_t *__restrict__ off,
+                                                         int64_t m, int2 *__restrict__ res)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock)
+        res[e] = make_int2(truss[e], (int)(off[e + 1] - off[e]));
+}
+
 __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
                                                              const int32_t *__restrict__ col, int64_t ns,
-                                                             const int32_t *__restrict__ deg, const uint32_t *__restrict__ ebase,
+                                                             const unsigned long long *__restrict__ obits,
+                                                             const uint32_t *__restrict__ ebase,
                                                              const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
-                                                             const uint32_t *__restrict__ off, const int32_t *__restrict__ truss,
+                                                             const int2 *__restrict__ res,
                                                              int32_t *__restrict__ eu, int32_t *__restrict__ ev,
                                                              int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
@@ -497,17 +515,17 @@ __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__r
         const uint32_t eb = ebase[u];
         const uint32_t first_upper = rowptr[u + 1] - (ebase[u + 1] - eb);
         const uint32_t o = eb + ((uint32_t)j - first_upper);
-        const int32_t du = deg[u], dv = deg[v];
-        const bool u_first = du < dv || (du == dv && u < v);
+        const bool u_first = (obits[j >> 6] >> (j & 63)) & 1ull;       // slot (u,v) is the oriented copy: u precedes v
         const int32_t a = u_first ? u : v, t = u_first ? v : u;
         uint32_t lo = orow[a], hi = orow[a + 1];
         while (lo < hi) {                                       // t is present by construction
             const uint32_t mid = lo + ((hi - lo) >> 1);
             if (ocol[mid] < t) lo = mid + 1; else hi = mid;
         }
+        const int2 r = res[lo];
         eu[o] = u; ev[o] = v;
-        tr_out[o] = truss[lo];
-        sup_out[o] = (int32_t)(off[lo + 1] - off[lo]);
+        tr_out[o] = r.x;
+        sup_out[o] = r.y;
     }
 }
 
@@ -577,24 +595,28 @@ void truss_free(komb_ctx *ctx)
 // ordered compaction of the CSR slots (src,col)[ns] that satisfy pred -> (out_src,out_col)[n_out] + out_rowptr
 template <class Pred>
 static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const int32_t *col, int64_t ns, int64_t nv, Pred pred,
-                         uint32_t *out_rowptr, int32_t **out_col, int32_t **out_src, int64_t *n_out)
+                         uint32_t *out_rowptr, int32_t **out_col, int32_t **out_src, int64_t *n_out,
+                         unsigned long long **keep_bits_out = nullptr)
 {
     hipStream_t s = ctx->stream;
     const int64_t nchunks = (ns + kChunkSlots - 1) / kChunkSlots;
     uint32_t *d_cc = nullptr, *d_cb = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_cc, (size_t)nchunks + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_cb, (size_t)nchunks + 1));
+    unsigned long long *d_bits = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_bits, (size_t)(ns + 63) / 64 + 1));
     KOMB_HIP(ctx, hipMemsetAsync(d_cc, 0, ((size_t)nchunks + 1) * sizeof(uint32_t), s));
     const int g = grid_for(nchunks, 1, 256 * 32);
-    k_slot_filter<Pred, false><<<g, kBlock, 0, s>>>(src, col, ns, pred, d_cc, nullptr, nullptr, nullptr);
+    k_slot_filter<Pred, false><<<g, kBlock, 0, s>>>(src, col, ns, pred, d_cc, nullptr, nullptr, nullptr, d_bits);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cc, d_cb, nchunks + 1));
     uint32_t kept = 0;
     KOMB_HIP(ctx, d2h(ctx, &kept, d_cb + nchunks, sizeof(uint32_t)));
     KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept));
     KOMB_HIP(ctx, bufs.alloc(out_src, (size_t)kept));
-    k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src);
+    k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits);
     k_rowptr_from_src<<<grid_for(kept > 0 ? kept : nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
     bufs.release(d_cc); bufs.release(d_cb);
+    if (keep_bits_out) *keep_bits_out = d_bits; else bufs.release(d_bits);
     *n_out = (int64_t)kept;
     return KOMB_OK;
 }
@@ -652,7 +674,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg);
     int32_t *d_ocol = nullptr, *d_osrc = nullptr;
     int64_t m = 0;
-    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg}, d_orow, &d_ocol, &d_osrc, &m));
+    unsigned long long *d_obits = nullptr;                           // bit j: working slot j is the oriented copy of its edge
+    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg}, d_orow, &d_ocol, &d_osrc, &m, &d_obits));
     st.ms_orient = ctx->timer.stop(s);
 
     // ---- triangle support + incidence index
@@ -802,7 +825,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_deg, d_ebase, d_orow, d_ocol, d_off, d_truss,
+    int2 *d_res = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
+    k_pack_results<<<grid_for(m), kBlock, 0, s>>>(d_truss, d_off, m, d_res);
+    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_ebase, d_orow, d_ocol, d_res,
                                                         ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
     ctx->t_ne = m;
