@@ -31,7 +31,11 @@
 #include <vector>
 
 #include <omp.h>
+#include <parallel/algorithm>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "komb_accel.h"
 
@@ -120,138 +124,254 @@ Args parse_args(int argc, const char **argv)
 }
 
 // ---------------------------------------------------------------------- SAM
-// read key -> set of unitig vids.  Reference: umapset (src/graph.h:24) keyed by
-// read.substr(1, read.find('/')) (src/graph.cpp:235).
-using ReadMap = std::unordered_map<std::string, std::vector<int32_t>>;
-
-struct Names {                                             // unitig name <-> vid (src/graph.cpp:242-256)
-    std::unordered_map<std::string, int32_t> vid;
-    std::vector<std::string> name;
-    int32_t get(const char *s, size_t n)
+// SAM -> graph pipeline (reference: readSAM src/graph.cpp:166-257, getEdgeInfo :259-285,
+// generateGraph :287-393).  Same observable result -- vertex = unitig name seen on a parsed
+// line, edge = two unitigs sharing a read key in either file -- built without per-read string
+// hash sets: both files are mmap'ed, every thread parses the lines of its own byte chunk into
+// (read-key view, unitig id) records, records are sorted by read key (64-bit hash first,
+// bytes on a tie, so grouping is exact), each run of equal keys is one clique, and the
+// expanded pairs are deduplicated by sort + unique.
+struct Mapped {
+    const char *data = nullptr;
+    size_t size = 0;
+    std::string fallback;                                  // used when mmap is not possible
+    void open(const std::string &path)
     {
-        std::string k(s, n);
-        auto it = vid.find(k);
-        if (it != vid.end()) return it->second;
-        int32_t v = (int32_t)name.size();
-        vid.emplace(k, v);
-        name.push_back(std::move(k));
-        return v;
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) file_not_found(path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); file_not_found(path); }
+        size = (size_t)st.st_size;
+        if (size == 0) { ::close(fd); data = ""; return; }
+        void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) {
+            fallback.resize(size);
+            size_t got = 0;
+            while (got < size) {
+                ssize_t r = ::read(fd, &fallback[got], size - got);
+                if (r <= 0) { fprintf(stderr, "Encountered error while reading %s\n", path.c_str()); exit(EXIT_FAILURE); }   // src/graph.cpp:188-192
+                got += (size_t)r;
+            }
+            data = fallback.data();
+        } else {
+            data = (const char *)p;
+            madvise(p, size, MADV_SEQUENTIAL);
+        }
+        ::close(fd);
+    }
+    ~Mapped() { if (data && fallback.empty() && size) munmap((void *)data, size); }
+};
+
+struct View { const char *p; uint32_t n; };
+inline bool operator==(const View &a, const View &b) { return a.n == b.n && memcmp(a.p, b.p, a.n) == 0; }
+struct ViewHash {
+    size_t operator()(const View &v) const
+    {
+        uint64_t h = 0xCBF29CE484222325ull;                // FNV-1a, then a final mix
+        for (uint32_t i = 0; i < v.n; ++i) { h ^= (unsigned char)v.p[i]; h *= 0x100000001B3ull; }
+        h ^= h >> 32; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+        return (size_t)h;
     }
 };
 
-std::string slurp(const std::string &path)
-{
-    FILE *f = fopen(path.c_str(), "r");
-    if (!f) file_not_found(path);
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    rewind(f);
-    std::string buf((size_t)sz, '\0');
-    if (sz > 0 && fread(&buf[0], 1, (size_t)sz, f) != (size_t)sz) {
-        fprintf(stderr, "Encountered error while reading %s\n", path.c_str());   // src/graph.cpp:188-192
-        exit(EXIT_FAILURE);
-    }
-    fclose(f);
-    return buf;
-}
+struct Names {                                             // unitig name <-> vid (src/graph.cpp:242-256)
+    std::vector<std::string> name;                         // vid order = first appearance (file, then byte offset)
+};
 
-// Which lines does the reference parse?  readSAM (src/graph.cpp:195-238) splits
-// the BYTES of the file over T OpenMP threads (static schedule: the first
-// n mod T threads get ceil(n/T) bytes, the rest floor(n/T)); each thread records
-// the newlines inside its own chunk and parses only the lines that lie between
-// two of its own newlines (thread 0 also gets a synthetic newline before byte
-// 0).  The line that starts after a chunk's last newline is parsed by nobody,
-// and neither is a final line without '\n'.  strict = every line.
-std::vector<std::pair<size_t, size_t>> line_spans(const std::string &buf, int T, bool strict)
+struct Rec {                                               // one parsed alignment line
+    uint64_t hash;                                         // of the read key
+    View key;                                              // read.substr(1, read.find('/')) (src/graph.cpp:235)
+    int32_t vid;                                           // thread-local unitig id, later the global vid
+};
+
+// Which lines does the reference parse?  readSAM (src/graph.cpp:195-238) splits the BYTES of the
+// file over T OpenMP threads (static schedule: the first n mod T threads get ceil(n/T) bytes, the
+// rest floor(n/T)); each thread records the newlines inside its own chunk and parses only the lines
+// that lie between two of its own newlines (thread 0 also gets a synthetic newline before byte 0).
+// The line that starts after a chunk's last newline is parsed by nobody, and neither is a final
+// line without '\n'.  strict = every line.  Calls f(begin, end) for every parsed line of chunk t.
+template <class F>
+void for_lines_of_chunk(const char *buf, size_t n, int T, int t, bool strict, F &&f)
 {
-    std::vector<std::pair<size_t, size_t>> spans;          // [begin, end) without the newline
-    const size_t n = buf.size();
-    if (strict) {
-        size_t b = 0;
-        for (size_t i = 0; i <= n; ++i)
-            if (i == n || buf[i] == '\n' || buf[i] == '\0') { if (i > b) spans.emplace_back(b, i); b = i + 1; }
-        return spans;
-    }
     const size_t q = n / (size_t)T, r = n % (size_t)T;
-    size_t lo = 0;
-    for (int t = 0; t < T; ++t) {
-        const size_t len = q + ((size_t)t < r ? 1 : 0), hi = lo + len;
-        bool have_prev = (t == 0);                         // thread 0: position[0] = {0}
-        size_t prev = 0;                                   // the reference's start_pos rule: pos+1, or 0 for the synthetic entry
-        for (size_t i = lo; i < hi; ++i) {
-            if (buf[i] == '\n' || buf[i] == '\0') {
-                if (have_prev) {
-                    size_t start = prev + 1;
-                    if (start == 1) start = 0;             // src/graph.cpp:218-219
-                    spans.emplace_back(start, i);
-                }
-                prev = i; have_prev = true;
-            }
+    const size_t lo = (size_t)t * q + std::min((size_t)t, r), hi = lo + q + ((size_t)t < r ? 1 : 0);
+    if (strict) {
+        // every line belongs to the chunk that holds its first byte
+        size_t b = lo;
+        if (lo > 0) { while (b < n && buf[b - 1] != '\n' && buf[b - 1] != '\0') ++b; }
+        while (b < hi && b < n) {
+            size_t e = b;
+            while (e < n && buf[e] != '\n' && buf[e] != '\0') ++e;
+            if (e > b) f(b, e);
+            b = e + 1;
         }
-        lo = hi;
+        return;
     }
-    return spans;
-}
-
-void read_sam(const std::string &path, int threads, bool strict, ReadMap &umap, Names &names)
-{
-    const std::string buf = slurp(path);
-    const auto spans = line_spans(buf, threads, strict);
-    for (const auto &sp : spans) {
-        const char *line = buf.data() + sp.first;
-        const size_t len = sp.second - sp.first;
-        if (len == 0 || line[0] == '@') continue;          // header (src/graph.cpp:221)
-        // strtok_r(line, "\t"): empty fields are skipped; field 0 = QNAME, field 2 = RNAME
-        size_t pos = 0;
-        const char *tok[3] = {nullptr, nullptr, nullptr};
-        size_t tlen[3] = {0, 0, 0};
-        int nt = 0;
-        while (nt < 3 && pos < len) {
-            while (pos < len && line[pos] == '\t') ++pos;
-            if (pos >= len) break;
-            size_t e = pos;
-            while (e < len && line[e] != '\t') ++e;
-            tok[nt] = line + pos; tlen[nt] = e - pos; ++nt;
-            pos = e;
-        }
-        if (nt < 3) continue;                              // the reference would dereference NULL here
-        if (tlen[2] == 1 && tok[2][0] == '*') continue;    // unmapped (src/graph.cpp:233)
-        // key = read.substr(1, read.find('/'))
-        std::string read(tok[0], tlen[0]);
-        const size_t slash = read.find('/');
-        std::string key = read.size() >= 1 ? read.substr(1, slash) : std::string();
-        const int32_t v = names.get(tok[2], tlen[2]);
-        auto &set = umap[key];
-        if (std::find(set.begin(), set.end(), v) == set.end()) set.push_back(v);
-    }
-}
-
-// getEdgeInfo (src/graph.cpp:259-285): per read key, the union of both mates' unitig sets
-void merge_mates(ReadMap &a, ReadMap &b)
-{
-    for (auto &kv : b) {
-        auto &dst = a[kv.first];
-        for (int32_t v : kv.second)
-            if (std::find(dst.begin(), dst.end(), v) == dst.end()) dst.push_back(v);
-    }
-    ReadMap().swap(b);
-}
-
-// generateGraph (src/graph.cpp:310-352): every clique expands to all i<j pairs; a
-// pair already emitted in the same orientation is skipped (the reference's
-// per-thread seen-set; equal to this for -t 1).
-std::vector<int64_t> expand_cliques(const ReadMap &umap)
-{
-    std::vector<int64_t> edges;
-    std::unordered_set<uint64_t> seen;
-    for (const auto &kv : umap) {
-        const auto &c = kv.second;
-        for (size_t i = 0; i < c.size(); ++i)
-            for (size_t j = i + 1; j < c.size(); ++j) {
-                const uint64_t key = ((uint64_t)(uint32_t)c[i] << 32) | (uint32_t)c[j];
-                if (seen.insert(key).second) { edges.push_back(c[i]); edges.push_back(c[j]); }
+    bool have_prev = (t == 0);                             // thread 0: position[0] = {0}
+    size_t prev = 0;
+    for (size_t i = lo; i < hi; ++i) {
+        if (buf[i] == '\n' || buf[i] == '\0') {
+            if (have_prev) {
+                size_t start = prev + 1;
+                if (start == 1) start = 0;                 // src/graph.cpp:218-219
+                f(start, i);
             }
+            prev = i; have_prev = true;
+        }
     }
+}
+
+struct ThreadParse {
+    std::vector<Rec> recs;
+    std::unordered_map<View, int32_t, ViewHash> local;     // unitig name -> local id
+    std::vector<View> local_names;
+    std::vector<uint64_t> first_pos;                       // (file << 48 | byte offset) of the first line naming it
+};
+
+void parse_sam(const Mapped &m, int file_idx, int threads, bool strict, std::vector<ThreadParse> &tp)
+{
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int t = 0; t < threads; ++t) {
+        ThreadParse &me = tp[(size_t)t];
+        for_lines_of_chunk(m.data, m.size, threads, t, strict, [&](size_t b, size_t e) {
+            const char *line = m.data + b;
+            const size_t len = e - b;
+            if (len == 0 || line[0] == '@') return;        // header (src/graph.cpp:221)
+            // strtok_r(line, "\t"): empty fields are skipped; field 0 = QNAME, field 2 = RNAME
+            size_t pos = 0;
+            const char *tok[3] = {nullptr, nullptr, nullptr};
+            size_t tlen[3] = {0, 0, 0};
+            int nt = 0;
+            while (nt < 3 && pos < len) {
+                while (pos < len && line[pos] == '\t') ++pos;
+                if (pos >= len) break;
+                const char *tb = line + pos;
+                const char *te = (const char *)memchr(tb, '\t', len - pos);
+                const size_t l = te ? (size_t)(te - tb) : len - pos;
+                tok[nt] = tb; tlen[nt] = l; ++nt;
+                pos += l;
+            }
+            if (nt < 3) return;                            // the reference would dereference NULL here
+            if (tlen[2] == 1 && tok[2][0] == '*') return;  // unmapped (src/graph.cpp:233)
+            // key = read.substr(1, read.find('/')): drop the first char, keep through the first '/'
+            View key{tok[0], 0};
+            if (tlen[0] >= 1) {
+                const char *sl = (const char *)memchr(tok[0], '/', tlen[0]);
+                const size_t cnt = sl ? (size_t)(sl - tok[0]) : std::string::npos;        // find('/')
+                const size_t avail = tlen[0] - 1;
+                key.p = tok[0] + 1;
+                key.n = (uint32_t)std::min(avail, cnt);
+            }
+            const View nm{tok[2], (uint32_t)tlen[2]};
+            auto it = me.local.find(nm);
+            int32_t lid;
+            if (it == me.local.end()) {
+                lid = (int32_t)me.local_names.size();
+                me.local.emplace(nm, lid);
+                me.local_names.push_back(nm);
+                me.first_pos.push_back(((uint64_t)file_idx << 48) | (uint64_t)b);
+            } else lid = it->second;
+            me.recs.push_back(Rec{(uint64_t)ViewHash{}(key), key, lid});
+        });
+    }
+}
+
+// Parses both files and returns the raw (u,v) vertex pairs of all cliques, deduplicated.
+std::vector<int64_t> build_edges(const std::string &path1, const std::string &path2, int threads, bool strict, Names &names,
+                                 double *t_sam, double *t_merge, double *t_expand)
+{
+    const auto t0 = clk::now();
+    Mapped m1, m2;
+    m1.open(path1);                                        // src/komb2.cpp:93
+    m2.open(path2);                                        // src/komb2.cpp:95
+    std::vector<ThreadParse> tp1((size_t)threads), tp2((size_t)threads);
+    parse_sam(m1, 0, threads, strict, tp1);
+    parse_sam(m2, 1, threads, strict, tp2);
+    // global vid = order of first appearance (file 1 before file 2, then byte offset): independent of T in strict mode
+    std::unordered_map<View, uint64_t, ViewHash> first;
+    for (auto *tp : {&tp1, &tp2})
+        for (auto &th : *tp)
+            for (size_t i = 0; i < th.local_names.size(); ++i) {
+                auto ins = first.emplace(th.local_names[i], th.first_pos[i]);
+                if (!ins.second && th.first_pos[i] < ins.first->second) ins.first->second = th.first_pos[i];
+            }
+    std::vector<std::pair<uint64_t, View>> order;
+    order.reserve(first.size());
+    for (auto &kv : first) order.emplace_back(kv.second, kv.first);
+    std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    std::unordered_map<View, int32_t, ViewHash> vid_of;
+    vid_of.reserve(order.size() * 2);
+    names.name.clear();
+    names.name.reserve(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        vid_of.emplace(order[i].second, (int32_t)i);
+        names.name.emplace_back(order[i].second.p, order[i].second.n);
+    }
+    // gather all records, local id -> global vid
+    size_t total = 0;
+    std::vector<size_t> offs;
+    for (auto *tp : {&tp1, &tp2}) for (auto &th : *tp) { offs.push_back(total); total += th.recs.size(); }
+    std::vector<Rec> recs(total);
+    {
+        std::vector<ThreadParse *> all;
+        for (auto *tp : {&tp1, &tp2}) for (auto &th : *tp) all.push_back(&th);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (size_t k = 0; k < all.size(); ++k) {
+            ThreadParse &th = *all[k];
+            std::vector<int32_t> remap(th.local_names.size());
+            for (size_t i = 0; i < remap.size(); ++i) remap[i] = vid_of.find(th.local_names[i])->second;
+            for (size_t i = 0; i < th.recs.size(); ++i) { Rec r = th.recs[i]; r.vid = remap[(size_t)r.vid]; recs[offs[k] + i] = r; }
+            std::vector<Rec>().swap(th.recs);
+        }
+    }
+    *t_sam = since(t0);
+
+    // getEdgeInfo: one group per read key over both files -- sort by (hash, key bytes, vid)
+    const auto t1 = clk::now();
+    auto less = [](const Rec &a, const Rec &b) {
+        if (a.hash != b.hash) return a.hash < b.hash;
+        if (a.key.n != b.key.n) return a.key.n < b.key.n;
+        const int c = memcmp(a.key.p, b.key.p, a.key.n);
+        if (c != 0) return c < 0;
+        return a.vid < b.vid;
+    };
+    __gnu_parallel::sort(recs.begin(), recs.end(), less, __gnu_parallel::default_parallel_tag((unsigned)threads));
+    *t_merge = since(t1);
+
+    // generateGraph: every run of equal keys is a clique over its distinct vids
+    const auto t2 = clk::now();
+    std::vector<std::vector<uint64_t>> parts((size_t)threads);
+#pragma omp parallel num_threads(threads)
+    {
+        const int t = omp_get_thread_num();
+        size_t lo = recs.size() * (size_t)t / (size_t)threads, hi = recs.size() * (size_t)(t + 1) / (size_t)threads;
+        auto same = [&](size_t i, size_t j) { return recs[i].hash == recs[j].hash && recs[i].key == recs[j].key; };
+        while (lo > 0 && lo < recs.size() && same(lo - 1, lo)) ++lo;          // start at a run boundary
+        while (hi > 0 && hi < recs.size() && same(hi - 1, hi)) ++hi;
+        std::vector<uint64_t> &out = parts[(size_t)t];
+        std::vector<int32_t> clique;
+        for (size_t i = lo; i < hi;) {
+            size_t j = i;
+            clique.clear();
+            while (j < hi && same(i, j)) { if (clique.empty() || clique.back() != recs[j].vid) clique.push_back(recs[j].vid); ++j; }
+            for (size_t x = 0; x < clique.size(); ++x)
+                for (size_t y = x + 1; y < clique.size(); ++y)
+                    out.push_back(((uint64_t)(uint32_t)clique[x] << 32) | (uint32_t)clique[y]);   // vids ascending: x < y
+            i = j;
+        }
+    }
+    std::vector<Rec>().swap(recs);
+    size_t npairs = 0;
+    for (auto &v : parts) npairs += v.size();
+    std::vector<uint64_t> keys;
+    keys.reserve(npairs);
+    for (auto &v : parts) { keys.insert(keys.end(), v.begin(), v.end()); std::vector<uint64_t>().swap(v); }
+    __gnu_parallel::sort(keys.begin(), keys.end(), std::less<uint64_t>(), __gnu_parallel::default_parallel_tag((unsigned)threads));
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<int64_t> edges(keys.size() * 2);
+#pragma omp parallel for num_threads(threads)
+    for (size_t i = 0; i < keys.size(); ++i) { edges[2 * i] = (int64_t)(keys[i] >> 32); edges[2 * i + 1] = (int64_t)(keys[i] & 0xFFFFFFFFu); }
+    *t_expand = since(t2);
     return edges;
 }
 
@@ -360,25 +480,16 @@ int main(int argc, const char **argv)
 
     const bool strict = env_on("KOMB_STRICT_SAM");
     const auto begin_komb = clk::now();
-    ReadMap umap1, umap2;
     Names names;
-    read_sam(args.input, args.threads, strict, umap1, names);      // src/komb2.cpp:93
-    read_sam(args.input2, args.threads, strict, umap2, names);     // src/komb2.cpp:95
-    auto t_sam = clk::now();
-    fprintf(stdout, "\nTime elapsed for reading SAMs: %.3f s\n", since(begin_komb));
-
-    merge_mates(umap1, umap2);
-    auto t_edgeinfo = clk::now();
-    fprintf(stdout, "\nTime elapsed for edgeInfo: %.3f s\n", std::chrono::duration<double>(t_edgeinfo - t_sam).count());
-
-    auto t0 = clk::now();
-    fprintf(stdout, "\nTime elapsed for converting umapset to vec<vec>: %.3f s\n", since(t0));
-    t0 = clk::now();
-    std::vector<int64_t> edges = expand_cliques(umap1);
-    ReadMap().swap(umap1);
-    fprintf(stdout, "\nTime elapsed for constructing local edges: %.3f s\n", since(t0));
+    double t_sam_s = 0, t_merge_s = 0, t_expand_s = 0;
+    std::vector<int64_t> edges = build_edges(args.input, args.input2, args.threads, strict, names, &t_sam_s, &t_merge_s, &t_expand_s);
+    fprintf(stdout, "\nTime elapsed for reading SAMs: %.3f s\n", t_sam_s);
+    fprintf(stdout, "\nTime elapsed for edgeInfo: %.3f s\n", t_merge_s);
+    fprintf(stdout, "\nTime elapsed for converting umapset to vec<vec>: %.3f s\n", 0.0);
+    fprintf(stdout, "\nTime elapsed for constructing local edges: %.3f s\n", t_expand_s);
     auto t_generate = clk::now();
-    fprintf(stdout, "\nTime elapsed for generateGraph: %.3f s\n", std::chrono::duration<double>(t_generate - t_edgeinfo).count());
+    fprintf(stdout, "\nTime elapsed for generateGraph: %.3f s\n", t_expand_s);
+    auto t0 = clk::now();
 
     // readEdgeList (src/graph.cpp:395-453): edgelist.txt = the raw pairs
     const int64_t nv = (int64_t)names.name.size();
