@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 constexpr int kTriV = 16;
 constexpr int kTriCap = 512;
 constexpr int kTriU = 2;                       // probe items per lane per trip
+constexpr int kTriBuf = 192;                   // parked triangles per wave before they are handled
 constexpr int kTriWaves = kBlock / kWave;
 
 enum : int { TRI_COUNT = 0, TRI_FILL = 1, TRI_SINGLE = 2 };
@@ -194,8 +195,9 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
-                                                      const uint32_t *__restrict__ off, int2 *__restrict__ inc)
+                                                      const uint32_t *__restrict__ off, int2 *__restrict__ inc, int ablate)
 {
+    // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all
     __shared__ int32_t sh_col[kTriWaves][kTriCap];
     __shared__ uint32_t sh_cnt[kTriWaves][kTriCap];
     __shared__ uint32_t sh_orow[kTriWaves][kTriV + 1];
@@ -203,11 +205,13 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
     __shared__ uint32_t sh_rb0[kTriWaves][kWave];
     __shared__ uint32_t sh_ra0[kTriWaves][kWave];
     __shared__ uint32_t sh_ra1[kTriWaves][kWave];
+    __shared__ uint3 sh_tri[kTriWaves][kTriBuf];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     int32_t *s_col = sh_col[w];
     uint32_t *s_cnt = sh_cnt[w], *s_orow = sh_orow[w], *s_pref = sh_pref[w];
     uint32_t *s_rb0 = sh_rb0[w], *s_ra0 = sh_ra0[w], *s_ra1 = sh_ra1[w];
+    uint3 *s_tri = sh_tri[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
 
@@ -224,6 +228,54 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
         if (staged)
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { s_col[k] = ocol[S0 + k]; s_cnt[k] = 0u; }
         __builtin_amdgcn_wave_barrier();
+
+        uint32_t n_tri = 0;                                     // parked triangles (wave-uniform)
+        auto flush_tris = [&]() {
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t b0 = 0; b0 < n_tri; b0 += kWave) {
+                const uint32_t x = b0 + (uint32_t)lane;
+                if (x < n_tri) {
+                    const uint3 tr = s_tri[x];
+                    const uint32_t e_rel = tr.x, i_rel = tr.y, jj = tr.z;
+                    const uint32_t e = S0 + e_rel, i = S0 + i_rel;
+                    if (MODE == TRI_COUNT) {
+                        if (staged) { atomicAdd(&s_cnt[e_rel], 1u); atomicAdd(&s_cnt[i_rel], 1u); }
+                        else { atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); }
+                        atomicAdd(&other_or_cursor[jj], 1u);
+                    } else if (MODE == TRI_FILL) {
+                        uint32_t pe, pi;
+                        if (staged) {
+                            pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
+                            pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
+                        } else {
+                            pe = atomicAdd(&other_or_cursor[e], 1u);
+                            pi = atomicAdd(&other_or_cursor[i], 1u);
+                        }
+                        const uint32_t pj = atomicAdd(&other_or_cursor[jj], 1u);
+                        inc[pe] = make_int2((int)i, (int)jj);
+                        inc[pi] = make_int2((int)e, (int)jj);
+                        inc[pj] = make_int2((int)e, (int)i);
+                    } else {
+                        // single pass into capacity-bounded slices [off[x], off[x+1]): own-role entries
+                        // grow from the front, third-role entries from the back
+                        uint32_t pe, pi;
+                        if (staged) {
+                            pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
+                            pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
+                        } else {
+                            pe = off[e] + atomicAdd(&own[e], 1u);
+                            pi = off[i] + atomicAdd(&own[i], 1u);
+                        }
+                        const uint32_t pj = off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                        inc[pe] = make_int2((int)i, (int)jj);
+                        inc[pi] = make_int2((int)e, (int)jj);
+                        inc[pj] = make_int2((int)e, (int)i);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_tri = 0;
+        };
 
         for (uint32_t p0 = 0; p0 < E; p0 += kWave) {
             // lane <-> owned edge e = S0 + p0 + lane
@@ -243,12 +295,15 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
             }
             const uint32_t incl = wave_incl_scan(lenb);
             const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+            uint32_t maxrow = ra1 - ra0;
+            for (int o = 32; o > 0; o >>= 1) maxrow = max(maxrow, (uint32_t)__shfl_xor((int)maxrow, o));
+            const int row_steps = 32 - __clz((int)maxrow);          // trips that empty a range of maxrow elements
             __builtin_amdgcn_wave_barrier();
             s_pref[lane] = incl; s_rb0[lane] = rb0; s_ra0[lane] = ra0; s_ra1[lane] = ra1;
             __builtin_amdgcn_wave_barrier();
             // kTriU items per lane per trip: the owner search, the gather of w and the row search of
             // the items are independent chains, so their latencies overlap
-            for (uint32_t it0 = 0; it0 < total; it0 += kWave * kTriU) {
+            for (uint32_t it0 = 0; it0 < ((ablate & 8) ? 0u : total); it0 += kWave * kTriU) {
                 int t[kTriU];
                 uint32_t j[kTriU];
                 bool valid[kTriU];
@@ -256,74 +311,54 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
                 for (int k = 0; k < kTriU; ++k) {
                     const uint32_t it = it0 + (uint32_t)(k * kWave + lane);
                     valid[k] = it < total;
-                    int lo = 0, hi = kWave - 1;               // owner: smallest t with s_pref[t] > it
-                    if (valid[k]) {
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (s_pref[mid] > it) hi = mid; else lo = mid + 1;
-                        }
-                    }
+                    int lo = 0;                               // owner: smallest t with s_pref[t] > it (branchless, 6 fixed steps)
+#pragma unroll
+                    for (int st = kWave / 2; st > 0; st >>= 1) lo += (s_pref[lo + st - 1] <= it) ? st : 0;
                     t[k] = lo;
                     const uint32_t first = lo ? s_pref[lo - 1] : 0u;
                     j[k] = s_rb0[lo] + (it - first);          // slot of w in row b
                 }
                 int32_t wv[kTriU];
 #pragma unroll
-                for (int k = 0; k < kTriU; ++k) wv[k] = valid[k] ? ocol[j[k]] : 0;
+                for (int k = 0; k < kTriU; ++k) wv[k] = (valid[k] && !(ablate & 1)) ? ocol[j[k]] : (int32_t)j[k];
 #pragma unroll
                 for (int k = 0; k < kTriU; ++k) {
-                    if (!valid[k]) continue;
-                    uint32_t l = s_ra0[t[k]], h = s_ra1[t[k]];
+                    const bool look = valid[k] && !(ablate & 2);
+                    uint32_t l = look ? s_ra0[t[k]] : 0u, h = look ? s_ra1[t[k]] : 0u;
                     const uint32_t rend = h;
                     bool found;
                     if (staged) {
-                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (s_col[mid] < wv[k]) l = mid + 1; else h = mid; }
-                        found = l < rend && s_col[l] == wv[k];
+                        // branchless lower_bound, wave-uniform trip count (longest owned row of this pass)
+                        uint32_t n = h - l;
+                        for (int st = 0; st < row_steps; ++st) {
+                            const uint32_t half = n >> 1;
+                            const uint32_t probe = min(l + half, (uint32_t)kTriCap - 1u);
+                            const bool go = n > 0 && s_col[probe] < wv[k];
+                            l = go ? l + half + 1u : l;
+                            n = go ? n - half - 1u : half;
+                        }
+                        found = l < rend && s_col[min(l, (uint32_t)kTriCap - 1u)] == wv[k];
                     } else {
                         while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wv[k]) l = mid + 1; else h = mid; }
                         found = l < rend && ocol[S0 + l] == wv[k];
                     }
-                    if (found) {
-                        const uint32_t e_rel = p0 + (uint32_t)t[k], i_rel = l;
-                        const uint32_t e = S0 + e_rel, i = S0 + i_rel, jj = j[k];
-                        if (MODE == TRI_COUNT) {
-                            if (staged) { atomicAdd(&s_cnt[e_rel], 1u); atomicAdd(&s_cnt[i_rel], 1u); }
-                            else { atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); }
-                            atomicAdd(&other_or_cursor[jj], 1u);
-                        } else if (MODE == TRI_FILL) {
-                            uint32_t pe, pi;
-                            if (staged) {
-                                pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
-                                pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
-                            } else {
-                                pe = atomicAdd(&other_or_cursor[e], 1u);
-                                pi = atomicAdd(&other_or_cursor[i], 1u);
-                            }
-                            const uint32_t pj = atomicAdd(&other_or_cursor[jj], 1u);
-                            inc[pe] = make_int2((int)i, (int)jj);
-                            inc[pi] = make_int2((int)e, (int)jj);
-                            inc[pj] = make_int2((int)e, (int)i);
-                        } else {
-                            // single pass into capacity-bounded slices [off[x], off[x+1]): own-role entries
-                            // grow from the front, third-role entries from the back
-                            uint32_t pe, pi;
-                            if (staged) {
-                                pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
-                                pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
-                            } else {
-                                pe = off[e] + atomicAdd(&own[e], 1u);
-                                pi = off[i] + atomicAdd(&own[i], 1u);
-                            }
-                            const uint32_t pj = off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
-                            inc[pe] = make_int2((int)i, (int)jj);
-                            inc[pi] = make_int2((int)e, (int)jj);
-                            inc[pj] = make_int2((int)e, (int)i);
+                    // a hit is rare (~4% of probes): park it in the wave's LDS buffer and handle the
+                    // triangles densely, 64 at a time, instead of running the handler with a few lanes on
+                    const bool hit = found && !(ablate & 4);
+                    const uint64_t hm = __ballot(hit);
+                    if (hm) {
+                        if (hit) {
+                            const uint32_t slot = n_tri + (uint32_t)__popcll(hm & lanemask_lt());
+                            s_tri[slot] = make_uint3(p0 + (uint32_t)t[k], l, j[k]);   // e_rel, i_rel, j
                         }
+                        n_tri += (uint32_t)__popcll(hm);
                     }
                 }
+                if (n_tri >= (uint32_t)kTriBuf - kWave * kTriU) { flush_tris(); }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        flush_tris();
         if (MODE != TRI_FILL && staged) {
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) own[S0 + k] = s_cnt[k];
@@ -385,9 +420,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_inc(const uint32_t *__restri
         for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
             const uint32_t it = it0 + (uint32_t)lane;
             int t = 0;
-            if (it < total) {
-                int lo = 0, hi = kWave - 1;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_end[mid] > it) hi = mid; else lo = mid + 1; }
+            {
+                int lo = 0;
+#pragma unroll
+                for (int st = kWave / 2; st > 0; st >>= 1) lo += (s_end[lo + st - 1] <= it) ? st : 0;
                 t = lo;
             }
             const uint32_t first = t ? s_end[t - 1] : 0u;
@@ -699,6 +735,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // ranks, which needs the counts first) the exact two-pass layout is used.
     uint32_t *d_cap = nullptr, *d_offc = nullptr;
     int2 *d_sparse = nullptr;
+    const int ablate = getenv("KOMB_TRI_ABLATE") ? atoi(getenv("KOMB_TRI_ABLATE")) : 0;    // debug only: breaks results
     bool single = (world == 1) && !getenv("KOMB_TWO_PASS");
     if (single) {
         KOMB_HIP(ctx, bufs.alloc(&d_cap, (size_t)m + 1));
@@ -716,7 +753,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             if (bufs.alloc(&d_sparse, (size_t)cap_total) != hipSuccess) { (void)hipGetLastError(); single = false; }
         }
         if (single) {
-            k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse);
+            k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, ablate);
             st.ms_tri_fill = ctx->timer.stop(s);
             st.ms_tri_count = 0.0;
         } else {
@@ -727,7 +764,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (!single) {
         const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
         ctx->timer.start(s);
-        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr);
+        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr, ablate);
         st.ms_tri_count = ctx->timer.stop(s);
         if (world > 1) {                                               // sum the partial support vectors over the ranks
             ctx->timer.start(s);
@@ -769,7 +806,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     } else {
         k_init_cursor<<<ge, kBlock, 0, s>>>(d_off, d_own, m, d_other);        // d_other becomes the j-role cursor
         ctx->timer.start(s);
-        k_triangles<TRI_FILL><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, nullptr, d_other, d_off, d_inc);
+        k_triangles<TRI_FILL><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, nullptr, d_other, d_off, d_inc, ablate);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;

@@ -428,11 +428,9 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
                     active[k] = it < total;
                     me[k] = -1; pos[k] = 0;
                     if (active[k]) {
-                        int lo = 0, hi = kWave - 1;         // smallest t with s_end[t] > it
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (s_end[mid] > it) hi = mid; else lo = mid + 1;
-                        }
+                        int lo = 0;                         // smallest t with s_end[t] > it (branchless, 6 fixed steps)
+#pragma unroll
+                        for (int st = kWave / 2; st > 0; st >>= 1) lo += (s_end[lo + st - 1] <= it) ? st : 0;
                         const uint32_t first = lo ? s_end[lo - 1] : 0u;
                         me[k] = s_unit[lo];
                         pos[k] = s_beg[lo] + (it - first);
