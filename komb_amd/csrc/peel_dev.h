@@ -39,7 +39,7 @@ constexpr int kLight = 64;                     // units with <= kLight items are
 constexpr int kChunk = 128;                    // heavy units: one queue entry per kChunk items (= one trip of a wavefront)
 constexpr int kScanU = 4;                      // units per thread per trip in SCAN
 constexpr int kItemU = 2;                      // items per lane per trip in PROCESS
-constexpr int kChainBudget = 8;                // batches a wave may peel from its own triggers (chainable problems)
+constexpr int kChainBudget = 16;               // batches a wave may peel from its own triggers (chainable problems)
 constexpr int kStage = 192;                    // per-wave LDS staging of triggered light units
 constexpr int kGroup = 32;                     // workgroups per first-level arrival counter
 constexpr int kMaxGroups = 64;                 // grid <= kGroup * kMaxGroups
