@@ -422,6 +422,29 @@ bool read_kcore_tsv(const std::string &path, std::vector<int32_t> &core, std::ve
     return true;
 }
 
+// Writes rows 0..n-1 to fp: rows are formatted by all threads into per-thread buffers (row(i, buf)
+// appends the text of row i, exactly what the reference's fprintf would print) and the buffers are
+// written in order -- the 10^7..10^8 fprintf calls of src/graph.cpp:468-475 and
+// src/CombineCoreA.h:36-39 are the floor of the reference's own timed region.
+template <class RowFn>
+void write_rows(FILE *fp, int64_t n, int threads, RowFn &&row)
+{
+    const int64_t kBlockRows = 1 << 16;
+    const int64_t nblocks = (n + kBlockRows - 1) / kBlockRows;
+    for (int64_t b0 = 0; b0 < nblocks; b0 += threads) {
+        const int64_t nb = std::min<int64_t>(threads, nblocks - b0);
+        std::vector<std::string> out((size_t)nb);
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+        for (int64_t k = 0; k < nb; ++k) {
+            std::string &buf = out[(size_t)k];
+            const int64_t lo = (b0 + k) * kBlockRows, hi = std::min(n, lo + kBlockRows);
+            buf.reserve((size_t)(hi - lo) * 24);
+            for (int64_t i = lo; i < hi; ++i) row(i, buf);
+        }
+        for (auto &buf : out) fwrite(buf.data(), 1, buf.size(), fp);
+    }
+}
+
 [[noreturn]] void die_accel(komb_ctx *ctx, const char *what, int rc)
 {
     fprintf(stderr, "komb2: %s failed (%d): %s\n", what, rc, ctx ? komb_last_error(ctx) : "no context");
@@ -435,7 +458,7 @@ bool env_on(const char *name)
 }
 
 // CombineCoreA::run (src/CombineCoreA.h:16-43)
-void corea_stage(komb_ctx *ctx, const std::string &outdir, const std::vector<int32_t> &deg, const std::vector<int32_t> &core)
+void corea_stage(komb_ctx *ctx, const std::string &outdir, const std::vector<int32_t> &deg, const std::vector<int32_t> &core, int threads)
 {
     const int n = (int)deg.size();
     const double dense_ratio = n ? (double)(*std::max_element(core.begin(), core.end()) / 2) : 0.0;   // integer division (:24)
@@ -450,9 +473,11 @@ void corea_stage(komb_ctx *ctx, const std::string &outdir, const std::vector<int
     const std::string path = outdir + "/CoreA_anomaly.txt";
     FILE *fp = fopen(path.c_str(), "w+");
     if (!fp) file_not_found(path);
-    std::vector<char> buf(1 << 20);
-    setvbuf(fp, buf.data(), _IOFBF, buf.size());
-    for (int i = 0; i < n; ++i) fprintf(fp, "%d\t%f\n", i, score[(size_t)i]);
+    write_rows(fp, n, threads, [&](int64_t i, std::string &buf) {
+        char tmp[64];
+        const int len = snprintf(tmp, sizeof(tmp), "%d\t%f\n", (int)i, score[(size_t)i]);      // src/CombineCoreA.h:38
+        buf.append(tmp, (size_t)len);
+    });
     fclose(fp);
 }
 
@@ -473,7 +498,7 @@ int main(int argc, const char **argv)
         komb_opts o{};
         o.device = getenv("KOMB_DEVICE") ? atoi(getenv("KOMB_DEVICE")) : 0;
         komb_ctx *ctx = komb_create(&o);
-        corea_stage(ctx, args.outdir, deg, core);
+        corea_stage(ctx, args.outdir, deg, core, args.threads);
         komb_destroy(ctx);
         return 0;
     }
@@ -540,13 +565,17 @@ int main(int argc, const char **argv)
         const std::string path = args.outdir + "/kcore.tsv";
         FILE *kcf = fopen(path.c_str(), "w+");
         if (!kcf) file_not_found(path);
-        std::vector<char> buf(1 << 20);
-        setvbuf(kcf, buf.data(), _IOFBF, buf.size());
         fprintf(kcf, "#VID\tName\tCoreness\tDegree\n");
-        for (int64_t i = 0; i < nv; ++i) {
+        for (int64_t i = 0; i < nv; ++i)
             if (core[(size_t)i] == max_coreness) maxcore[(size_t)i] = 1;       // subgraph_nodes (:470-473)
-            fprintf(kcf, "%d\t%s\t%d\t%d\n", (int)i, names.name[(size_t)i].c_str(), core[(size_t)i], deg[(size_t)i]);
-        }
+        write_rows(kcf, nv, args.threads, [&](int64_t i, std::string &buf) {
+            char tmp[48];
+            int len = snprintf(tmp, sizeof(tmp), "%d\t", (int)i);
+            buf.append(tmp, (size_t)len);
+            buf.append(names.name[(size_t)i]);
+            len = snprintf(tmp, sizeof(tmp), "\t%d\t%d\n", core[(size_t)i], deg[(size_t)i]);   // src/graph.cpp:474
+            buf.append(tmp, (size_t)len);
+        });
         fclose(kcf);
     }
 
@@ -588,7 +617,7 @@ int main(int argc, const char **argv)
     auto t_combine = clk::now();
     fprintf(stdout, "\nTime elapsed for combineFile: %.3f s\n", std::chrono::duration<double>(t_combine - t_core).count());
 
-    corea_stage(ctx, args.outdir, deg, core);              // anomalyDetection (src/graph.cpp:637-648)
+    corea_stage(ctx, args.outdir, deg, core, args.threads);  // anomalyDetection (src/graph.cpp:637-648)
     fprintf(stdout, "\nTime elapsed for anomalyDetection: %.3f s\n", since(t_combine));
     fprintf(stdout, "Identified anomalous unitigs\n");
     fprintf(stdout, "Created anomalouss unitigs file\n");
