@@ -593,20 +593,21 @@ __global__ __launch_bounds__(kBlock) void k_graph_moments(const int32_t *__restr
 }
 
 struct DevBufs {                                    // returns everything it still owns to the context's pool
-    static constexpr int kMax = 48;
     komb_ctx *ctx;
-    void *p[kMax]; int n = 0;
+    std::vector<void *> owned;
     explicit DevBufs(komb_ctx *c) : ctx(c) {}
     template <class T> hipError_t alloc(T **out, size_t count)
     {
         void *q = nullptr;
         hipError_t e = ctx->pool.get(&q, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) { p[n++] = q; *out = (T *)q; }
+        if (e == hipSuccess) { owned.push_back(q); *out = (T *)q; }
         return e;
     }
-    void release(void *q) { for (int i = 0; i < n; ++i) if (p[i] == q) { ctx->pool.put(q); p[i] = nullptr; } }
-    void disown(void *q) { for (int i = 0; i < n; ++i) if (p[i] == q) p[i] = nullptr; }
-    ~DevBufs() { for (int i = 0; i < n; ++i) if (p[i]) ctx->pool.put(p[i]); }
+    void release(void *q)
+    {
+        for (auto &p : owned) if (p == q && q) { ctx->pool.put(q); p = nullptr; }
+    }
+    ~DevBufs() { for (void *p : owned) if (p) ctx->pool.put(p); }
 };
 
 // small blocking device-to-host read, ordered on the context's stream
