@@ -5,24 +5,25 @@
 // peeled; a triangle-free edge has trussness 2.
 //
 // MI355X-first design (no intersections inside the peel loop):
-//   1. orient every edge from the lower to the higher (degree,id) endpoint and
-//      build the oriented CSR (orow/ocol, rows still ascending by id).  The
-//      internal edge id is the oriented slot.  On power-law unitig graphs the
-//      oriented rows are tiny (max ~10^2), whatever the hub degrees are.
-//   2. enumerate every triangle once (edge a->b, merge N+(a) with N+(b)):
-//      pass 1 counts support with integer atomics; an exclusive scan of the
-//      supports gives each edge a slice of the incidence array; pass 2
-//      enumerates again and writes, for each of the triangle's three edges,
-//      the ids of the other two into its slice.  24 bytes per triangle -- the
-//      288 GB of HBM buy a peel that never touches the adjacency again.
+//   1. orient every edge from the lower to the higher (degree,id) endpoint: an
+//      ordered stream compaction of the CSR slots (k_slot_filter) gives the
+//      oriented CSR (orow/ocol, rows still ascending by id).  The internal edge
+//      id is the oriented slot.  On power-law unitig graphs the oriented rows
+//      are tiny (max ~10^2), whatever the hub degrees are.
+//   2. enumerate every triangle once (k_triangles: edge a->b, every element of
+//      N+(b) looked up in the LDS-staged N+(a)) and build the incidence index:
+//      for every edge, the pairs of the other two edges of its triangles
+//      (24 bytes per triangle).  Default: ONE enumeration into slices sized by
+//      the bound sup(a->b) <= d(a)-1 (~26 GB at |E|=100M -- the 288 GB of HBM
+//      buy it) followed by a streaming compaction into the dense index; the
+//      exact count-scan-fill two-pass layout serves sharded runs and fallback.
 //   3. peel: level-synchronous sub-rounds driven by the device control block
 //      (peel_dev.h).  A frontier edge walks its incidence slice; a triangle
 //      whose other two edges are both still present loses one support on each
 //      (ties between two frontier edges are broken by edge id so every
 //      triangle is destroyed exactly once); the decrement that lands an edge
-//      exactly on the level enqueues it for the next sub-round.  Frontier
-//      slices are flattened across the wavefront (prefix sum in LDS) so hub
-//      edges with thousands of triangles do not serialise a lane.
+//      exactly on the level enqueues it for the next sub-round.  The peel
+//      never touches the adjacency again.
 //   4. gather results into canonical (min,max)-lexicographic edge order with
 //      ORIGINAL vertex ids -- the identity the C ABI promises.
 #include "peel_dev.h"

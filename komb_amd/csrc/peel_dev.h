@@ -10,10 +10,11 @@
 // decided on the device from the control block its predecessor finalised:
 //   SCAN    : two passes over all units (later: over the compacted list of live
 //             units, rewritten by every SCAN once <= 1/4 of the units is left).
-//             Pass A counts, per wave, the live units with key <= level; one
-//             atomic per WORKGROUP reserves queue space; pass B re-evaluates the
-//             same predicate and writes the queue entries at wave-private
-//             offsets (no append atomics at all).
+//             Pass A classifies every unit (one byte each) and counts, per wave,
+//             the live units with key <= level; one atomic per WORKGROUP
+//             reserves queue space; pass B replays the bytes and writes the
+//             queue entries at wave-private offsets (no append atomics at all).
+//             Four units per thread per trip keep the sweep's loads overlapped.
 //   PROCESS : the frontier lives in two queues.  "Light" units (<= kLight
 //             items) are taken 64 per wavefront and their slices flattened
 //             across the lanes (prefix sum in LDS + binary search), so lanes
@@ -24,7 +25,10 @@
 //             per-wave LDS buffer and flushed with one atomic per ~100 entries.
 // The last workgroup to finish (two-level arrival ticket: 32 workgroups per
 // group counter, then one top counter, so no word sees more than ~32 serial
-// atomics) rewrites the control block for the next launch.
+// atomics; no cache-flushing fences, only atomics cross workgroups inside a
+// launch) rewrites the control block for the next launch.  A step that fits
+// one workgroup is finalised locally and the workgroup chains the next steps
+// in-kernel while they stay that small.
 #pragma once
 
 #include "common.h"
