@@ -516,7 +516,8 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             const uint32_t grp_size = (grp == ngrp - 1) ? (nblk - grp * kGroup) : (uint32_t)kGroup;
             if (atomicAdd(&grp_done[grp], 1u) == grp_size - 1) {
                 atomicExch(&grp_done[grp], 0u);
-                if (atomicAdd(&ctrl->blocks_done, 1u) == ngrp - 1) {
+                if (ngrp == 1) last = 1;                    // a single group: its last arrival is the last arrival
+                else if (atomicAdd(&ctrl->blocks_done, 1u) == ngrp - 1) {
                     atomicExch(&ctrl->blocks_done, 0u);
                     last = 1;
                 }
