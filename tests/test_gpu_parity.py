@@ -286,3 +286,19 @@ def test_many_tiny_graphs_vs_bruteforce(K):
             want_sup, want_tr = bf.support(adj), bf.trussness(adj)
             assert sup.tolist() == [want_sup[e] for e in edges]
             assert tr.tolist() == [want_tr[e] for e in edges]
+
+
+def test_incidence_limit_is_refused(K):
+    """K_2100 has 1.54e9 triangles = 4.6e9 incidence entries: beyond the 32-bit slice offsets.
+    The library must refuse with KOMB_ERR_LIMIT (never wrap); k-core still works."""
+    n = 2100
+    uv = np.stack(np.triu_indices(n, 1), axis=1).astype(np.int64)
+    with K.KombAccel() as a:
+        a.from_edges(n, uv)
+        deg, core = a.run_core()
+        assert np.all(core == n - 1)
+        with pytest.raises(K.KombError) as e:
+            a.truss_run()
+        assert e.value.code == K._lib.KOMB_ERR_LIMIT and "triangles" in str(e.value)
+        with pytest.raises(K.KombError):
+            a.truss_fetch()                      # no stale result is exposed
