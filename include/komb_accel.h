@@ -115,8 +115,8 @@ int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness);
 int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
 /* One process per GPU, every rank holding the same graph: the triangle-support
  * phase is sharded by source-vertex range [rank/world) and the partial support
- * vectors are summed across ranks by `allreduce` -- an in-place SUM all-reduce
- * over uint32[count] in device memory, ordered after all work already queued
+ * vectors (|E|+1 words) are summed across ranks by `allreduce` -- an in-place SUM
+ * all-reduce over uint32[count] in device memory, ordered after all work already queued
  * on the device's default stream (the host implements it with RCCL; return 0 on
  * success).  Incidence index, peel and gather then run on every rank; all
  * ranks end with identical results.  world == 1 is komb_truss_run. */

@@ -179,21 +179,27 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 // LDS); each item is looked up in the staged row of a by binary search in LDS.
 // Of a triangle's three edges, e and i belong to the owned rows, so their
 // counts / write cursors are LDS atomics private to the wave; only j needs a
-// global atomic.  FILL=false counts supports (own[] by plain stores, other[] by
-// atomics); FILL=true writes each edge's incidence pairs: own-role entries at
-// off[x] + LDS cursor, j-role entries at the global cursor (initialised to
-// off[x] + own[x]).  Tasks whose rows exceed the LDS budget fall back to global
-// binary search and global atomics for all three roles.
+// global atomic.  Hits are rare (~4% of the probes): they are parked in an LDS
+// buffer and handled densely, 64 triangles at a time.
+//   TRI_COUNT  counts supports (own[] by plain stores, other[] by atomics).
+//   TRI_SINGLE writes each edge's incidence pairs into its slice
+//              [off[x], off[x+1]): own-role entries from the front (LDS
+//              cursor), third-role entries from the back (global counter).  The
+//              slices are either capacity-bounded (no counting pass at all;
+//              k_compact_inc then packs them) or exact (after TRI_COUNT + scan:
+//              the two ends meet precisely).
+// Tasks whose rows exceed the LDS budget fall back to global binary search and
+// global atomics for all three roles.
 constexpr int kTriV = 16;
 constexpr int kTriCap = 512;
 constexpr int kTriU = 2;                       // probe items per lane per trip
 constexpr int kTriBuf = 192;                   // parked triangles per wave before they are handled
 constexpr int kTriWaves = kBlock / kWave;
 
-enum : int { TRI_COUNT = 0, TRI_FILL = 1, TRI_SINGLE = 2 };
+enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
+__global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
                                                       const uint32_t *__restrict__ off, int2 *__restrict__ inc, int ablate)
@@ -243,22 +249,9 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
                         if (staged) { atomicAdd(&s_cnt[e_rel], 1u); atomicAdd(&s_cnt[i_rel], 1u); }
                         else { atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); }
                         atomicAdd(&other_or_cursor[jj], 1u);
-                    } else if (MODE == TRI_FILL) {
-                        uint32_t pe, pi;
-                        if (staged) {
-                            pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
-                            pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
-                        } else {
-                            pe = atomicAdd(&other_or_cursor[e], 1u);
-                            pi = atomicAdd(&other_or_cursor[i], 1u);
-                        }
-                        const uint32_t pj = atomicAdd(&other_or_cursor[jj], 1u);
-                        inc[pe] = make_int2((int)i, (int)jj);
-                        inc[pi] = make_int2((int)e, (int)jj);
-                        inc[pj] = make_int2((int)e, (int)i);
                     } else {
-                        // single pass into capacity-bounded slices [off[x], off[x+1]): own-role entries
-                        // grow from the front, third-role entries from the back
+                        // slices [off[x], off[x+1]) -- capacity-bounded (single pass) or exact (after a
+                        // counting pass): own-role entries grow from the front, third-role from the back
                         uint32_t pe, pi;
                         if (staged) {
                             pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
@@ -360,14 +353,22 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const uint32_t *__restrict
             __builtin_amdgcn_wave_barrier();
         }
         flush_tris();
-        if (MODE != TRI_FILL && staged) {
+        if (staged) {
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) own[S0 + k] = s_cnt[k];
         }
     }
 }
 
-// sup = own + other; cursor (reusing other) = where j-role entries of the slice start
+__global__ __launch_bounds__(kBlock) void k_total_u32(const uint32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ total)
+{
+    unsigned long long t = 0;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) t += v[e];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane_id() == 0 && t) atomicAdd(total, t);
+}
+
+// sup = own + other (64-bit total on the side)
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ own, const uint32_t *__restrict__ other,
                                                        int64_t m1, uint32_t *__restrict__ sum, unsigned long long *__restrict__ total)
 {
@@ -439,11 +440,6 @@ __global__ __launch_bounds__(kBlock) void k_compact_inc(const uint32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_init_cursor(const uint32_t *__restrict__ off, const uint32_t *__restrict__ own,
-                                                        int64_t m, uint32_t *__restrict__ cursor)
-{
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) cursor[e] = off[e] + own[e];
-}
 
 // peel state from the slice lengths.  Triangle-free edges are peeled here (trussness 2); init[0]
 // counts them and init[1] receives the smallest positive support = the first populated level.
@@ -768,14 +764,17 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         ctx->timer.start(s);
         k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr, ablate);
         st.ms_tri_count = ctx->timer.stop(s);
-        if (world > 1) {                                               // sum the partial support vectors over the ranks
-            ctx->timer.start(s);
-            if (fn(user, d_own, (int64_t)(2 * ((size_t)m + 1))) != 0)
-                KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
-            st.ms_allreduce = ctx->timer.stop(s);
-        }
     }
     k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt, d_mom + 5);
+    if (!single && world > 1) {
+        // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
+        ctx->timer.start(s);
+        if (fn(user, d_cnt, (int64_t)m + 1) != 0)
+            KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
+        st.ms_allreduce = ctx->timer.stop(s);
+        KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
+        k_total_u32<<<ge, kBlock, 0, s>>>(d_cnt, m + 1, d_mom + 5);
+    }
     // graph statistics for the roofline model (sum d^2, sum min(d,d), max d, sum d+ + d+): properties of
     // the graph, not results of the path -- computed on the first whole-graph run and on every subgraph run
     const bool want_moments = vmask_host != nullptr || !ctx->moments_valid;
@@ -806,9 +805,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         st.ms_compact = ctx->timer.stop(s);
         bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc);
     } else {
-        k_init_cursor<<<ge, kBlock, 0, s>>>(d_off, d_own, m, d_other);        // d_other becomes the j-role cursor
+        // second enumeration, same writer as the single-pass layout but into the EXACT slices: own-role
+        // entries from the front and third-role entries from the back meet precisely -- no compaction
+        KOMB_HIP(ctx, hipMemsetAsync(d_other, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
         ctx->timer.start(s);
-        k_triangles<TRI_FILL><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, nullptr, d_other, d_off, d_inc, ablate);
+        k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, ablate);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;

@@ -5,8 +5,7 @@ What is sharded (BASELINE north_star "edge-range partitioned 
 RCCL all-reduce on the support vectors"): every rank holds the same graph; the
 triangle-support phase is split by source-vertex range (each rank enumerates
 the triangles of its own slice of the oriented CSR), and the per-edge partial
-support vectors ([own | other] roles, 2*(|E|+1) int32) are summed over the
-ranks with ONE all-reduce.  Integer sums are order independent, so results are
+support vectors (|E|+1 int32) are summed over the ranks with ONE all-reduce.  Integer sums are order independent, so results are
 bit-identical for any world size.  The incidence index, the peel and the
 gather then run replicated: the peel is ~500 dependent sub-rounds of tens of
 microseconds each, which a per-sub-round collective (>= ~20 us latency) cannot

@@ -36,7 +36,7 @@ def oriented(rowptr, col):
 
 
 def partial_support(orow, rows, v_lo, v_hi):
-    """[own | other] role counts for source vertices [v_lo, v_hi), internal edge id = oriented slot."""
+    """Per-edge triangle counts contributed by source vertices [v_lo, v_hi); internal edge id = oriented slot."""
     m = int(orow[-1])
     own = np.zeros(m + 1, dtype=np.int32)
     other = np.zeros(m + 1, dtype=np.int32)
@@ -49,7 +49,7 @@ def partial_support(orow, rows, v_lo, v_hi):
                     own[orow[a] + ib] += 1
                     own[orow[a] + pos_a[w]] += 1
                     other[orow[b] + jw] += 1
-    return np.concatenate([own, other])
+    return own + other                                   # what the library sums before the exchange
 
 
 def main():
@@ -69,7 +69,7 @@ def main():
         full = partial_support(orow, rows, 0, nv)
         assert np.array_equal(t.numpy(), full), "sum of shards != single-rank count"
         m = int(orow[-1])
-        sup_internal = full[:m + 1] + full[m + 1:]
+        sup_internal = full
         osup, otri = O.support(rowptr, col)
         assert int(sup_internal.sum()) == 3 * otri
         assert sorted(sup_internal[:m].tolist()) == sorted(osup.tolist())
