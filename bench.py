@@ -185,7 +185,7 @@ def main():
         kernels = {"k_truss_step": (phase["ms_peel"], st["truss_subrounds"] + st["truss_scans"], ab["peel"])}
         if phase["ms_tri_count"] > 0:            # exact two-pass layout (sharded runs, or bounded index too large)
             kernels["k_triangles<count>"] = (phase["ms_tri_count"], 1, ab["tri_count"])
-            kernels["k_triangles<fill>"] = (phase["ms_tri_fill"], 1, ab["tri_fill"])
+            kernels["k_triangles<single> (exact slices)"] = (phase["ms_tri_fill"], 1, ab["tri_fill"])
         else:                                    # single enumeration into bounded slices + dense compaction
             kernels["k_triangles<single>"] = (phase["ms_tri_fill"], 1, ab["tri_fill"])
             kernels["k_compact_inc"] = (phase["ms_compact"], 1, 16 * st["ne"] + 48 * st["triangles"])
