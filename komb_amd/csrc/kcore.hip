@@ -47,11 +47,12 @@ struct CoreProblem {
     int32_t *degw;
     int32_t *core;
 
-    __device__ __forceinline__ bool live_below(uint32_t v, int L, int32_t &key) const
+    __device__ __forceinline__ bool scan_probe(uint32_t v, int32_t &key, uint32_t &len) const
     {
-        if (core[v] != kAlive) { key = 0x7FFFFFFF; return false; }
+        const int32_t c = core[v];
         key = degw[v];
-        return key <= L;
+        len = rowptr[v + 1] - rowptr[v];
+        return c == kAlive;
     }
     __device__ __forceinline__ void mark_scanned(uint32_t v, const CtrlView &cv) const { core[v] = cv.level; }
     __device__ __forceinline__ void slice(uint32_t v, uint32_t &b, uint32_t &len) const

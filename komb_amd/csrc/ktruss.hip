@@ -483,11 +483,12 @@ struct TrussProblem {
     int32_t *stamp;
     int32_t *truss;
 
-    __device__ __forceinline__ bool live_below(uint32_t e, int L, int32_t &key) const
+    __device__ __forceinline__ bool scan_probe(uint32_t e, int32_t &key, uint32_t &len) const
     {
-        if (stamp[e] != kAlive) { key = 0x7FFFFFFF; return false; }
+        const int32_t st = stamp[e];
         key = sup[e];
-        return key <= L;
+        len = off[e + 1] - off[e];
+        return st == kAlive;
     }
     __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const
     {

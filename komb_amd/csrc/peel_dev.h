@@ -242,8 +242,8 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 // Problem concept (all __device__):
 //   static constexpr bool kChain;        triggered light units may be peeled in the same launch
 //   uint32_t units;
-//   bool live_below(u, L, int32_t &key)  true when unit u is live and its key <= L; key is set
-//                                        (to 0x7FFFFFFF for a dead unit) so the caller can track the minimum
+//   bool scan_probe(u, int32_t &key, uint32_t &len)   liveness, live key and slice length of unit u,
+//                                        all loaded unconditionally (independent loads)
 //   void mark_scanned(u, cv)             unit enters the frontier through SCAN
 //   void slice(u, uint32_t &begin, uint32_t &len)
 //   Loaded item_load(unit, pos, cv)      the item's loads (no side effects)
@@ -307,13 +307,15 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
                 code[k] = SC_NONE;
                 if (idx < n_in) {
                     const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
+                    // liveness, key and slice length are loaded unconditionally: independent loads (and, in
+                    // the dense sweep, sequential ones) instead of a chain of three dependent round trips
                     int32_t key;
-                    if (p.live_below(u, L, key)) {
-                        uint32_t b, len;
-                        p.slice(u, b, len);
+                    uint32_t len;
+                    const bool live = p.scan_probe(u, key, len);
+                    if (live && key <= L) {
                         if (len <= (uint32_t)kLight) code[k] = len > 0 ? SC_LIGHT : SC_EMPTY;
                         else { n_chunks += (len + kChunk - 1) / kChunk; code[k] = SC_HEAVY; }
-                    } else if (key != 0x7FFFFFFF) { lmin = min(lmin, key); code[k] = SC_SURVIVOR; }
+                    } else if (live) { lmin = min(lmin, key); code[k] = SC_SURVIVOR; }
                 }
             }
 #pragma unroll
