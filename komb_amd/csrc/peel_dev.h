@@ -145,17 +145,24 @@ __device__ __forceinline__ void stage_push(WaveStage &st, bool pred, int32_t val
 }
 __device__ __forceinline__ void heavy_push(bool pred, int32_t unit, uint32_t nchunks, int2 *q, uint32_t *tail)
 {
+    // one reservation for all heavy units the wave triggered in this trip (a serial atomic per unit
+    // would put one memory round trip per unit on the step's critical path)
     uint64_t m = __ballot(pred);
     const int lane = lane_id();
+    const uint32_t mine = pred ? nchunks : 0u;
+    const uint32_t incl = wave_incl_scan(mine);
+    const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(tail, total);
+    base = (uint32_t)__shfl((int)base, 0);
+    const uint32_t excl = incl - mine;
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
         const int32_t u = __shfl(unit, src);
         const uint32_t n = (uint32_t)__shfl((int)nchunks, src);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(tail, n);
-        base = (uint32_t)__shfl((int)base, 0);
-        for (uint32_t c = (uint32_t)lane; c < n; c += kWave) q[base + c] = make_int2(u, (int)c);
+        const uint32_t o = base + (uint32_t)__shfl((int)excl, src);
+        for (uint32_t c = (uint32_t)lane; c < n; c += kWave) q[o + c] = make_int2(u, (int)c);
     }
 }
 
