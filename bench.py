@@ -49,13 +49,13 @@ def measured_traffic(config, kernel):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{config}_*traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     data = json.load(open(files[-1]))
     name = {"k_truss_step": "k_peel_step<Truss>"}.get(kernel, kernel)
     rec = data.get(name)
     if not rec:
-        return None, os.path.basename(files[-1])
-    return rec["hbm_bytes_per_launch"], os.path.basename(files[-1])
+        return None, None, os.path.basename(files[-1])
+    return rec["hbm_bytes_per_launch"], rec.get("hbm_bytes_per_launch_max"), os.path.basename(files[-1])
 
 
 def cpu_baseline():
@@ -192,11 +192,13 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, nbytes = kernels[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(args.config, dom)
+        traffic, traffic_max, traffic_src = measured_traffic(args.config, dom)
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
+            # FETCH_SIZE is exact for line gathers and 1/2 for coalesced streams (calibrated on this box):
+            # traffic = FETCH+WRITE is the lower bound, traffic_max = 2*FETCH+WRITE the upper bound
+            "traffic_max": traffic_max, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
             "launches_per_step": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
             "algorithmic_bytes_per_step": nbytes,
             "per_kernel": {k: {"ms_per_step": v[0], "launches": v[1], "alg_bytes": v[2],

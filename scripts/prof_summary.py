@@ -6,8 +6,10 @@
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --stats), profiles/<tag>_kernels.json
 (per-kernel launches / total / average from the kernel trace) and, when the two PMC directories
 are given, profiles/<tag>_traffic.json: HBM bytes per launch from FETCH_SIZE and WRITE_SIZE
-(separate --pmc passes, kilobyte units; raw values -- the 2x FETCH_SIZE correction of
-MI355X_MICROARCH.md applies to 16 B/lane streaming reads, these kernels gather 4-8 B/lane).
+(separate --pmc passes, kilobyte units).  FETCH_SIZE was calibrated on this box
+(scripts/calib/fetch_calib.hip, profiles/r01_fetch_size_calibration.txt): coalesced streams of 4, 8 and
+16 B/lane read exactly 1/2, random 4-byte gathers exactly one 64-byte line each; the kernels here mix both,
+so the raw sum (lower bound) and 2*FETCH+WRITE (upper bound) are both recorded.
 """
 import collections
 import csv
@@ -67,9 +69,13 @@ def main():
         res = {}
         for k, v in traffic.items():
             tot = v.get("fetch_size_bytes", 0.0) + v.get("write_size_bytes", 0.0)
+            hi = 2.0 * v.get("fetch_size_bytes", 0.0) + v.get("write_size_bytes", 0.0)
             res[k] = {"launches_profiled": v["launches"], "fetch_bytes": v.get("fetch_size_bytes", 0.0),
                       "write_bytes": v.get("write_size_bytes", 0.0), "hbm_bytes": tot,
-                      "hbm_bytes_per_launch": tot / max(v["launches"], 1)}
+                      "hbm_bytes_per_launch": tot / max(v["launches"], 1),
+                      # FETCH_SIZE is exact for 64-byte-line gathers and 1/2 for coalesced streams
+                      # (profiles/r01_fetch_size_calibration.txt): true bytes lie between the two
+                      "hbm_bytes_per_launch_max": hi / max(v["launches"], 1)}
         json.dump(res, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
         print({k: round(v["hbm_bytes"] / 1e9, 2) for k, v in res.items() if v["hbm_bytes"] > 1e8})
 
