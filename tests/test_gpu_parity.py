@@ -302,3 +302,37 @@ def test_incidence_limit_is_refused(K):
         assert e.value.code == K._lib.KOMB_ERR_LIMIT and "triangles" in str(e.value)
         with pytest.raises(K.KombError):
             a.truss_fetch()                      # no stale result is exposed
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_kernel_threshold_boundaries(K, O, monkeypatch, two_pass):
+    """Slice lengths around kLight=64 and kChunk=128 ("book" graphs: one spine edge with k pages), and
+    16-vertex task blocks whose staged oriented rows straddle the 512-slot LDS budget (dense G(n,p))."""
+    if two_pass:
+        monkeypatch.setenv("KOMB_TWO_PASS", "1")
+    else:
+        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+
+    def check(nv, uv):
+        o_rowptr, o_col = O.simplify(nv, uv)
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            deg, core = a.run_core()
+            assert np.array_equal(core, O.coreness(o_rowptr, o_col))
+            eu, ev, tr, sup = a.run_truss(with_support=True)
+            osup, _ = O.support(o_rowptr, o_col)
+            assert np.array_equal(sup, osup)
+            assert np.array_equal(tr, O.trussness(o_rowptr, o_col))
+
+    for k in (63, 64, 65, 127, 128, 129, 255, 256, 257, 700):
+        pages = np.arange(2, k + 2)
+        uv = np.concatenate([[[0, 1]], np.stack([np.zeros(k, int), pages], 1), np.stack([np.ones(k, int), pages], 1)])
+        # a second book sharing the spine's endpoint, and a clique on some pages, to keep several levels alive
+        extra = np.stack(np.triu_indices(min(k, 12), 1), axis=1) + 2
+        check(k + 2, np.concatenate([uv, extra]).astype(np.int64))
+
+    rng = np.random.default_rng(99)
+    for n in (48, 64, 72, 80, 96, 128):
+        dense = np.stack(np.triu_indices(n, 1), axis=1)
+        keep = rng.random(len(dense)) < 0.9
+        check(n, dense[keep].astype(np.int64))
