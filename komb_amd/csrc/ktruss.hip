@@ -223,11 +223,23 @@ __global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restr
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
 
     for (int64_t task = task_lo + gw; task < task_hi; task += nw) {
-        const int64_t v0 = task * kTriV;
-        const int nvt = (int)min((int64_t)kTriV, nv - v0);
+      const int64_t v0t = task * kTriV;
+      const int nvt_all = (int)min((int64_t)kTriV, nv - v0t);
+      const uint32_t myrow = (lane <= nvt_all) ? orow[v0t + lane] : 0u;       // lane l holds orow[v0t + l]
+      // A task whose rows exceed the LDS budget is cut into sub-ranges of consecutive vertices that fit;
+      // only a single row longer than the budget runs unstaged (global binary search, global atomics).
+      for (int sub = 0; sub < nvt_all;) {
+        const uint32_t sub_base = (uint32_t)__shfl((int)myrow, sub);
+        const bool fits = lane > sub && lane <= nvt_all && myrow - sub_base <= (uint32_t)kTriCap;
+        const int nfit = __popcll(__ballot(fits));                            // rows are cumulative: a prefix of lanes fits
+        const int nvt = nfit > 0 ? nfit : 1;
         __builtin_amdgcn_wave_barrier();
-        if (lane <= nvt) s_orow[lane] = orow[v0 + lane];
+        {
+            const uint32_t val = (uint32_t)__shfl((int)myrow, (lane + sub) & (kWave - 1));
+            if (lane <= nvt) s_orow[lane] = val;
+        }
         __builtin_amdgcn_wave_barrier();
+        sub += nvt;
         const uint32_t S0 = s_orow[0], S1 = s_orow[nvt];
         const uint32_t E = S1 - S0;
         if (E == 0) continue;
@@ -357,6 +369,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restr
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) own[S0 + k] = s_cnt[k];
         }
+      }   // sub-ranges
     }
 }
 
