@@ -144,6 +144,21 @@ __global__ __launch_bounds__(kBlock) void k_rowptr_from_src(const int32_t *__res
     }
 }
 
+// same result, one thread per ROW (binary search in src): used when the kept slots are few compared with
+// the vertices, where the gap-filling form above would leave one thread to fill millions of empty rows
+__global__ __launch_bounds__(kBlock) void k_rowptr_search(const int32_t *__restrict__ src, int64_t ns, int64_t nv,
+                                                          uint32_t *__restrict__ rowptr)
+{
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) {
+        int64_t lo = 0, hi = ns;                                // first slot with src >= v
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)src[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        rowptr[v] = (uint32_t)lo;
+    }
+}
+
 // number of upper slots (col > row id) of every row: rows are ascending, so it is a suffix
 __global__ __launch_bounds__(kBlock) void k_upper_count(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                         int64_t nv, uint32_t *__restrict__ ucnt)
@@ -662,7 +677,8 @@ static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const
     KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept));
     KOMB_HIP(ctx, bufs.alloc(out_src, (size_t)kept));
     k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits);
-    k_rowptr_from_src<<<grid_for(kept > 0 ? kept : nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
+    if ((int64_t)kept * 4 < nv) k_rowptr_search<<<grid_for(nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
+    else k_rowptr_from_src<<<grid_for(kept), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
     bufs.release(d_cc); bufs.release(d_cb);
     if (keep_bits_out) *keep_bits_out = d_bits; else bufs.release(d_bits);
     *n_out = (int64_t)kept;
