@@ -84,3 +84,26 @@ def test_thread_count_changes_the_graph_like_the_reference(fixture):
     assert len(t1) == len(strict)                  # file ends with '\n': nothing lost at T=1
     assert len(strict) - 3 <= len(t4) < len(strict)
     assert set(t4) <= set(strict)
+
+
+@pytest.mark.parametrize("case", ["no_trailing_nl", "empty_second", "header_only", "short_lines"])
+def test_sam_edge_cases(fixture, tmp_path, case):
+    """Unterminated last line (the reference never parses it), empty / header-only files, lines with fewer
+    than three fields: same graph as the restatement for several thread counts, strict and faithful."""
+    d, s1, s2 = fixture
+    a, b = {"no_trailing_nl": (s1.rstrip(b"\n"), s2), "empty_second": (s1, b""),
+            "header_only": (b"@HD\tVN:1.0\n", s2), "short_lines": (b"a\nb\tc\n\n\n" + s1, s2)}[case]
+    (tmp_path / "a.sam").write_bytes(a)
+    (tmp_path / "b.sam").write_bytes(b)
+    for threads in (1, 3, 16):
+        for strict in (False, True):
+            env = {"KOMB_STOP_AFTER_EDGES": "1"}
+            if strict:
+                env["KOMB_STRICT_SAM"] = "1"
+            out = tmp_path / f"o{threads}{int(strict)}"
+            r = run(["-t", str(threads), "-o", str(out), "-i", str(tmp_path / "a.sam"), "-j", str(tmp_path / "b.sam"),
+                     "-u", str(d / "unitigs.fa")], env=env)
+            assert r.returncode == 0, r.stderr
+            names, edges = _graph_from_run(str(out))
+            want_names, want_edges = samgraph.build_graph(a, b, threads, strict)
+            assert names == want_names and edges == want_edges, (case, threads, strict)
