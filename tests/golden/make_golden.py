@@ -78,7 +78,7 @@ def cases():
     yield "petersen", 10, list(nx.petersen_graph().edges())
     yield "karate", 34, list(nx.karate_club_graph().edges())
     yield "cliques_300", 300, union_of_cliques(300, 700, 1)
-    yield "cliques_2000", 2000, union_of_cliques(2000, 5200, 2)
+    yield "cliques_800", 800, union_of_cliques(800, 2000, 2)
 
 
 def main():
