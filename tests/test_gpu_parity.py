@@ -336,3 +336,28 @@ def test_kernel_threshold_boundaries(K, O, monkeypatch, two_pass):
         dense = np.stack(np.triu_indices(n, 1), axis=1)
         keep = rng.random(len(dense)) < 0.9
         check(n, dense[keep].astype(np.int64))
+
+
+def test_full_size_c3_known_answer(K, O):
+    """BASELINE config C3 (|V|=10M, |E|=100.1M, T=88.3M), the workload bench.py times.  Coreness against
+    the oracle; trussness through properties and through the SHA-256 recorded when EVERY value was compared
+    with the oracle's (scripts/c3_parity_oneoff.py, profiles/r01_c3_full_parity.log: 335 s of CPU)."""
+    import hashlib
+    nv = 10_000_000
+    uv = K.gen_hug_edges(nv, 24_250_000, 2.6, 42)
+    with K.KombAccel() as a:
+        a.from_edges(nv, uv)
+        del uv
+        assert a.ne == 100_120_558
+        rowptr, col = a.get_csr()
+        deg, core = a.run_core()
+        assert np.array_equal(deg, np.diff(rowptr).astype(np.int32))
+        assert np.array_equal(core, O.coreness(rowptr, col))
+        del rowptr, col
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        st = a.stats()
+        assert st["triangles"] == 88_336_441 and int(sup.sum(dtype=np.int64)) == 3 * 88_336_441
+        assert np.all(eu < ev) and np.all(tr >= 2) and np.all(tr <= sup + 2)
+        assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
+        assert hashlib.sha256(core.tobytes()).hexdigest()[:16] == "120d47bf172d8b8f"
+        assert hashlib.sha256(tr.tobytes()).hexdigest()[:16] == "5970a467914854ea"
