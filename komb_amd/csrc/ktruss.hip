@@ -208,13 +208,14 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 constexpr int kTriV = 16;
 constexpr int kTriCap = 512;
 constexpr int kTriU = 2;                       // probe items per lane per trip
-constexpr int kTriBuf = 192;                   // parked triangles per wave before they are handled
+constexpr int kTriBuf = 128;                   // parked triangles per wave (handled once >= 64 are waiting)
+constexpr int kTriCand = 192;                  // parked lookup candidates per wave (searched once >= 64 are waiting)
 constexpr int kTriWaves = kBlock / kWave;
 
 enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
+__global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
                                                       const uint32_t *__restrict__ off, int2 *__restrict__ inc, int ablate)
@@ -228,12 +229,16 @@ __global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restr
     __shared__ uint32_t sh_ra0[kTriWaves][kWave];
     __shared__ uint32_t sh_ra1[kTriWaves][kWave];
     __shared__ uint3 sh_tri[kTriWaves][kTriBuf];
+    __shared__ uint3 sh_cand[kTriWaves][kTriCand];
+    __shared__ uint32_t sh_sig[kTriWaves][2 * kTriV];
+    __shared__ uint32_t sh_ri[kTriWaves][kWave];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     int32_t *s_col = sh_col[w];
     uint32_t *s_cnt = sh_cnt[w], *s_orow = sh_orow[w], *s_pref = sh_pref[w];
     uint32_t *s_rb0 = sh_rb0[w], *s_ra0 = sh_ra0[w], *s_ra1 = sh_ra1[w];
-    uint3 *s_tri = sh_tri[w];
+    uint3 *s_tri = sh_tri[w], *s_cand = sh_cand[w];
+    uint32_t *s_sig = sh_sig[w], *s_ri = sh_ri[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
 
@@ -259,8 +264,22 @@ __global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restr
         const uint32_t E = S1 - S0;
         if (E == 0) continue;
         const bool staged = E <= (uint32_t)kTriCap;
-        if (staged)
+        int task_steps = 0;                                     // binary-search trips for the longest owned row
+        if (staged) {
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { s_col[k] = ocol[S0 + k]; s_cnt[k] = 0u; }
+            if (lane < 2 * kTriV) s_sig[lane] = 0u;
+            uint32_t rl = (lane < nvt) ? s_orow[lane + 1] - s_orow[lane] : 0u;
+            for (int o = 32; o > 0; o >>= 1) rl = max(rl, (uint32_t)__shfl_xor((int)rl, o));
+            task_steps = 32 - __clz((int)rl);
+            __builtin_amdgcn_wave_barrier();
+            // 64-bit Bloom signature of every owned row: a probe whose bit is clear cannot be in the row
+            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
+                int lo = 0, hi = nvt - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_orow[mid] <= S0 + k) lo = mid; else hi = mid - 1; }
+                const uint32_t hb = ((uint32_t)s_col[k] * 0x9E3779B1u) >> 26;
+                atomicOr(&s_sig[2 * lo + (int)(hb >> 5)], 1u << (hb & 31u));
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 
         uint32_t n_tri = 0;                                     // parked triangles (wave-uniform)
@@ -298,11 +317,47 @@ __global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restr
             n_tri = 0;
         };
 
+        // staged tasks: probes that pass the signature test are parked too and looked up densely
+        uint32_t n_cand = 0;                                    // wave-uniform
+        auto search_cands = [&]() {
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t b0 = 0; b0 < n_cand; b0 += kWave) {
+                const uint32_t x = b0 + (uint32_t)lane;
+                bool hit = false;
+                uint32_t e_rel = 0, l = 0, jj = 0;
+                if (x < n_cand) {
+                    const uint3 c = s_cand[x];
+                    e_rel = c.x & 0xFFFFu; jj = c.y;
+                    const uint32_t r = c.x >> 16;
+                    const int32_t wvv = (int32_t)c.z;
+                    l = s_orow[r] - S0;
+                    const uint32_t rend = s_orow[r + 1] - S0;
+                    uint32_t n = rend - l;
+                    for (int st = 0; st < task_steps; ++st) {   // branchless lower_bound, wave-uniform trip count
+                        const uint32_t half = n >> 1;
+                        const uint32_t probe = min(l + half, (uint32_t)kTriCap - 1u);
+                        const bool go = n > 0 && s_col[probe] < wvv;
+                        l = go ? l + half + 1u : l;
+                        n = go ? n - half - 1u : half;
+                    }
+                    hit = l < rend && s_col[min(l, (uint32_t)kTriCap - 1u)] == wvv;
+                }
+                const uint64_t hm = __ballot(hit);
+                if (hm) {
+                    if (hit) s_tri[n_tri + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint3(e_rel, l, jj);
+                    n_tri += (uint32_t)__popcll(hm);
+                    if (n_tri >= (uint32_t)kTriBuf - kWave) flush_tris();
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_cand = 0;
+        };
+
         for (uint32_t p0 = 0; p0 < E; p0 += kWave) {
             // lane <-> owned edge e = S0 + p0 + lane
             const uint32_t rel = p0 + (uint32_t)lane;
             const bool valid = rel < E;
-            uint32_t rb0 = 0, lenb = 0, ra0 = 0, ra1 = 0;
+            uint32_t rb0 = 0, lenb = 0, ra0 = 0, ra1 = 0, ri = 0;
             if (valid) {
                 int lo = 0, hi = nvt - 1;                     // source vertex: last idx with s_orow[idx] <= S0+rel
                 while (lo < hi) {
@@ -310,17 +365,15 @@ __global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restr
                     if (s_orow[mid] <= S0 + rel) lo = mid; else hi = mid - 1;
                 }
                 ra0 = s_orow[lo] - S0; ra1 = s_orow[lo + 1] - S0;
+                ri = (uint32_t)lo;
                 const int32_t b = staged ? s_col[rel] : ocol[S0 + rel];
                 rb0 = orow[b];
                 lenb = orow[b + 1] - rb0;
             }
             const uint32_t incl = wave_incl_scan(lenb);
             const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
-            uint32_t maxrow = ra1 - ra0;
-            for (int o = 32; o > 0; o >>= 1) maxrow = max(maxrow, (uint32_t)__shfl_xor((int)maxrow, o));
-            const int row_steps = 32 - __clz((int)maxrow);          // trips that empty a range of maxrow elements
             __builtin_amdgcn_wave_barrier();
-            s_pref[lane] = incl; s_rb0[lane] = rb0; s_ra0[lane] = ra0; s_ra1[lane] = ra1;
+            s_pref[lane] = incl; s_rb0[lane] = rb0; s_ra0[lane] = ra0; s_ra1[lane] = ra1; s_ri[lane] = ri;
             __builtin_amdgcn_wave_barrier();
             // kTriU items per lane per trip: the owner search, the gather of w and the row search of
             // the items are independent chains, so their latencies overlap
@@ -342,43 +395,44 @@ __global__ __launch_bounds__(kBlock, 5) void k_triangles(const uint32_t *__restr
                 int32_t wv[kTriU];
 #pragma unroll
                 for (int k = 0; k < kTriU; ++k) wv[k] = (valid[k] && !(ablate & 1)) ? ocol[j[k]] : (int32_t)j[k];
+                if (staged) {
 #pragma unroll
-                for (int k = 0; k < kTriU; ++k) {
-                    const bool look = valid[k] && !(ablate & 2);
-                    uint32_t l = look ? s_ra0[t[k]] : 0u, h = look ? s_ra1[t[k]] : 0u;
-                    const uint32_t rend = h;
-                    bool found;
-                    if (staged) {
-                        // branchless lower_bound, wave-uniform trip count (longest owned row of this pass)
-                        uint32_t n = h - l;
-                        for (int st = 0; st < row_steps; ++st) {
-                            const uint32_t half = n >> 1;
-                            const uint32_t probe = min(l + half, (uint32_t)kTriCap - 1u);
-                            const bool go = n > 0 && s_col[probe] < wv[k];
-                            l = go ? l + half + 1u : l;
-                            n = go ? n - half - 1u : half;
+                    for (int k = 0; k < kTriU; ++k) {
+                        bool cand = false;
+                        uint32_t r = 0;
+                        if (valid[k] && !(ablate & 2)) {
+                            r = s_ri[t[k]];
+                            const uint32_t hb = ((uint32_t)wv[k] * 0x9E3779B1u) >> 26;
+                            cand = (s_sig[2 * r + (hb >> 5)] >> (hb & 31u)) & 1u;
                         }
-                        found = l < rend && s_col[min(l, (uint32_t)kTriCap - 1u)] == wv[k];
-                    } else {
-                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wv[k]) l = mid + 1; else h = mid; }
-                        found = l < rend && ocol[S0 + l] == wv[k];
+                        const uint64_t cm = __ballot(cand);
+                        if (cm) {
+                            if (cand) s_cand[n_cand + (uint32_t)__popcll(cm & lanemask_lt())] =
+                                make_uint3((p0 + (uint32_t)t[k]) | (r << 16), j[k], (uint32_t)wv[k]);
+                            n_cand += (uint32_t)__popcll(cm);
+                        }
                     }
-                    // a hit is rare (~4% of probes): park it in the wave's LDS buffer and handle the
-                    // triangles densely, 64 at a time, instead of running the handler with a few lanes on
-                    const bool hit = found && !(ablate & 4);
-                    const uint64_t hm = __ballot(hit);
-                    if (hm) {
-                        if (hit) {
-                            const uint32_t slot = n_tri + (uint32_t)__popcll(hm & lanemask_lt());
-                            s_tri[slot] = make_uint3(p0 + (uint32_t)t[k], l, j[k]);   // e_rel, i_rel, j
+                    if (n_cand >= (uint32_t)kTriCand - kWave * kTriU) search_cands();
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kTriU; ++k) {
+                        const bool look = valid[k] && !(ablate & 2);
+                        uint32_t l = look ? s_ra0[t[k]] : 0u, h = look ? s_ra1[t[k]] : 0u;
+                        const uint32_t rend = h;
+                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wv[k]) l = mid + 1; else h = mid; }
+                        const bool hit = l < rend && ocol[S0 + l] == wv[k] && !(ablate & 4);
+                        const uint64_t hm = __ballot(hit);
+                        if (hm) {
+                            if (hit) s_tri[n_tri + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint3(p0 + (uint32_t)t[k], l, j[k]);
+                            n_tri += (uint32_t)__popcll(hm);
+                            if (n_tri >= (uint32_t)kTriBuf - kWave) flush_tris();
                         }
-                        n_tri += (uint32_t)__popcll(hm);
                     }
                 }
-                if (n_tri >= (uint32_t)kTriBuf - kWave * kTriU) { flush_tris(); }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        search_cands();
         flush_tris();
         if (staged) {
             __builtin_amdgcn_wave_barrier();
