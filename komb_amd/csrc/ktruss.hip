@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restr
                         l = go ? l + half + 1u : l;
                         n = go ? n - half - 1u : half;
                     }
-                    hit = l < rend && s_col[min(l, (uint32_t)kTriCap - 1u)] == wvv;
+                    hit = l < rend && s_col[min(l, (uint32_t)kTriCap - 1u)] == wvv && !(ablate & 4);
                 }
                 const uint64_t hm = __ballot(hit);
                 if (hm) {
