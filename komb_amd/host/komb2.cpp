@@ -10,6 +10,10 @@
 // There is no CPU fallback: without a GPU the program exits non-zero.
 //
 // Environment knobs (KOMB.py passes a fixed argv, so extras are env vars):
+//   KOMB_V1_OUTPUTS=1   re-enable combineFile and splitAnomalousUnitigs (commented out at
+//                       src/komb2.cpp:126,139): combined.fasta, top_/low_scoring_anomalous_unitigs.txt,
+//                       reference quirks kept; "fixed" = per-vertex decision and unitig names
+//   KOMB_V1_ONLY=1      only those two stages, from the kcore.tsv + CoreA_anomaly.txt already in -o
 //   KOMB_TRUSS=1        re-enable the runTruss stage the reference has commented
 //                       out at src/graph.cpp:478 (writes truss_unitigs.fasta)
 //   KOMB_STRICT_SAM=1   parse every SAM line (the reference drops the line that
@@ -402,7 +406,7 @@ std::unordered_map<std::string, std::string> read_unitigs(const std::string &pat
 }
 
 // CoreA::readKOMBOutput (src/CoreA.h:24-56): field 2 = coreness, field 3 = degree; '#' lines skipped
-bool read_kcore_tsv(const std::string &path, std::vector<int32_t> &core, std::vector<int32_t> &deg)
+bool read_kcore_tsv(const std::string &path, std::vector<int32_t> &core, std::vector<int32_t> &deg, std::vector<std::string> *name = nullptr)
 {
     FILE *fp = fopen(path.c_str(), "r");
     if (!fp) return false;
@@ -413,6 +417,7 @@ bool read_kcore_tsv(const std::string &path, std::vector<int32_t> &core, std::ve
         int i = 0;
         char *save = nullptr;
         for (char *tok = strtok_r(line, "\t", &save); tok; tok = strtok_r(nullptr, "\t", &save), ++i) {
+            if (i == 1 && name) name->emplace_back(tok);
             if (i == 2) core.push_back(atoi(tok));
             if (i == 3) deg.push_back(atoi(tok));
         }
@@ -481,6 +486,84 @@ void corea_stage(komb_ctx *ctx, const std::string &outdir, const std::vector<int
     fclose(fp);
 }
 
+// combineFile (src/graph.cpp:591-635; call commented out at src/komb2.cpp:126): one FASTA record per
+// kcore.tsv row, header ">Unitig_<name>|<coreness>", sequence only when the unitig file has that name.
+// The reference re-parses kcore.tsv for the fields; the same values are still in memory here.
+void combine_file(const std::string &outdir, const Names &names, const std::vector<int32_t> &core,
+                  const std::unordered_map<std::string, std::string> &unitigs, int threads)
+{
+    const std::string path = outdir + "/combined.fasta";
+    FILE *fp = fopen(path.c_str(), "w+");
+    if (!fp) file_not_found(path);
+    write_rows(fp, (int64_t)core.size(), threads, [&](int64_t i, std::string &buf) {
+        const std::string &nm = names.name[(size_t)i];
+        buf.append(">Unitig_").append(nm).append("|").append(std::to_string(core[(size_t)i])).append("\n");
+        auto it = unitigs.find(nm);
+        if (it != unitigs.end()) buf.append(it->second).append("\n");
+    });
+    fclose(fp);
+}
+
+// getMedian (src/graph.cpp:650-665), including its window: size = end - start - 1
+double v1_median(const std::vector<double> &v, int start, int end)
+{
+    const int size = end - start - 1;
+    if (size % 2 == 0) return (v[(size_t)(start + size / 2 - 1)] + v[(size_t)(start + size / 2)]) / 2;
+    return v[(size_t)(start + (size - 1) / 2)];
+}
+
+// splitAnomalousUnitigs (src/graph.cpp:667-749; call commented out at src/komb2.cpp:139). Kept as the
+// reference has it, quirks included: scores are the six-decimal text of CoreA_anomaly.txt read back;
+// row i of the output is decided by the i-th SMALLEST score (the sorted copy is what :725 indexes), is
+// labelled "Unitig_<i>" and looks the sequence up under the name "<i>". mode "fixed" instead decides
+// row i by vertex i's own score and uses the vertex's unitig name.
+// The quartile windows read outside the vector for fewer than 6 scores (undefined in the reference):
+// refused with a note.
+bool split_anomalous(const std::string &outdir, const Names &names, const std::unordered_map<std::string, std::string> &unitigs,
+                     bool fixed, int threads)
+{
+    const std::string in_path = outdir + "/CoreA_anomaly.txt";
+    FILE *in = fopen(in_path.c_str(), "r");
+    if (!in) file_not_found(in_path);
+    std::vector<double> score;
+    char *line = nullptr;
+    size_t cap = 0;
+    while (getline(&line, &cap, in) != -1) {
+        const char *tab = strchr(line, '\t');
+        if (tab) score.push_back(strtod(tab + 1, nullptr));
+    }
+    free(line);
+    fclose(in);
+    const int size = (int)score.size();
+    if (size < 6) {
+        fprintf(stderr, "komb2: note: %d CoreA scores; the reference's quartile windows (src/graph.cpp:714-724) need at least 6, split skipped\n", size);
+        return false;
+    }
+    std::vector<double> sorted(score);
+    std::sort(sorted.begin(), sorted.end());
+    const double q1 = v1_median(sorted, 0, size / 2 - 1);
+    const double q3 = size % 2 == 0 ? v1_median(sorted, size / 2, size - 1) : v1_median(sorted, size / 2 + 1, size - 1);
+    const double cutoff = q3 + 1.5 * (q3 - q1);
+    const std::vector<double> &decide = fixed ? score : sorted;
+
+    const std::string top_path = outdir + "/top_scoring_anomalous_unitigs.txt", low_path = outdir + "/low_scoring_anomalous_unitigs.txt";
+    FILE *top = fopen(top_path.c_str(), "w+"), *low = fopen(low_path.c_str(), "w+");
+    if (!top) file_not_found(top_path);
+    if (!low) file_not_found(low_path);
+    for (int pass = 0; pass < 2; ++pass) {
+        write_rows(pass == 0 ? top : low, size, threads, [&](int64_t i, std::string &buf) {
+            if ((decide[(size_t)i] >= cutoff) != (pass == 0)) return;
+            const std::string key = fixed && (size_t)i < names.name.size() ? names.name[(size_t)i] : std::to_string(i);
+            buf.append("Unitig_").append(key).append("\n");
+            auto it = unitigs.find(key);
+            if (it != unitigs.end()) buf.append(it->second).append("\n");
+        });
+    }
+    fclose(top);
+    fclose(low);
+    return true;
+}
+
 } // namespace
 
 int main(int argc, const char **argv)
@@ -500,6 +583,18 @@ int main(int argc, const char **argv)
         komb_ctx *ctx = komb_create(&o);
         corea_stage(ctx, args.outdir, deg, core, args.threads);
         komb_destroy(ctx);
+        return 0;
+    }
+
+    // v1-outputs-only mode: combined.fasta and the split from an existing kcore.tsv + CoreA_anomaly.txt (no device)
+    if (env_on("KOMB_V1_ONLY")) {
+        std::vector<int32_t> core, deg;
+        Names names;
+        if (!read_kcore_tsv(args.outdir + "/kcore.tsv", core, deg, &names.name)) file_not_found(args.outdir + "/kcore.tsv");
+        const auto unitigs = read_unitigs(args.unitigs);
+        const char *mode = getenv("KOMB_V1_OUTPUTS");
+        combine_file(args.outdir, names, core, unitigs, args.threads);
+        split_anomalous(args.outdir, names, unitigs, mode && strcmp(mode, "fixed") == 0, args.threads);
         return 0;
     }
 
@@ -614,12 +709,16 @@ int main(int argc, const char **argv)
     fprintf(stdout, "Created Kcore\n");
     auto t_core = clk::now();
     fprintf(stdout, "\nTime elapsed for edgeInfo: %.3f s\n", std::chrono::duration<double>(t_core - t_generate).count());   // sic (src/komb2.cpp:124)
+    const char *v1 = getenv("KOMB_V1_OUTPUTS");
+    const bool v1_on = env_on("KOMB_V1_OUTPUTS");
+    if (v1_on) combine_file(args.outdir, names, core, unitigs, args.threads);
     auto t_combine = clk::now();
     fprintf(stdout, "\nTime elapsed for combineFile: %.3f s\n", std::chrono::duration<double>(t_combine - t_core).count());
 
     corea_stage(ctx, args.outdir, deg, core, args.threads);  // anomalyDetection (src/graph.cpp:637-648)
     fprintf(stdout, "\nTime elapsed for anomalyDetection: %.3f s\n", since(t_combine));
     fprintf(stdout, "Identified anomalous unitigs\n");
+    if (v1_on) split_anomalous(args.outdir, names, unitigs, strcmp(v1, "fixed") == 0, args.threads);
     fprintf(stdout, "Created anomalouss unitigs file\n");
     fprintf(stdout, "\nTime elapsed for KOMB: %.3f s\n", since(begin_komb));
     fprintf(stdout, "\nTime elapsed for analysis (sec) = %.3f \n", since(begin));

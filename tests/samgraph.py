@@ -104,3 +104,61 @@ def make_fixture(n_unitigs=2000, n_lines=20000, seed=1):
         return "".join(out).encode()
 
     return "".join(fasta).encode(), sam(1), sam(2)
+
+
+# ---- v1 outputs (combineFile / splitAnomalousUnitigs), restated for the checker -------------------
+
+def read_unitigs(fasta: bytes):
+    """readUnitigsFile (src/graph.cpp:565-589): name = text between '>' and the first space;
+    each sequence line contributes all but its last character."""
+    out, cur = {}, None
+    for ln in fasta.decode().splitlines(keepends=True):
+        if ln.startswith(">"):
+            sp = ln.find(" ")
+            cur = ln[1:sp] if sp >= 0 else ln[1:]
+            out[cur] = ""
+        else:
+            out[cur] += ln[:-1]
+    return out
+
+
+def combined_fasta(kcore_tsv: str, unitigs: dict) -> str:
+    """combineFile (src/graph.cpp:591-635)."""
+    out = []
+    for ln in kcore_tsv.splitlines():
+        if ln.startswith("#"):
+            continue
+        f = ln.split("\t")
+        out.append(f">Unitig_{f[1]}|{f[2]}\n")
+        if f[1] in unitigs:
+            out.append(unitigs[f[1]] + "\n")
+    return "".join(out)
+
+
+def _v1_median(v, start, end):
+    """getMedian (src/graph.cpp:650-665), window quirk kept: size = end - start - 1."""
+    size = end - start - 1
+    if size % 2 == 0:
+        return (v[start + size // 2 - 1] + v[start + size // 2]) / 2
+    return v[start + (size - 1) // 2]
+
+
+def split_anomalous(corea_txt: str, unitigs: dict, names=None):
+    """splitAnomalousUnitigs (src/graph.cpp:667-749): returns (top, low, cutoff). names=None keeps the
+    reference's behaviour (row i decided by the i-th smallest score, labelled by the index i);
+    a list of names gives the "fixed" variant."""
+    score = [float(ln.split("\t")[1]) for ln in corea_txt.splitlines()]
+    n = len(score)
+    s = sorted(score)
+    q1 = _v1_median(s, 0, n // 2 - 1)
+    q3 = _v1_median(s, n // 2, n - 1) if n % 2 == 0 else _v1_median(s, n // 2 + 1, n - 1)
+    cutoff = q3 + 1.5 * (q3 - q1)
+    decide = s if names is None else score
+    top, low = [], []
+    for i in range(n):
+        key = str(i) if names is None else names[i]
+        dst = top if decide[i] >= cutoff else low
+        dst.append(f"Unitig_{key}\n")
+        if key in unitigs:
+            dst.append(unitigs[key] + "\n")
+    return "".join(top), "".join(low), cutoff

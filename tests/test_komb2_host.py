@@ -107,3 +107,52 @@ def test_sam_edge_cases(fixture, tmp_path, case):
             names, edges = _graph_from_run(str(out))
             want_names, want_edges = samgraph.build_graph(a, b, threads, strict)
             assert names == want_names and edges == want_edges, (case, threads, strict)
+
+
+@pytest.mark.parametrize("n,mode", [(6, "1"), (7, "1"), (401, "1"), (400, "fixed"), (37, "fixed")])
+def test_v1_outputs(built, tmp_path, n, mode):
+    """combineFile + splitAnomalousUnitigs (src/graph.cpp:591-635,667-749; off at src/komb2.cpp:126,139),
+    from an existing kcore.tsv / CoreA_anomaly.txt, against the restatement in samgraph.py."""
+    import random
+    rnd = random.Random(n)
+    # unitig names: a permutation of 0..n-1 minus a few (so index-named and name-keyed lookups differ and some miss)
+    ids = list(range(n))
+    rnd.shuffle(ids)
+    fasta = "".join(f">{u} LN:i:60 KC:i:9\n{''.join(rnd.choice('ACGT') for _ in range(70))}\n"
+                    f"{''.join(rnd.choice('ACGT') for _ in range(11))}\n" for u in ids if u % 9 != 4)
+    names = [str(u) for u in ids]
+    kcore = "#VID\tName\tCoreness\tDegree\n" + "".join(
+        f"{i}\t{names[i]}\t{rnd.randrange(1, 9)}\t{rnd.randrange(1, 40)}\n" for i in range(n))
+    # heavy-tailed scores with ties, six decimals like "%f" prints them
+    corea = "".join(f"{i}\t{(rnd.random() ** 4) * rnd.choice([1, 1, 1, 6]):.6f}\n" for i in range(n))
+    (tmp_path / "u.fa").write_text(fasta)
+    (tmp_path / "kcore.tsv").write_text(kcore)
+    (tmp_path / "CoreA_anomaly.txt").write_text(corea)
+    r = run(["-t", "3", "-o", str(tmp_path), "-i", "x", "-j", "y", "-u", str(tmp_path / "u.fa")],
+            env={"KOMB_V1_ONLY": "1", "KOMB_V1_OUTPUTS": mode})
+    assert r.returncode == 0, r.stderr
+    unitigs = samgraph.read_unitigs(fasta.encode())
+    assert (tmp_path / "combined.fasta").read_text() == samgraph.combined_fasta(kcore, unitigs)
+    top, low, _ = samgraph.split_anomalous(corea, unitigs, names if mode == "fixed" else None)
+    assert (tmp_path / "top_scoring_anomalous_unitigs.txt").read_text() == top
+    assert (tmp_path / "low_scoring_anomalous_unitigs.txt").read_text() == low
+    assert low and (top or n < 100)
+
+
+def test_v1_split_known_answer_and_small_input(built, tmp_path):
+    """Hand-worked case: 8 scores 0..7 -> q1 window [0,3) size 2 -> (s[0]+s[1])/2 = 0.5; q3 window
+    start 4, size 2 -> (s[4]+s[5])/2 = 4.5; cutoff 10.5 -> nothing on top. With the last score 20 the sorted
+    row 7 (and only it) goes on top and is labelled Unitig_7 although the outlier is vertex 2."""
+    (tmp_path / "u.fa").write_text("".join(f">{i} x\nACGT\n" for i in range(8)))
+    (tmp_path / "kcore.tsv").write_text("#VID\tName\tCoreness\tDegree\n" + "".join(f"{i}\t{i}\t1\t1\n" for i in range(8)))
+    vals = [0, 1, 20, 3, 4, 5, 6, 2]
+    (tmp_path / "CoreA_anomaly.txt").write_text("".join(f"{i}\t{float(v):.6f}\n" for i, v in enumerate(vals)))
+    args = ["-o", str(tmp_path), "-i", "x", "-j", "y", "-u", str(tmp_path / "u.fa")]
+    assert run(args, env={"KOMB_V1_ONLY": "1"}).returncode == 0
+    assert (tmp_path / "top_scoring_anomalous_unitigs.txt").read_text() == "Unitig_7\nACGT\n"
+    assert run(args, env={"KOMB_V1_ONLY": "1", "KOMB_V1_OUTPUTS": "fixed"}).returncode == 0
+    assert (tmp_path / "top_scoring_anomalous_unitigs.txt").read_text() == "Unitig_2\nACGT\n"
+    # fewer than 6 scores: the reference reads outside its vector; refused with a note, combined.fasta still written
+    (tmp_path / "CoreA_anomaly.txt").write_text("0\t0.100000\n1\t0.200000\n2\t0.300000\n")
+    r = run(args, env={"KOMB_V1_ONLY": "1"})
+    assert r.returncode == 0 and "split skipped" in r.stderr
