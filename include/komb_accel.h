@@ -53,7 +53,7 @@ typedef struct komb_stats {
     int64_t oriented_items;         /* sum_{(a->b)} d+(a)+d+(b), (degree,id) orientation */
     int32_t max_degree, max_coreness, max_trussness;
     int32_t core_levels, core_subrounds;    /* populated levels; PROCESS sub-rounds   */
-    int32_t core_launches, reserved0;       /* launches issued                        */
+    int32_t core_launches, truss_tail_runs; /* launches issued; hand-overs to the LDS tail kernel */
     int32_t truss_levels, truss_subrounds;  /* populated levels; PROCESS sub-rounds   */
     int32_t truss_scans, truss_launches;    /* SCAN launches; launches issued         */
     /* HIP-event times (ms), each measured on the stream the kernels run on */

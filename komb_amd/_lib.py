@@ -27,7 +27,7 @@ class KombStats(ctypes.Structure):
         ("sum_deg_sq", ctypes.c_int64), ("wedge_items", ctypes.c_int64), ("oriented_items", ctypes.c_int64),
         ("max_degree", ctypes.c_int32), ("max_coreness", ctypes.c_int32), ("max_trussness", ctypes.c_int32),
         ("core_levels", ctypes.c_int32), ("core_subrounds", ctypes.c_int32),
-        ("core_launches", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("core_launches", ctypes.c_int32), ("truss_tail_runs", ctypes.c_int32),
         ("truss_levels", ctypes.c_int32), ("truss_subrounds", ctypes.c_int32),
         ("truss_scans", ctypes.c_int32), ("truss_launches", ctypes.c_int32),
         ("ms_build", ctypes.c_double), ("ms_core", ctypes.c_double), ("ms_orient", ctypes.c_double),

@@ -24,7 +24,7 @@ struct PeelCtrl {
     int32_t  mode;          // 0 = SCAN, 1 = PROCESS
     int32_t  level;         // current peel level (degree k / support L)
     int32_t  round;         // sub-round id stamped on the current frontier
-    int32_t  done;          // 1 once every unit is peeled (2 = inconsistent state)
+    int32_t  done;          // 1 once every unit is peeled (2 = inconsistent state, 3 = handed over, see tail_limit)
     uint32_t cur_light;     // entries in the current light queue (unit ids)
     uint32_t cur_heavy;     // entries in the current heavy queue ((unit, chunk) pairs)
     int32_t  cur_sel;       // which of the two queue pairs is current
@@ -43,7 +43,9 @@ struct PeelCtrl {
     int32_t  next_min;      // min live key above the scanned level
     uint32_t blocks_done;   // second-level arrival ticket
     uint32_t acc;           // units that entered a frontier in this launch
-    uint32_t pad1[9];
+    // ---- hand-over to a specialised tail kernel (k-truss, truss_tail.h)
+    uint32_t tail_limit;    // a level that starts with at most this many units left sets done = 3 (0: never)
+    uint32_t pad1[8];
 };
 static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
 
@@ -181,7 +183,7 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
 void graph_free(komb_ctx *ctx);
 void truss_free(komb_ctx *ctx);
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done);
-void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units);
+void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units, uint32_t tail_limit = 0);
 int peel_grid(int64_t units);
 
 // Issue `launch()` in batches until the device control block reports done.

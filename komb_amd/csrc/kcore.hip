@@ -82,7 +82,7 @@ __global__ void k_ctrl_pre(uint32_t *grp_done)
     if (threadIdx.x < kMaxGroups) grp_done[threadIdx.x] = 0u;
     if (threadIdx.x == 0) { grp_done[kMaxGroups] = 0u; grp_done[kMaxGroups + 1] = 0x7FFFFFFFu; }
 }
-__global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t units)
+__global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t units, uint32_t tail_limit)
 {
     if (threadIdx.x == 0) {
         const uint32_t peeled = grp_done[kMaxGroups];
@@ -94,6 +94,7 @@ __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t u
         c.level = c.remaining ? first : 0;           // start at the first populated level
         c.n_levels = peeled ? 1 : 0;                 // level 0 was populated by item-less units
         c.next_min = 0x7FFFFFFF;
+        c.tail_limit = tail_limit;
         *ctrl = c;
     }
 }
@@ -102,9 +103,9 @@ __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t u
 
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done) { k_ctrl_pre<<<1, 128, 0, s>>>(d_grp_done); }
 
-void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units)
+void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units, uint32_t tail_limit)
 {
-    k_ctrl_init<<<1, 64, 0, s>>>(d_ctrl, d_grp_done, units);
+    k_ctrl_init<<<1, 64, 0, s>>>(d_ctrl, d_grp_done, units, tail_limit);
 }
 
 int peel_grid(int64_t units)

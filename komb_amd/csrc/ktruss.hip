@@ -27,6 +27,7 @@
 //   4. gather results into canonical (min,max)-lexicographic edge order with
 //      ORIGINAL vertex ids -- the identity the C ABI promises.
 #include "peel_dev.h"
+#include "truss_tail.h"
 
 #include <cstdlib>
 
@@ -916,15 +917,85 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kMaxGroups + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
+    // hand-over threshold of the LDS tail (truss_tail.h); KOMB_TAIL=0 keeps the whole peel in the general engine
+    uint32_t tail_limit = kTailEdges;
+    if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
+    if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
+    TailBufs T{};
+    if (tail_limit) {
+        KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
+        KOMB_HIP(ctx, bufs.alloc(&T.cnt, 16));
+        KOMB_HIP(ctx, bufs.alloc(&T.vlist, (size_t)kTailMaxV));
+        KOMB_HIP(ctx, bufs.alloc(&T.rows, (size_t)kTailMaxV * kTailRowWords));
+        KOMB_HIP(ctx, bufs.alloc(&T.pair, (size_t)tail_limit));
+        KOMB_HIP(ctx, bufs.alloc(&T.sup, (size_t)tail_limit));
+        KOMB_HIP(ctx, bufs.alloc(&T.gid, (size_t)tail_limit));
+        KOMB_HIP(ctx, bufs.alloc(&T.gid_by_rank, (size_t)tail_limit));
+        KOMB_HIP(ctx, bufs.alloc(&T.truss_by_rank, (size_t)tail_limit));
+        KOMB_HIP(ctx, bufs.alloc(&T.spill[0], (size_t)tail_limit));
+        KOMB_HIP(ctx, bufs.alloc(&T.spill[1], (size_t)tail_limit));
+        T.max_edges = tail_limit;
+    }
+    // the live edges are those of `list` (or all m when list is null) whose stamp is still kAlive
+    auto run_tail = [&](const int32_t *list, uint32_t n_in) -> int {
+        KOMB_HIP(ctx, hipMemsetAsync(T.vmap, 0, (size_t)nv * sizeof(int32_t), s));
+        KOMB_HIP(ctx, hipMemsetAsync(T.cnt, 0, 8 * sizeof(uint32_t), s));
+        KOMB_HIP(ctx, hipMemsetAsync(T.rows, 0, (size_t)kTailMaxV * kTailRowWords * sizeof(unsigned long long), s));
+        const int g = grid_for(n_in, kBlock, 256);
+        // KOMB_TAIL_DEBUG=1: one line per hand-over on stderr (HIP-event times; building with -DKOMB_TAIL_TIMERS
+        // adds the kernel's own per-phase stopwatch)
+        const bool dbg = getenv("KOMB_TAIL_DEBUG") != nullptr;
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        if (dbg) { for (auto &e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], s); }
+        k_tail_mark<<<g, kBlock, 0, s>>>(list, n_in, d_sup, d_stamp, d_osrc, d_ocol, T);
+        k_tail_number<<<1, kTailMaxV, 0, s>>>(T);
+        k_tail_rows<<<g, kBlock, 0, s>>>(list, n_in, d_sup, d_stamp, d_osrc, d_ocol, T);
+        if (dbg) (void)hipEventRecord(ev[1], s);
+        k_truss_tail<<<1, 1024, 0, s>>>(d_ctrl, T, d_truss);
+        if (dbg) (void)hipEventRecord(ev[2], s);
+        KOMB_HIP(ctx, d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)));
+        ++st.truss_tail_runs;
+        if (dbg) {
+            uint32_t h[16];
+            float m0 = 0, m1 = 0, m2 = 0;
+            (void)hipEventElapsedTime(&m0, ctx->timer.a, ev[0]); (void)hipEventElapsedTime(&m1, ev[0], ev[1]); (void)hipEventElapsedTime(&m2, ev[1], ev[2]);
+            for (auto &e : ev) (void)hipEventDestroy(e);
+            KOMB_HIP(ctx, d2h(ctx, h, T.cnt, sizeof(h)));
+            fprintf(stderr, "komb tail: %u vertices, %u edges, %s; general engine before it %.1f us, setup %.1f us, tail kernel %.1f us\n",
+                    h[0], h[1], ctx->h_ctrl[0].done == 1 ? "done" : "refused", m0 * 1000.f, m1 * 1000.f, m2 * 1000.f);
+#ifdef KOMB_TAIL_TIMERS
+            fprintf(stderr, "komb tail: us in kernel: load %.1f ranks %.1f supports %.1f scan %.1f mark %.1f triangles %.1f retire %.1f results %.1f\n",
+                    h[14] / 100.0, h[15] / 100.0, h[8] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0, h[12] / 100.0, h[13] / 100.0);
+#endif
+        }
+        return KOMB_OK;
+    };
     ctx->timer.start(s);
     peel_ctrl_pre(s, d_grp);
     k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kMaxGroups);
-    peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m);
+    peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
     const int gp = peel_grid(m);
-    int launches = 0;
-    int rc = drive_peel(ctx, d_ctrl, m, [&]() {
-        k_peel_step<TrussProblem><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
-    }, &launches);
+    int launches = 0, rc = KOMB_OK;
+    st.truss_tail_runs = 0;
+    if (tail_limit && (uint64_t)m <= tail_limit) {
+        // small graph: the tail takes the whole peel (unless it is refused, or nothing is left to peel)
+        rc = d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) == hipSuccess ? KOMB_OK : KOMB_ERR_DEVICE;
+        if (rc == KOMB_OK && !ctx->h_ctrl[0].done) rc = run_tail(nullptr, (uint32_t)m);
+    } else {
+        ctx->h_ctrl[0].done = 0;
+    }
+    for (int guard = 0; rc == KOMB_OK && ctx->h_ctrl[0].done != 1 && ctx->h_ctrl[0].done != 2 && guard < 64; ++guard) {
+        if (ctx->h_ctrl[0].done == 3) {
+            const PeelCtrl &c = ctx->h_ctrl[0];
+            rc = c.live_mode ? run_tail(Q.live[c.live_sel], c.live_count) : run_tail(nullptr, (uint32_t)m);
+            continue;
+        }
+        int batch = 0;
+        rc = drive_peel(ctx, d_ctrl, m, [&]() {
+            k_peel_step<TrussProblem><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
+        }, &batch);
+        launches += batch;
+    }
     st.ms_peel = ctx->timer.stop(s);
     KOMB_TRY(rc);
     if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss peel ended in an inconsistent state");

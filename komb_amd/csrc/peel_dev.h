@@ -53,6 +53,7 @@ struct CtrlView {                              // launch-stable part of the cont
     uint32_t cur_light, cur_heavy, remaining;
     uint32_t live_count;
     int32_t live_sel, live_mode;
+    uint32_t tail_limit;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -234,7 +235,10 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
         nsel = sel ^ 1; round += 1;
         if (cur_l + cur_h == 0) {
             if (remaining == 0) done = 1;
-            else { level += 1; mode = MODE_SCAN; }
+            else {
+                level += 1; mode = MODE_SCAN;
+                if (remaining <= cv.tail_limit) done = 3;    // the rest goes to the problem's tail kernel
+            }
         }
     }
     ctrl->mode = mode; ctrl->level = level; ctrl->round = round; ctrl->done = done;
@@ -243,6 +247,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
     out->mode = mode; out->level = level; out->round = round; out->done = done;
     out->cur_sel = nsel; out->cur_light = cur_l; out->cur_heavy = cur_h; out->remaining = remaining;
     out->live_count = live_count; out->live_sel = live_sel; out->live_mode = live_mode;
+    out->tail_limit = cv.tail_limit;
 }
 
 // ------------------------------------------------------------ the step kernel
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         sh_cv.cur_sel = ctrl->cur_sel; sh_cv.cur_light = ctrl->cur_light; sh_cv.cur_heavy = ctrl->cur_heavy;
         sh_cv.remaining = ctrl->remaining; sh_cv.live_count = ctrl->live_count;
         sh_cv.live_sel = ctrl->live_sel; sh_cv.live_mode = ctrl->live_mode;
+        sh_cv.tail_limit = ctrl->tail_limit;
     }
     __syncthreads();
     CtrlView cv = sh_cv;

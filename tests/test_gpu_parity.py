@@ -361,3 +361,43 @@ def test_full_size_c3_known_answer(K, O):
         assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
         assert hashlib.sha256(core.tobytes()).hexdigest()[:16] == "120d47bf172d8b8f"
         assert hashlib.sha256(tr.tobytes()).hexdigest()[:16] == "5970a467914854ea"
+
+
+def test_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
+    """The single-workgroup LDS tail (truss_tail.h) against the general engine (KOMB_TAIL=0) and the oracle:
+    whole small graphs, hand-over in mid-peel at several thresholds, refusal (too many vertices),
+    frontier spill beyond the LDS queues (a clique peels all its edges in one sub-round)."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for nv, ne in ((60, 900), (400, 14000), (900, 30000), (3000, 90000)):
+        cases.append((nv, rng.integers(0, nv, (ne, 2)).astype(np.int64)))
+    cases.append((30000, K.gen_hug_edges(30000, 90000, 2.3, 9)))
+    cases.append((120000, K.gen_hug_edges(120000, 300000, 2.6, 10)))
+    for n in (40, 300, 340):                                    # K_300: 44,850 edges, K_340: 57,630
+        cases.append((n, np.stack(np.triu_indices(n, 1), axis=1).astype(np.int64)))
+    # many disjoint triangles + one K_20: few edges left at the end but on > 1024 vertices at first
+    tri = np.arange(6000).reshape(-1, 3)
+    k20 = 6000 + np.stack(np.triu_indices(20, 1), axis=1)
+    cases.append((6020, np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [0, 2]], k20]).astype(np.int64)))
+    for nv, uv in cases:
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            rowptr, col = a.get_csr()
+            want = O.trussness(rowptr, col)
+            monkeypatch.setenv("KOMB_TAIL", "0")
+            _, _, tr0 = a.run_truss()
+            assert a.stats()["truss_tail_runs"] == 0
+            assert np.array_equal(tr0, want)
+            ran = 0
+            for limit in (None, "65534", "2000", "150"):
+                if limit is None:
+                    monkeypatch.delenv("KOMB_TAIL", raising=False)
+                else:
+                    monkeypatch.setenv("KOMB_TAIL", limit)
+                _, _, tr = a.run_truss()
+                st = a.stats()
+                assert np.array_equal(tr, want), (nv, limit)
+                assert st["max_trussness"] == want.max()
+                ran += st["truss_tail_runs"]
+            assert ran > 0 or want.max() <= 2, nv
+    monkeypatch.delenv("KOMB_TAIL", raising=False)
