@@ -931,6 +931,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&T.sup, (size_t)tail_limit));
         KOMB_HIP(ctx, bufs.alloc(&T.gid, (size_t)tail_limit));
         KOMB_HIP(ctx, bufs.alloc(&T.gid_by_rank, (size_t)tail_limit));
+        KOMB_HIP(ctx, bufs.alloc(&T.pair_by_rank, (size_t)tail_limit));
         KOMB_HIP(ctx, bufs.alloc(&T.truss_by_rank, (size_t)tail_limit));
         KOMB_HIP(ctx, bufs.alloc(&T.spill[0], (size_t)tail_limit));
         KOMB_HIP(ctx, bufs.alloc(&T.spill[1], (size_t)tail_limit));

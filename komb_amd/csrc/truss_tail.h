@@ -42,6 +42,7 @@ struct TailBufs {
     int32_t *sup;                  // [E] live support
     int32_t *gid;                  // [E] edge id of the general engine
     int32_t *gid_by_rank;          // [E]
+    uint32_t *pair_by_rank;        // [E]
     int32_t *truss_by_rank;        // [E]
     uint32_t *spill[2];            // [E] frontier entries beyond the LDS queues
     uint32_t max_edges;            // capacity of the [E] arrays
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(1024) void k_truss_tail(PeelCtrl *ctrl, TailBufs T,
         const uint32_t r = tail_rank(t, lo, hi);
         atomicOr(&t.S[r >> 1], ((uint32_t)T.sup[j] & 0xFFFFu) << (16 * (r & 1)));
         T.gid_by_rank[r] = T.gid[j];
+        T.pair_by_rank[r] = code;
     }
     __syncthreads();
 
@@ -262,47 +264,39 @@ __global__ __launch_bounds__(1024) void k_truss_tail(PeelCtrl *ctrl, TailBufs T,
     const uint32_t gl = (uint32_t)lane & 15u;
     uint32_t *park = t.park + (tid >> 6) * kTailPark;
     while (alive > 0) {
-        // ---- SCAN: live edges with support <= L, straight from the matrix (the rank runs along the row)
-        if (tid == 0) { sh_cnt[sel] = 0u; sh_min = 0x7FFFFFFF; }
+        // ---- SCAN, linear in the rank-ordered supports.  Pass 1: the smallest live support = the next
+        // populated level (everything <= the level just finished is gone).  Pass 2: the edges at that
+        // level become the frontier; their vertex pairs come from the rank-ordered copy of the edge list.
+        if (tid == 0) { sh_cnt[sel] = 0u; sh_cnt[sel ^ 1] = 0u; sh_min = 0x7FFFFFFF; }
         __syncthreads();
         int32_t lmin = 0x7FFFFFFF;
-        for (uint32_t w = tid; w < n * t.W; w += 1024) {
-            const uint32_t u = w / t.W, j = w % t.W;
-            if (j < (u >> 6)) continue;
-            const uint32_t wt = tail_tri(u, t.W) + j - (u >> 6);
-            const unsigned long long all = t.U[wt];
-            unsigned long long bits = all & t.A[w];                 // original rank order, live edges only
-            const uint32_t r0 = (uint32_t)t.base[u] + (uint32_t)t.pre[wt];
-            while (bits) {
-                const uint32_t b = (uint32_t)__ffsll((long long)bits) - 1u;
-                bits &= bits - 1ull;
-                const uint32_t s = tail_sup(t, r0 + (uint32_t)__popcll(all & ((1ull << b) - 1ull)));
-                if ((int32_t)s <= L) q_push(sel, (u << 16) | (j * 64 + b));
-                else lmin = min(lmin, (int32_t)s);
-            }
+        for (uint32_t w = tid; w < wS; w += 1024) {
+            const uint32_t two = t.S[w];
+            const uint32_t s0 = two & 0xFFFFu, s1 = two >> 16;
+            if (s0 < kTDead) lmin = min(lmin, (int32_t)s0);
+            if (s1 < kTDead && 2 * w + 1 < E) lmin = min(lmin, (int32_t)s1);
         }
         lmin = wave_min(lmin);
         if (lane == 0 && lmin != 0x7FFFFFFF) atomicMin(&sh_min, lmin);
         __syncthreads();
+        if (sh_min == 0x7FFFFFFF) { state = 2; break; }
+        L = max(L, sh_min);
+        for (uint32_t w = tid; w < wS; w += 1024) {
+            const uint32_t two = t.S[w];
+#pragma unroll
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t s = (two >> (16 * h)) & 0xFFFFu, r = 2 * w + h;
+                if (s < kTDead && r < E && (int32_t)s <= L) {
+                    q_push(sel, __hip_atomic_load(&T.pair_by_rank[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    tail_to_frontier(t, r);
+                    T.truss_by_rank[r] = L + 2;
+                }
+            }
+        }
+        __syncthreads();
         uint32_t ncur = sh_cnt[sel];
         tick(1);
-        if (ncur == 0) {
-            if (sh_min == 0x7FFFFFFF) { state = 2; break; }
-            L = sh_min;                            // jump to the next populated level
-            __syncthreads();
-            continue;
-        }
         ++levels; max_level = L;
-        // mark the scanned frontier
-        for (uint32_t i = tid; i < ncur; i += 1024) {
-            const uint32_t code = q_get(sel, i);
-            const uint32_t r = tail_rank(t, code >> 16, code & 0xFFFFu);
-            tail_to_frontier(t, r);
-            T.truss_by_rank[r] = L + 2;
-        }
-        if (tid == 0) sh_cnt[sel ^ 1] = 0u;
-        __syncthreads();
-        tick(2);
         while (ncur > 0) {
             // ---- destroy the triangles of the frontier edges.  Extraction: a 16-lane group per edge, a matrix
             // word per lane, one common live neighbour x per lane per trip -- cheap, but the lanes' bit counts

@@ -156,3 +156,24 @@ def test_v1_split_known_answer_and_small_input(built, tmp_path):
     (tmp_path / "CoreA_anomaly.txt").write_text("0\t0.100000\n1\t0.200000\n2\t0.300000\n")
     r = run(args, env={"KOMB_V1_ONLY": "1"})
     assert r.returncode == 0 and "split skipped" in r.stderr
+
+
+@pytest.mark.parametrize("threads", [1, 4, 7])
+def test_sam_port_agrees(fixture, tmp_path, threads):
+    """oracle/sam_port (the reference's pipeline restated with its own hash containers, used as the CPU
+    baseline of the host pipeline at scale) gives the graph of the Python restatement and of komb2."""
+    port = os.path.join(ROOT, "oracle", "sam_port")
+    d, s1, s2 = fixture
+    r = subprocess.run([port, str(threads), str(d / "r1.sam"), str(d / "r2.sam"), str(tmp_path / "pairs.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    names, edges = set(), set()
+    for ln in open(tmp_path / "pairs.txt"):
+        a, b = ln.rstrip("\n").split("\t")
+        names.update((a, b))
+        if a != b:
+            edges.add(frozenset((a, b)))
+    want_names, want_edges = samgraph.build_graph(s1, s2, threads, False)
+    assert edges == want_edges
+    assert names <= want_names               # the pair list does not show vertices whose cliques are singletons
+    assert f"vertices {len(want_names)} " in r.stdout
