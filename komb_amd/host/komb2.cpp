@@ -229,6 +229,7 @@ struct ThreadParse {
     std::vector<Rec> recs;
     std::unordered_map<View, int32_t, ViewHash> local;     // unitig name -> local id
     std::vector<View> local_names;
+    std::vector<uint64_t> local_hash;                      // ViewHash of local_names[i]
     std::vector<uint64_t> first_pos;                       // (file << 48 | byte offset) of the first line naming it
 };
 
@@ -273,6 +274,7 @@ void parse_sam(const Mapped &m, int file_idx, int threads, bool strict, std::vec
                 lid = (int32_t)me.local_names.size();
                 me.local.emplace(nm, lid);
                 me.local_names.push_back(nm);
+                me.local_hash.push_back((uint64_t)ViewHash{}(nm));
                 me.first_pos.push_back(((uint64_t)file_idx << 48) | (uint64_t)b);
             } else lid = it->second;
             me.recs.push_back(Rec{(uint64_t)ViewHash{}(key), key, lid});
@@ -291,25 +293,41 @@ std::vector<int64_t> build_edges(const std::string &path1, const std::string &pa
     std::vector<ThreadParse> tp1((size_t)threads), tp2((size_t)threads);
     parse_sam(m1, 0, threads, strict, tp1);
     parse_sam(m2, 1, threads, strict, tp2);
-    // global vid = order of first appearance (file 1 before file 2, then byte offset): independent of T in strict mode
-    std::unordered_map<View, uint64_t, ViewHash> first;
-    for (auto *tp : {&tp1, &tp2})
-        for (auto &th : *tp)
-            for (size_t i = 0; i < th.local_names.size(); ++i) {
-                auto ins = first.emplace(th.local_names[i], th.first_pos[i]);
-                if (!ins.second && th.first_pos[i] < ins.first->second) ins.first->second = th.first_pos[i];
+    // global vid = order of first appearance (file 1 before file 2, then byte offset): independent of T in strict mode.
+    // Every thread has met most of the unitigs, so the per-thread dictionaries hold T x |V| names in total;
+    // merging them serially was the largest single cost of the pipeline.  The names are partitioned by hash
+    // instead: bucket b takes the names with hash % B == b from every dictionary, all buckets in parallel.
+    std::vector<ThreadParse *> all;
+    for (auto *tp : {&tp1, &tp2}) for (auto &th : *tp) all.push_back(&th);
+    const size_t B = (size_t)threads * 4;
+    std::vector<std::unordered_map<View, uint64_t, ViewHash>> bucket(B);      // name -> first position, later -> vid
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (size_t b = 0; b < B; ++b) {
+        auto &m = bucket[b];
+        for (ThreadParse *th : all)
+            for (size_t i = 0; i < th->local_names.size(); ++i) {
+                if (th->local_hash[i] % B != b) continue;
+                auto ins = m.emplace(th->local_names[i], th->first_pos[i]);
+                if (!ins.second && th->first_pos[i] < ins.first->second) ins.first->second = th->first_pos[i];
             }
-    std::vector<std::pair<uint64_t, View>> order;
-    order.reserve(first.size());
-    for (auto &kv : first) order.emplace_back(kv.second, kv.first);
-    std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-    std::unordered_map<View, int32_t, ViewHash> vid_of;
-    vid_of.reserve(order.size() * 2);
+    }
+    std::vector<size_t> boff(B + 1, 0);
+    for (size_t b = 0; b < B; ++b) boff[b + 1] = boff[b] + bucket[b].size();
+    std::vector<std::pair<uint64_t, View>> order(boff[B]);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (size_t b = 0; b < B; ++b) {
+        size_t k = boff[b];
+        for (auto &kv : bucket[b]) order[k++] = std::make_pair(kv.second, kv.first);
+    }
+    __gnu_parallel::sort(order.begin(), order.end(), [](const auto &x, const auto &y) { return x.first < y.first; },
+                         __gnu_parallel::default_parallel_tag((unsigned)threads));
     names.name.clear();
-    names.name.reserve(order.size());
+    names.name.resize(order.size());
+#pragma omp parallel for num_threads(threads) schedule(static)
     for (size_t i = 0; i < order.size(); ++i) {
-        vid_of.emplace(order[i].second, (int32_t)i);
-        names.name.emplace_back(order[i].second.p, order[i].second.n);
+        const View &nm = order[i].second;
+        bucket[(size_t)ViewHash{}(nm) % B].find(nm)->second = (uint64_t)i;      // no insertion: elements are written in place
+        names.name[i].assign(nm.p, nm.n);
     }
     // gather all records, local id -> global vid
     size_t total = 0;
@@ -317,13 +335,11 @@ std::vector<int64_t> build_edges(const std::string &path1, const std::string &pa
     for (auto *tp : {&tp1, &tp2}) for (auto &th : *tp) { offs.push_back(total); total += th.recs.size(); }
     std::vector<Rec> recs(total);
     {
-        std::vector<ThreadParse *> all;
-        for (auto *tp : {&tp1, &tp2}) for (auto &th : *tp) all.push_back(&th);
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
         for (size_t k = 0; k < all.size(); ++k) {
             ThreadParse &th = *all[k];
             std::vector<int32_t> remap(th.local_names.size());
-            for (size_t i = 0; i < remap.size(); ++i) remap[i] = vid_of.find(th.local_names[i])->second;
+            for (size_t i = 0; i < remap.size(); ++i) remap[i] = (int32_t)bucket[th.local_hash[i] % B].find(th.local_names[i])->second;
             for (size_t i = 0; i < th.recs.size(); ++i) { Rec r = th.recs[i]; r.vid = remap[(size_t)r.vid]; recs[offs[k] + i] = r; }
             std::vector<Rec>().swap(th.recs);
         }
@@ -618,9 +634,11 @@ int main(int argc, const char **argv)
         const std::string path = args.outdir + "/edgelist.txt";
         FILE *f = fopen(path.c_str(), "w");
         if (!f) file_not_found(path);
-        std::vector<char> buf(1 << 20);
-        setvbuf(f, buf.data(), _IOFBF, buf.size());
-        for (size_t i = 0; i + 1 < edges.size(); i += 2) fprintf(f, "%ld\t%ld\n", (long)edges[i], (long)edges[i + 1]);
+        write_rows(f, (int64_t)(edges.size() / 2), args.threads, [&](int64_t i, std::string &buf) {
+            char tmp[48];
+            const int len = snprintf(tmp, sizeof(tmp), "%ld\t%ld\n", (long)edges[2 * (size_t)i], (long)edges[2 * (size_t)i + 1]);   // src/graph.cpp:425
+            buf.append(tmp, (size_t)len);
+        });
         fclose(f);
     }
     if (env_on("KOMB_STOP_AFTER_EDGES")) {
