@@ -15,7 +15,12 @@ namespace komb {
 
 constexpr int kBlock = 256;                 // 4 wave64 per workgroup
 constexpr int kWave = 64;
-constexpr int32_t kAlive = 0x7FFFFFFF;      // stamp / core value of a live edge / vertex
+// stamp / core value of a live edge / vertex: kAlive - c, where c = 0 for a unit with a short slice
+// ("light") and c = its number of kChunk-item chunks otherwise.  Whoever reads the marker to test
+// liveness (the SCAN sweep, the item that decrements the unit) learns the unit's class for free,
+// instead of fetching its slice bounds.
+constexpr int32_t kAlive = 0x7FFFFFFF;
+constexpr int32_t kAliveMin = 0x40000000;   // every alive marker is >= this; every round / level number is below it
 
 // Device-side control block of a peel loop.  One 128-byte record; the fields a
 // launch reads at entry are written only by the previous launch's last block.

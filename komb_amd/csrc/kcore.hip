@@ -6,7 +6,7 @@
 // slice = the vertex's CSR row.  Peeling v at level k walks its row (coalesced
 // col reads) and atomically decrements every live neighbour; the decrement
 // that lands a neighbour exactly on k triggers it.  core[] doubles as the
-// liveness flag (kAlive until peeled).  Hub rows are split into 256-slot
+// liveness flag (an alive marker, common.h, until peeled).  Hub rows are split into 256-slot
 // chunks across wavefronts; low-degree frontier vertices are packed 64 to a
 // wavefront with their rows flattened over the lanes.
 // Coreness is a unique integer per vertex, so peeling order inside a level
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(kBlock) void k_core_init(const uint32_t *__restrict
         const int32_t d = (int32_t)(rowptr[v + 1] - rowptr[v]);
         deg[v] = d; degw[v] = d;
         if (d == 0) { core[v] = 0; ++zeros; }
-        else { core[v] = kAlive; lmin = min(lmin, d); }
+        else { core[v] = alive_marker((uint32_t)d); lmin = min(lmin, d); }
     }
     zeros = wave_sum(zeros);
     lmin = wave_min(lmin);
@@ -47,12 +47,12 @@ struct CoreProblem {
     int32_t *degw;
     int32_t *core;
 
-    __device__ __forceinline__ bool scan_probe(uint32_t v, int32_t &key, uint32_t &len) const
+    __device__ __forceinline__ bool scan_probe(uint32_t v, int32_t &key, uint32_t &nch) const
     {
         const int32_t c = core[v];
         key = degw[v];
-        len = rowptr[v + 1] - rowptr[v];
-        return c == kAlive;
+        nch = marker_chunks(c);
+        return marker_alive(c);
     }
     __device__ __forceinline__ void mark_scanned(uint32_t v, const CtrlView &cv) const { core[v] = cv.level; }
     __device__ __forceinline__ void slice(uint32_t v, uint32_t &b, uint32_t &len) const
@@ -68,10 +68,10 @@ struct CoreProblem {
         ld.c = core[ld.u];
         return ld;
     }
-    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &) const
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &, uint32_t &c0, uint32_t &) const
     {
-        if (ld.c == kAlive) {                           // a stale "alive" only costs a no-op decrement
-            if (atomicSub(&degw[ld.u], 1) == cv.level + 1) { core[ld.u] = cv.level; t0 = ld.u; }
+        if (marker_alive(ld.c)) {                       // a stale "alive" only costs a no-op decrement
+            if (atomicSub(&degw[ld.u], 1) == cv.level + 1) { core[ld.u] = cv.level; t0 = ld.u; c0 = marker_chunks(ld.c); }
         }
     }
 };

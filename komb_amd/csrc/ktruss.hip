@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t 
         const int32_t s0 = (int32_t)(off[e + 1] - off[e]);
         sup[e] = s0;
         if (s0 == 0) { stamp[e] = 0; truss[e] = 2; ++zeros; }       // round 0: gone before the first sub-round
-        else { stamp[e] = kAlive; lmin = min(lmin, s0); }
+        else { stamp[e] = alive_marker((uint32_t)s0); lmin = min(lmin, s0); }
     }
     zeros = wave_sum(zeros);
     lmin = wave_min(lmin);
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t 
 // ------------------------------------------------------------------ the peel
 // peel_dev.h's engine with: unit = edge, key = live support, slice = the
 // edge's incidence slice (pairs of the other two edges of each triangle).
-// stamp[e] = kAlive while e is live, else the sub-round in which e is (to be)
+// stamp[e] = an alive marker (common.h) while e is live, else the sub-round in which e is (to be)
 // peeled.  For a frontier edge `me` (stamp == round r) and a triangle {me,x,y}:
 //   - x or y peeled in an earlier sub-round (stamp < r): the triangle is gone.
 //   - otherwise the triangle is destroyed now; each of x,y that is not itself
@@ -566,12 +566,12 @@ struct TrussProblem {
     int32_t *stamp;
     int32_t *truss;
 
-    __device__ __forceinline__ bool scan_probe(uint32_t e, int32_t &key, uint32_t &len) const
+    __device__ __forceinline__ bool scan_probe(uint32_t e, int32_t &key, uint32_t &nch) const
     {
         const int32_t st = stamp[e];
         key = sup[e];
-        len = off[e + 1] - off[e];
-        return st == kAlive;
+        nch = marker_chunks(st);
+        return marker_alive(st);
     }
     __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const
     {
@@ -592,15 +592,15 @@ struct TrussProblem {
         ld.sx = stamp[p.x]; ld.sy = stamp[p.y];
         return ld;
     }
-    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &t1) const
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &t1, uint32_t &c0, uint32_t &c1) const
     {
         const int32_t r = cv.round, L = cv.level;
         if (ld.sx < r || ld.sy < r) return;             // an edge of the triangle is already gone
         const bool xin = (ld.sx == r), yin = (ld.sy == r);
         const bool decx = !xin && (!yin || ld.me < ld.y);
         const bool decy = !yin && (!xin || ld.me < ld.x);
-        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; truss[ld.x] = L + 2; t0 = ld.x; }
-        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; truss[ld.y] = L + 2; t1 = ld.y; }
+        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; truss[ld.x] = L + 2; t0 = ld.x; c0 = marker_chunks(ld.sx); }
+        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; truss[ld.y] = L + 2; t1 = ld.y; c1 = marker_chunks(ld.sy); }
     }
 };
 
@@ -937,7 +937,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&T.spill[1], (size_t)tail_limit));
         T.max_edges = tail_limit;
     }
-    // the live edges are those of `list` (or all m when list is null) whose stamp is still kAlive
+    // the live edges are those of `list` (or all m when list is null) whose stamp is still an alive marker
     auto run_tail = [&](const int32_t *list, uint32_t n_in) -> int {
         KOMB_HIP(ctx, hipMemsetAsync(T.vmap, 0, (size_t)nv * sizeof(int32_t), s));
         KOMB_HIP(ctx, hipMemsetAsync(T.cnt, 0, 8 * sizeof(uint32_t), s));

@@ -56,6 +56,13 @@ struct CtrlView {                              // launch-stable part of the cont
     uint32_t tail_limit;
 };
 
+__device__ __forceinline__ int32_t alive_marker(uint32_t len)
+{
+    return kAlive - (int32_t)(len <= (uint32_t)kLight ? 0u : (len + kChunk - 1) / kChunk);
+}
+__device__ __forceinline__ bool marker_alive(int32_t m) { return m >= kAliveMin; }
+__device__ __forceinline__ uint32_t marker_chunks(int32_t m) { return (uint32_t)(kAlive - m); }   // 0 = light
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
@@ -83,7 +90,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
-enum : uint8_t { SC_NONE = 0, SC_LIGHT = 1, SC_HEAVY = 2, SC_EMPTY = 3, SC_SURVIVOR = 4 };   // SCAN pass A -> pass B
+enum : uint8_t { SC_NONE = 0, SC_LIGHT = 1, SC_HEAVY = 2, SC_SURVIVOR = 4 };   // SCAN pass A -> pass B
 
 struct PeelQueues {
     uint8_t *code;           // one classification byte per SCAN input position
@@ -254,12 +261,14 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 // Problem concept (all __device__):
 //   static constexpr bool kChain;        triggered light units may be peeled in the same launch
 //   uint32_t units;
-//   bool scan_probe(u, int32_t &key, uint32_t &len)   liveness, live key and slice length of unit u,
-//                                        all loaded unconditionally (independent loads)
+//   bool scan_probe(u, int32_t &key, uint32_t &nch)   liveness, live key and class of unit u (nch = 0: light,
+//                                        else its chunk count), from two independent loads: the alive
+//                                        marker carries the class (common.h)
 //   void mark_scanned(u, cv)             unit enters the frontier through SCAN
 //   void slice(u, uint32_t &begin, uint32_t &len)
 //   Loaded item_load(unit, pos, cv)      the item's loads (no side effects)
-//   void item_apply(ld, cv, int32_t &t0, int32_t &t1)    decrements; ids of triggered units or -1
+//   void item_apply(ld, cv, int32_t &t0, int32_t &t1, uint32_t &c0, uint32_t &c1)
+//                                        decrements; ids of triggered units or -1, and their classes
 // (load and apply are split so that the loads of several items are in flight together)
 template <class P>
 __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p)
@@ -323,11 +332,11 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
                     // liveness, key and slice length are loaded unconditionally: independent loads (and, in
                     // the dense sweep, sequential ones) instead of a chain of three dependent round trips
                     int32_t key;
-                    uint32_t len;
-                    const bool live = p.scan_probe(u, key, len);
+                    uint32_t nch;
+                    const bool live = p.scan_probe(u, key, nch);
                     if (live && key <= L) {
-                        if (len <= (uint32_t)kLight) code[k] = len > 0 ? SC_LIGHT : SC_EMPTY;
-                        else { n_chunks += (len + kChunk - 1) / kChunk; code[k] = SC_HEAVY; }
+                        if (nch == 0) code[k] = SC_LIGHT;
+                        else { n_chunks += nch; code[k] = SC_HEAVY; }
                     } else if (live) { lmin = min(lmin, key); code[k] = SC_SURVIVOR; }
                 }
             }
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             for (int k = 0; k < kScanU; ++k) {
                 const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
                 if (idx < n_in) Q.code[idx] = code[k];      // pass B reads this byte instead of the unit's state
-                const bool hit = code[k] == SC_LIGHT || code[k] == SC_HEAVY || code[k] == SC_EMPTY;
+                const bool hit = code[k] == SC_LIGHT || code[k] == SC_HEAVY;
                 n_light += (uint32_t)__popcll(__ballot(code[k] == SC_LIGHT));
                 n_hits += (uint32_t)__popcll(__ballot(hit));
                 if (emit) n_surv += (uint32_t)__popcll(__ballot(code[k] == SC_SURVIVOR));
@@ -399,17 +408,15 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         const uint64_t gw = (uint64_t)blockIdx.x * kPeelWaves + (uint64_t)w;
         const uint64_t nw = (uint64_t)nblk * kPeelWaves;
 
-        auto push_trigger = [&](int32_t t) {
+        auto push_trigger = [&](int32_t t, uint32_t nch) {
             const bool trig = t >= 0;
             const uint64_t m = __ballot(trig);
             if (m == 0) return;
             n_trig += (uint32_t)__popcll(m);
-            uint32_t b = 0, len = 0;
-            if (trig) p.slice((uint32_t)t, b, len);
-            const bool is_light = trig && len <= (uint32_t)kLight;
-            const bool is_heavy = trig && len > (uint32_t)kLight;
+            const bool is_light = trig && nch == 0;
+            const bool is_heavy = trig && nch != 0;
             stage_push(st, is_light, t, qn_l, tail_nl);
-            if (__ballot(is_heavy)) heavy_push(is_heavy, t, (len + kChunk - 1) / kChunk, qn_h, tail_nh);
+            if (__ballot(is_heavy)) heavy_push(is_heavy, t, nch, qn_h, tail_nh);
         };
         // kItemU items per lane per trip: all loads first, then the decrements
         auto run_items = [&](const bool (&active)[kItemU], const int32_t (&unit)[kItemU], const uint32_t (&pos)[kItemU]) {
@@ -418,13 +425,15 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             for (int k = 0; k < kItemU; ++k)
                 if (active[k]) ld[k] = p.item_load(unit[k], pos[k], cv);
             int32_t trg[2 * kItemU];
+            uint32_t tch[2 * kItemU];
 #pragma unroll
             for (int k = 0; k < kItemU; ++k) {
                 trg[2 * k] = -1; trg[2 * k + 1] = -1;
-                if (active[k]) p.item_apply(ld[k], cv, trg[2 * k], trg[2 * k + 1]);
+                tch[2 * k] = 0; tch[2 * k + 1] = 0;
+                if (active[k]) p.item_apply(ld[k], cv, trg[2 * k], trg[2 * k + 1], tch[2 * k], tch[2 * k + 1]);
             }
 #pragma unroll
-            for (int k = 0; k < 2 * kItemU; ++k) push_trigger(trg[k]);
+            for (int k = 0; k < 2 * kItemU; ++k) push_trigger(trg[k], tch[k]);
         };
 
         // light units: bsz per wave, slices flattened over the lanes

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_mark(const int32_t *__restrict_
     uint32_t live = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_in; i += gridDim.x * kBlock) {
         const int32_t e = list ? list[i] : (int32_t)i;
-        if (stamp[e] != kAlive) continue;
+        if (!marker_alive(stamp[e])) continue;
         ++live;
         const int32_t ab[2] = {osrc[e], ocol[e]};
         for (int k = 0; k < 2; ++k)
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rows(const int32_t *__restrict_
         int32_t e = -1;
         int32_t st = 0;
         if (i < n_in) { e = list ? list[i] : (int32_t)i; st = stamp[e]; }
-        const bool live = e >= 0 && st == kAlive;
+        const bool live = e >= 0 && marker_alive(st);
         const uint64_t m = __ballot(live);
         uint32_t base = 0;
         if (lane_id() == 0 && m) base = atomicAdd(&T.cnt[3], (uint32_t)__popcll(m));
