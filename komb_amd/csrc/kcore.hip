@@ -76,17 +76,17 @@ struct CoreProblem {
     }
 };
 
-// grp_done[kMaxGroups] = #units peeled by the init kernel, grp_done[kMaxGroups+1] = min live key
+// grp_done[kInitOff] = #units peeled by the init kernel, grp_done[kInitOff+1] = min live key
 __global__ void k_ctrl_pre(uint32_t *grp_done)
 {
-    if (threadIdx.x < kMaxGroups) grp_done[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) { grp_done[kMaxGroups] = 0u; grp_done[kMaxGroups + 1] = 0x7FFFFFFFu; }
+    for (int i = threadIdx.x; i < kInitOff; i += blockDim.x) grp_done[i] = 0u;
+    if (threadIdx.x == 0) { grp_done[kInitOff] = 0u; grp_done[kInitOff + 1] = 0x7FFFFFFFu; }
 }
 __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t units, uint32_t tail_limit)
 {
     if (threadIdx.x == 0) {
-        const uint32_t peeled = grp_done[kMaxGroups];
-        const int32_t first = (int32_t)grp_done[kMaxGroups + 1];
+        const uint32_t peeled = grp_done[kInitOff];
+        const int32_t first = (int32_t)grp_done[kInitOff + 1];
         PeelCtrl c{};
         c.mode = MODE_SCAN; c.round = 1;
         c.remaining = units - peeled;
@@ -143,7 +143,7 @@ int core_run(komb_ctx *ctx)
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.live[i], ((size_t)nv / 4 + 64) * sizeof(int32_t));
     if (e == hipSuccess) e = ctx->pool.get((void **)&Q.code, (size_t)nv);
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_ctrl, sizeof(PeelCtrl));
-    if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, (kMaxGroups + 2) * sizeof(uint32_t));
+    if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, (kInitOff + 2) * sizeof(uint32_t));
     if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
 
     int64_t g = (nv + kBlock - 1) / kBlock;
@@ -152,7 +152,7 @@ int core_run(komb_ctx *ctx)
     CoreProblem P{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, d_degw, ctx->d_core};
     ctx->timer.start(s);
     peel_ctrl_pre(s, d_grp);
-    k_core_init<<<grid_init, kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_deg, d_degw, ctx->d_core, d_grp + kMaxGroups);
+    k_core_init<<<grid_init, kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_deg, d_degw, ctx->d_core, d_grp + kInitOff);
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)nv);
     int launches = 0;
     int st = drive_peel(ctx, d_ctrl, nv, [&]() {

@@ -915,7 +915,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));
-    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kMaxGroups + 2));
+    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
     // hand-over threshold of the LDS tail (truss_tail.h); KOMB_TAIL=0 keeps the whole peel in the general engine
     uint32_t tail_limit = kTailEdges;
@@ -973,7 +973,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     };
     ctx->timer.start(s);
     peel_ctrl_pre(s, d_grp);
-    k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kMaxGroups);
+    k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff);
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
     const int gp = peel_grid(m);
     int launches = 0, rc = KOMB_OK;

@@ -47,6 +47,7 @@ constexpr int kChainBudget = 16;               // batches a wave may peel from i
 constexpr int kStage = 192;                    // per-wave LDS staging of triggered light units
 constexpr int kGroup = 32;                     // workgroups per first-level arrival counter
 constexpr int kMaxGroups = 64;                 // grid <= kGroup * kMaxGroups
+constexpr int kInitOff = 2 * (kMaxGroups + 1);  // the ticket buffer: kMaxGroups + 1 64-bit tickets, then the init kernel's two words
 
 struct CtrlView {                              // launch-stable part of the control block
     int32_t mode, level, round, done, cur_sel;
@@ -205,7 +206,7 @@ __device__ __forceinline__ uint32_t plan_step(const CtrlView &cv, uint32_t grid,
 // participating workgroup has arrived; the independent atomics are issued from different lanes
 // so they cost one round trip, not seven.  The new state is also left in *out (LDS) so that a
 // single workgroup can go on to the next step without re-reading global memory.
-__device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out)
+__device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out, uint32_t acc)
 {
     const int lane = lane_id();
     const bool scan = cv.mode == MODE_SCAN;
@@ -213,15 +214,13 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
     const bool emitted = scan && (cv.live_mode != 0 || cv.remaining <= units / 4);
     const int next_q = scan ? sel : (sel ^ 1);
     uint32_t v = 0;
-    if (lane == 0) v = atomicExch(&ctrl->acc, 0u);
-    else if (lane == 1) v = coherent_load(&ctrl->tail_l[next_q]);
+    if (lane == 1) v = coherent_load(&ctrl->tail_l[next_q]);
     else if (lane == 2) v = coherent_load(&ctrl->tail_h[next_q]);
     else if (lane == 3) v = (uint32_t)atomicExch(&ctrl->next_min, 0x7FFFFFFF);
     else if (lane == 4) v = emitted ? atomicExch(&ctrl->live_tail, 0u) : 0u;
     else if (lane == 5) { if (!scan) atomicExch(&ctrl->tail_l[sel], 0u); }
     else if (lane == 6) { if (!scan) atomicExch(&ctrl->tail_h[sel], 0u); }
     else if (lane == 7) atomicAdd(scan ? &ctrl->n_scans : &ctrl->n_rounds, 1);
-    const uint32_t acc = (uint32_t)__shfl((int)v, 0);
     const uint32_t cur_l = (uint32_t)__shfl((int)v, 1), cur_h = (uint32_t)__shfl((int)v, 2);
     const int32_t nmin = __shfl((int)v, 3);
     const uint32_t live_n = (uint32_t)__shfl((int)v, 4);
@@ -276,6 +275,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
     __shared__ CtrlView sh_cv;
     __shared__ uint32_t sh_w[kPeelWaves][4];           // per-wave counts / bases
     __shared__ uint32_t sh_base[3];
+    __shared__ uint32_t sh_acc;                        // units this workgroup moved into a frontier in this step
     __shared__ int32_t sh_min[kPeelWaves];
     __shared__ uint32_t sh_end[kPeelWaves][kWave];
     __shared__ uint32_t sh_beg[kPeelWaves][kWave];
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             sh_base[0] = tl ? atomicAdd(&ctrl->tail_l[sel], tl) : 0u;
             sh_base[1] = th ? atomicAdd(&ctrl->tail_h[sel], th) : 0u;
             sh_base[2] = ts ? atomicAdd(&ctrl->live_tail, ts) : 0u;
-            if (hits) atomicAdd(&ctrl->acc, hits);
+            sh_acc = hits;
             if (bmin != 0x7FFFFFFF) atomicMin(&ctrl->next_min, bmin);
         }
         __syncthreads();
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         if (threadIdx.x == 0) {
             uint32_t t = 0;
             for (int i = 0; i < kPeelWaves; ++i) t += sh_w[i][3];
-            if (t) atomicAdd(&ctrl->acc, t);
+            sh_acc = t;
         }
     }
 
@@ -533,26 +533,38 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         // themselves are ordered by their data dependence.
         if (threadIdx.x >= kWave) return;
         int last = 0;
+        uint32_t total = 0;
         if (lane == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // a ticket is 64 bits: arrivals in the high word, the arrivals' frontier counts summed in the low
+            // word -- the step's total reaches the finaliser with the arrival itself, not through one more
+            // atomic that every workgroup would have to wait out first
+            unsigned long long *tick = reinterpret_cast<unsigned long long *>(grp_done);
             const uint32_t grp = blockIdx.x / kGroup;
             const uint32_t ngrp = (nblk + kGroup - 1) / kGroup;
             const uint32_t grp_size = (grp == ngrp - 1) ? (nblk - grp * kGroup) : (uint32_t)kGroup;
-            if (atomicAdd(&grp_done[grp], 1u) == grp_size - 1) {
-                atomicExch(&grp_done[grp], 0u);
-                if (ngrp == 1) last = 1;                    // a single group: its last arrival is the last arrival
-                else if (atomicAdd(&ctrl->blocks_done, 1u) == ngrp - 1) {
-                    atomicExch(&ctrl->blocks_done, 0u);
-                    last = 1;
+            const uint32_t mine = sh_acc;
+            const unsigned long long old = atomicAdd(&tick[grp], (1ull << 32) | mine);
+            if ((uint32_t)(old >> 32) == grp_size - 1) {
+                atomicExch(&tick[grp], 0ull);
+                const uint32_t grp_acc = (uint32_t)old + mine;
+                if (ngrp == 1) { last = 1; total = grp_acc; }      // a single group: its last arrival is the last arrival
+                else {
+                    const unsigned long long old2 = atomicAdd(&tick[kMaxGroups], (1ull << 32) | grp_acc);
+                    if ((uint32_t)(old2 >> 32) == ngrp - 1) {
+                        atomicExch(&tick[kMaxGroups], 0ull);
+                        last = 1; total = (uint32_t)old2 + grp_acc;
+                    }
                 }
             }
         }
         last = __shfl(last, 0);
-        if (last) finalize_step(ctrl, cv, p.units, &sh_cv);
+        total = (uint32_t)__shfl((int)total, 0);
+        if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total);
         return;
     }
     // one workgroup did the whole step: finalise locally, chain the next step if it is small too
-    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv);
+    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc);
     __syncthreads();
     cv = sh_cv;
     if (cv.done || chained >= kMaxInKernelSteps) return;
