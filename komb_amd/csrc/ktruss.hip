@@ -128,6 +128,20 @@ __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restric
     }
 }
 
+// kept slots before every 64-slot word of the keep bitmask (chunk bases + the words of the chunk before it):
+// output position of a kept slot j = word_rank[j >> 6] + popcount(bits[j >> 6] below j)
+__global__ __launch_bounds__(kBlock) void k_word_rank(const unsigned long long *__restrict__ bits, const uint32_t *__restrict__ chunk_base,
+                                                      int64_t nwords, uint32_t *__restrict__ word_rank)
+{
+    constexpr int kWordsPerChunk = kChunkSlots / 64;
+    const int64_t nchunks = (nwords + kWordsPerChunk - 1) / kWordsPerChunk;
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kBlock) {
+        uint32_t r = chunk_base[c];
+        const int64_t w1 = min(nwords, (c + 1) * kWordsPerChunk);
+        for (int64_t w = c * kWordsPerChunk; w < w1; ++w) { word_rank[w] = r; r += (uint32_t)__popcll(bits[w]); }
+    }
+}
+
 // row pointers of a CSR from the ascending src[] of its slots (gaps = empty rows)
 __global__ __launch_bounds__(kBlock) void k_rowptr_from_src(const int32_t *__restrict__ src, int64_t ns, int64_t nv,
                                                             uint32_t *__restrict__ rowptr)
@@ -620,6 +634,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_results(const int32_t *__restri
 __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
                                                              const int32_t *__restrict__ col, int64_t ns,
                                                              const unsigned long long *__restrict__ obits,
+                                                             const uint32_t *__restrict__ wrank,
                                                              const uint32_t *__restrict__ ebase,
                                                              const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                              const int2 *__restrict__ res,
@@ -632,12 +647,19 @@ __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__r
         const uint32_t eb = ebase[u];
         const uint32_t first_upper = rowptr[u + 1] - (ebase[u + 1] - eb);
         const uint32_t o = eb + ((uint32_t)j - first_upper);
-        const bool u_first = (obits[j >> 6] >> (j & 63)) & 1ull;       // slot (u,v) is the oriented copy: u precedes v
-        const int32_t a = u_first ? u : v, t = u_first ? v : u;
-        uint32_t lo = orow[a], hi = orow[a + 1];
-        while (lo < hi) {                                       // t is present by construction
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (ocol[mid] < t) lo = mid + 1; else hi = mid;
+        const unsigned long long word = obits[j >> 6];
+        const bool u_first = (word >> (j & 63)) & 1ull;                // slot (u,v) is the oriented copy: u precedes v
+        uint32_t lo;
+        if (u_first) {
+            // the oriented slot is this slot's own position in the compaction: no search, no gather
+            lo = wrank[j >> 6] + (uint32_t)__popcll(word & ((1ull << (j & 63)) - 1ull));
+        } else {
+            lo = orow[v];
+            uint32_t hi = orow[v + 1];
+            while (lo < hi) {                                   // u is present in v's oriented row by construction
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (ocol[mid] < u) lo = mid + 1; else hi = mid;
+            }
         }
         const int2 r = res[lo];
         eu[o] = u; ev[o] = v;
@@ -714,7 +736,7 @@ void truss_free(komb_ctx *ctx)
 template <class Pred>
 static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const int32_t *col, int64_t ns, int64_t nv, Pred pred,
                          uint32_t *out_rowptr, int32_t **out_col, int32_t **out_src, int64_t *n_out,
-                         unsigned long long **keep_bits_out = nullptr)
+                         unsigned long long **keep_bits_out = nullptr, uint32_t **word_rank_out = nullptr)
 {
     hipStream_t s = ctx->stream;
     const int64_t nchunks = (ns + kChunkSlots - 1) / kChunkSlots;
@@ -734,6 +756,11 @@ static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const
     k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits);
     if ((int64_t)kept * 4 < nv) k_rowptr_search<<<grid_for(nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
     else k_rowptr_from_src<<<grid_for(kept), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
+    if (word_rank_out) {
+        const int64_t nwords = (ns + 63) / 64;
+        KOMB_HIP(ctx, bufs.alloc(word_rank_out, (size_t)nwords + 1));
+        k_word_rank<<<grid_for((nwords + kChunkSlots / 64 - 1) / (kChunkSlots / 64)), kBlock, 0, s>>>(d_bits, d_cb, nwords, *word_rank_out);
+    }
     bufs.release(d_cc); bufs.release(d_cb);
     if (keep_bits_out) *keep_bits_out = d_bits; else bufs.release(d_bits);
     *n_out = (int64_t)kept;
@@ -794,7 +821,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     int32_t *d_ocol = nullptr, *d_osrc = nullptr;
     int64_t m = 0;
     unsigned long long *d_obits = nullptr;                           // bit j: working slot j is the oriented copy of its edge
-    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg}, d_orow, &d_ocol, &d_osrc, &m, &d_obits));
+    uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
+    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank));
     st.ms_orient = ctx->timer.stop(s);
 
     // ---- triangle support + incidence index
@@ -1024,7 +1052,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     int2 *d_res = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
     k_pack_results<<<grid_for(m), kBlock, 0, s>>>(d_truss, d_off, m, d_res);
-    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_ebase, d_orow, d_ocol, d_res,
+    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol, d_res,
                                                         ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
     ctx->t_ne = m;
