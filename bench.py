@@ -51,7 +51,7 @@ def measured_traffic(config, kernel):
     if not files:
         return None, None, None
     data = json.load(open(files[-1]))
-    name = {"k_truss_step": "k_peel_step<Truss>"}.get(kernel, kernel)
+    name = kernel
     rec = data.get(name)
     if not rec:
         return None, None, os.path.basename(files[-1])
@@ -146,7 +146,7 @@ def main():
         step()
     barrier_sync()
     t0 = time.perf_counter()
-    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_compact", "ms_peel", "ms_gather")}
+    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_compact", "ms_peel", "ms_tail", "ms_gather")}
     for _ in range(args.steps):
         step()
         s = acc.stats()
@@ -185,7 +185,11 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(st)
-        kernels = {"k_truss_step": (phase["ms_peel"], st["truss_subrounds"] + st["truss_scans"], ab["peel"])}
+        # the peel = the launches of k_peel_step<Truss> (all of them, including the no-op launches of the last blind
+        # batch, as rocprofv3 counts them) + the single-workgroup LDS tail (setup kernels + k_truss_tail)
+        kernels = {"k_peel_step<Truss>": (phase["ms_peel"] - phase["ms_tail"], st["truss_launches"], ab["peel"])}
+        if st["truss_tail_runs"]:
+            kernels["k_truss_tail"] = (phase["ms_tail"], st["truss_tail_runs"], 0)
         if phase["ms_tri_count"] > 0:            # exact two-pass layout (sharded runs, or bounded index too large)
             kernels["k_triangles<count>"] = (phase["ms_tri_count"], 1, ab["tri_count"])
             kernels["k_triangles<single> (exact slices)"] = (phase["ms_tri_fill"], 1, ab["tri_fill"])

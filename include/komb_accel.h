@@ -68,6 +68,7 @@ typedef struct komb_stats {
     double  ms_peel;                /* truss: all peel launches (SCAN + PROCESS)      */
     double  ms_gather;              /* truss: canonical-order result gather           */
     double  ms_corea;               /* a9/a10: CoreA rank kernels                     */
+    double  ms_tail;                /* truss: setup + LDS tail kernel, part of ms_peel */
 } komb_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

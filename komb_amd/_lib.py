@@ -34,7 +34,7 @@ class KombStats(ctypes.Structure):
         ("ms_tri_count", ctypes.c_double), ("ms_tri_fill", ctypes.c_double), ("ms_compact", ctypes.c_double),
         ("ms_support", ctypes.c_double),
         ("ms_allreduce", ctypes.c_double),
-        ("ms_peel", ctypes.c_double), ("ms_gather", ctypes.c_double), ("ms_corea", ctypes.c_double),
+        ("ms_peel", ctypes.c_double), ("ms_gather", ctypes.c_double), ("ms_corea", ctypes.c_double), ("ms_tail", ctypes.c_double),
     ]
 
 

@@ -975,20 +975,22 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         // adds the kernel's own per-phase stopwatch)
         const bool dbg = getenv("KOMB_TAIL_DEBUG") != nullptr;
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-        if (dbg) { for (auto &e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], s); }
+        for (auto &e : ev) (void)hipEventCreate(&e);
+        (void)hipEventRecord(ev[0], s);
         k_tail_mark<<<g, kBlock, 0, s>>>(list, n_in, d_sup, d_stamp, d_osrc, d_ocol, T);
         k_tail_number<<<1, kTailMaxV, 0, s>>>(T);
         k_tail_rows<<<g, kBlock, 0, s>>>(list, n_in, d_sup, d_stamp, d_osrc, d_ocol, T);
-        if (dbg) (void)hipEventRecord(ev[1], s);
+        (void)hipEventRecord(ev[1], s);
         k_truss_tail<<<1, 1024, 0, s>>>(d_ctrl, T, d_truss);
-        if (dbg) (void)hipEventRecord(ev[2], s);
+        (void)hipEventRecord(ev[2], s);
         KOMB_HIP(ctx, d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)));
         ++st.truss_tail_runs;
+        float m0 = 0, m1 = 0, m2 = 0;
+        (void)hipEventElapsedTime(&m0, ctx->timer.a, ev[0]); (void)hipEventElapsedTime(&m1, ev[0], ev[1]); (void)hipEventElapsedTime(&m2, ev[1], ev[2]);
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        st.ms_tail += (double)m1 + (double)m2;
         if (dbg) {
             uint32_t h[16];
-            float m0 = 0, m1 = 0, m2 = 0;
-            (void)hipEventElapsedTime(&m0, ctx->timer.a, ev[0]); (void)hipEventElapsedTime(&m1, ev[0], ev[1]); (void)hipEventElapsedTime(&m2, ev[1], ev[2]);
-            for (auto &e : ev) (void)hipEventDestroy(e);
             KOMB_HIP(ctx, d2h(ctx, h, T.cnt, sizeof(h)));
             fprintf(stderr, "komb tail: %u vertices, %u edges, %s; general engine before it %.1f us, setup %.1f us, tail kernel %.1f us\n",
                     h[0], h[1], ctx->h_ctrl[0].done == 1 ? "done" : "refused", m0 * 1000.f, m1 * 1000.f, m2 * 1000.f);
@@ -1005,7 +1007,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
     const int gp = peel_grid(m);
     int launches = 0, rc = KOMB_OK;
-    st.truss_tail_runs = 0;
+    st.truss_tail_runs = 0; st.ms_tail = 0.0;
     if (tail_limit && (uint64_t)m <= tail_limit) {
         // small graph: the tail takes the whole peel (unless it is refused, or nothing is left to peel)
         rc = d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) == hipSuccess ? KOMB_OK : KOMB_ERR_DEVICE;

@@ -41,10 +41,10 @@ def main():
     tag, trace_dir = sys.argv[1], sys.argv[2]
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(trace_dir, "*", "*_kernel_stats.csv"))
+    stats = glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
-    trace = glob.glob(os.path.join(trace_dir, "*", "*_kernel_trace.csv"))[0]
+    trace = glob.glob(os.path.join(trace_dir, "**", "*_kernel_trace.csv"), recursive=True)[0]
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         d[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -55,7 +55,7 @@ def main():
     if len(sys.argv) >= 5:
         traffic = collections.defaultdict(lambda: {"launches": 0})
         for ctr_dir in sys.argv[3:5]:
-            f = glob.glob(os.path.join(ctr_dir, "*", "*_counter_collection.csv"))[0]
+            f = glob.glob(os.path.join(ctr_dir, "**", "*_counter_collection.csv"), recursive=True)[0]
             seen = collections.Counter()
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
