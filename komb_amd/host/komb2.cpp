@@ -291,8 +291,15 @@ std::vector<int64_t> build_edges(const std::string &path1, const std::string &pa
     m1.open(path1);                                        // src/komb2.cpp:93
     m2.open(path2);                                        // src/komb2.cpp:95
     std::vector<ThreadParse> tp1((size_t)threads), tp2((size_t)threads);
+    const bool host_times = getenv("KOMB_HOST_TIMES") != nullptr;
+    auto lap = [&, last = clk::now()](const char *what) mutable {
+        if (host_times) fprintf(stderr, "komb2 host: %-28s %.3f s\n", what, since(last));
+        last = clk::now();
+    };
+    lap("mmap");
     parse_sam(m1, 0, threads, strict, tp1);
     parse_sam(m2, 1, threads, strict, tp2);
+    lap("parse both SAM files");
     // global vid = order of first appearance (file 1 before file 2, then byte offset): independent of T in strict mode.
     // Every thread has met most of the unitigs, so the per-thread dictionaries hold T x |V| names in total;
     // merging them serially was the largest single cost of the pipeline.  The names are partitioned by hash
@@ -311,6 +318,7 @@ std::vector<int64_t> build_edges(const std::string &path1, const std::string &pa
                 if (!ins.second && th->first_pos[i] < ins.first->second) ins.first->second = th->first_pos[i];
             }
     }
+    lap("merge unitig dictionaries");
     std::vector<size_t> boff(B + 1, 0);
     for (size_t b = 0; b < B; ++b) boff[b + 1] = boff[b] + bucket[b].size();
     std::vector<std::pair<uint64_t, View>> order(boff[B]);
@@ -329,6 +337,7 @@ std::vector<int64_t> build_edges(const std::string &path1, const std::string &pa
         bucket[(size_t)ViewHash{}(nm) % B].find(nm)->second = (uint64_t)i;      // no insertion: elements are written in place
         names.name[i].assign(nm.p, nm.n);
     }
+    lap("number the vertices");
     // gather all records, local id -> global vid
     size_t total = 0;
     std::vector<size_t> offs;
@@ -344,6 +353,7 @@ std::vector<int64_t> build_edges(const std::string &path1, const std::string &pa
             std::vector<Rec>().swap(th.recs);
         }
     }
+    lap("gather records");
     *t_sam = since(t0);
 
     // getEdgeInfo: one group per read key over both files -- sort by (hash, key bytes, vid)
