@@ -1,9 +1,9 @@
 """One-off: full-size C3 (|V|=10M, |E|~100M) GPU results vs the CPU oracle, every value.
 Too slow for the test suite (the single-thread oracle needs ~10 min); run by hand:
-    python scripts/c3_parity_oneoff.py > gpurun_out/c3_parity.log
+    python tests/manual/c3_parity_oneoff.py > gpurun_out/c3_parity.log
 """
 import hashlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import komb_amd
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """One-off: long peel cascades (one unit per sub-round): path for k-core, triangle strip for k-truss."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import komb_amd
 from oracle import oracle as O

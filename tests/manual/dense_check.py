@@ -1,6 +1,6 @@
 """One-off: moderately dense random graphs (16-vertex tasks exceed the LDS budget, single rows do not)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import komb_amd
 from oracle import oracle as O

@@ -2,7 +2,7 @@
 reference's pipeline restated with its own hash containers, on the same synthetic SAM pair; then, when a GPU
 is present, the whole komb2 run with its own stage times.
 
-    python scripts/komb2_scale.py [n_unitigs] [n_reads] [threads] [workdir]
+    python tests/manual/komb2_scale.py [n_unitigs] [n_reads] [threads] [workdir]
 
 Prints the graph comparison (must be identical) and the wall-clock of both.
 """
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KOMB2 = os.path.join(ROOT, "komb_amd", "bin", "komb2")
 PORT = os.path.join(ROOT, "oracle", "sam_port")
 

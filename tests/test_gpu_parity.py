@@ -341,7 +341,7 @@ def test_kernel_threshold_boundaries(K, O, monkeypatch, two_pass):
 def test_full_size_c3_known_answer(K, O):
     """BASELINE config C3 (|V|=10M, |E|=100.1M, T=88.3M), the workload bench.py times.  Coreness against
     the oracle; trussness through properties and through the SHA-256 recorded when EVERY value was compared
-    with the oracle's (scripts/c3_parity_oneoff.py, profiles/r01_c3_full_parity.log: 335 s of CPU)."""
+    with the oracle's (tests/manual/c3_parity_oneoff.py, profiles/r01_c3_full_parity.log: 335 s of CPU)."""
     import hashlib
     nv = 10_000_000
     uv = K.gen_hug_edges(nv, 24_250_000, 2.6, 42)
