@@ -106,6 +106,35 @@ int main()
         snprintf(nm, sizeof nm, "ctrl + %d dependent returning atomics, 256 x 1024", hops);
         timeit(nm, [&] { k_chain_atomic<<<256, 1024, 0, s>>>(ctrl, next, hops, sink); });
     }
+    // the same 24-launch batch as a hipGraph (what the peel driver could replay instead of 24 launches)
+    {
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < 24; ++i) k_ticket<<<256, 1024, 0, s>>>(ctrl, grp, top);
+        CK(hipStreamEndCapture(s, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int i = 0; i < 4; ++i) (void)hipGraphLaunch(ge, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipEventRecord(a, s);
+        for (int i = 0; i < N / 24; ++i) (void)hipGraphLaunch(ge, s);
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+        printf("%-52s %7.2f us/launch\n", "ctrl + ticket, 256 x 1024, hipGraph of 24", ms * 1000.f / (N / 24 * 24));
+        hipGraph_t g2; hipGraphExec_t ge2;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < 24; ++i) k_empty<<<256, 1024, 0, s>>>();
+        CK(hipStreamEndCapture(s, &g2));
+        CK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+        for (int i = 0; i < 4; ++i) (void)hipGraphLaunch(ge2, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipEventRecord(a, s);
+        for (int i = 0; i < N / 24; ++i) (void)hipGraphLaunch(ge2, s);
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        (void)hipEventElapsedTime(&ms, a, b);
+        printf("%-52s %7.2f us/launch\n", "empty, 256 x 1024, hipGraph of 24", ms * 1000.f / (N / 24 * 24));
+    }
     int one = 1;
     CK(hipMemcpy(ctrl, &one, 4, hipMemcpyHostToDevice));
     timeit("done path (ctrl says stop), 256 x 1024", [&] { k_ticket<<<256, 1024, 0, s>>>(ctrl, grp, top); });
