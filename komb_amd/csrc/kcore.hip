@@ -159,6 +159,14 @@ int core_run(komb_ctx *ctx)
         k_peel_step<CoreProblem><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
     }, &launches);
     ctx->stats.ms_core = ctx->timer.stop(s);
+#ifdef KOMB_STEP_TIMERS
+    {
+        const PeelCtrl &c = ctx->h_ctrl[0];
+        const double n = c.pad1[7] ? (double)c.pad1[7] : 1.0;
+        fprintf(stderr, "komb core step timers (block 0, %u small multi-workgroup PROCESS steps), us per step: ctrl %.2f queue+slice %.2f items %.2f flush %.2f barrier %.2f ticket %.2f\n",
+                c.pad1[7], c.pad1[0] / n / 100.0, c.pad1[1] / n / 100.0, c.pad1[2] / n / 100.0, c.pad1[3] / n / 100.0, c.pad1[4] / n / 100.0, c.pad1[5] / n / 100.0);
+    }
+#endif
     cleanup();
     KOMB_TRY(st);
     if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-core peel ended in an inconsistent state");

@@ -1029,6 +1029,14 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
     st.ms_peel = ctx->timer.stop(s);
     KOMB_TRY(rc);
+#ifdef KOMB_STEP_TIMERS
+    {
+        const PeelCtrl &c = ctx->h_ctrl[0];
+        const double n = c.pad1[7] ? (double)c.pad1[7] : 1.0;
+        fprintf(stderr, "komb step timers (block 0, %u small multi-workgroup PROCESS steps), us per step: ctrl %.2f queue+slice %.2f items %.2f flush %.2f barrier %.2f ticket %.2f\n",
+                c.pad1[7], c.pad1[0] / n / 100.0, c.pad1[1] / n / 100.0, c.pad1[2] / n / 100.0, c.pad1[3] / n / 100.0, c.pad1[4] / n / 100.0, c.pad1[5] / n / 100.0);
+    }
+#endif
     if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss peel ended in an inconsistent state");
     st.truss_levels = ctx->h_ctrl[0].n_levels;
     st.truss_subrounds = ctx->h_ctrl[0].n_rounds;

@@ -126,53 +126,50 @@ __device__ __forceinline__ void wave_write_chunks(bool pred, int32_t unit, uint3
     }
 }
 
-// PROCESS: staged append of triggered units.  Light units collect in the wave's LDS buffer.
+// PROCESS: staged append of triggered units.  Light units and heavy units (with their chunk counts) collect in
+// the wave's LDS buffers; a flush reserves queue space for both kinds at once -- two atomics issued from two
+// lanes of one instruction, ONE round trip -- and then writes the light ids and expands the heavy units into
+// their (unit, chunk) entries.  (Reserving for the heavy units inside the item loop cost a returning atomic per
+// trip, on the critical path of most k-core steps.)
+constexpr int kStageH = 64;                     // staged heavy units per wave
 struct WaveStage {
-    int32_t *buf;            // [kStage] in LDS, private to the wave
-    uint32_t n;              // wave-uniform fill
+    int32_t *buf;            // [kStage] light unit ids, LDS, private to the wave
+    int2 *hbuf;              // [kStageH] (heavy unit id, chunks)
+    uint32_t n, hn;          // wave-uniform fills
 };
-__device__ __forceinline__ void stage_flush(WaveStage &st, int32_t *q, uint32_t *tail)
+__device__ __forceinline__ void stage_flush(WaveStage &st, int32_t *ql, uint32_t *tail_l, int2 *qh, uint32_t *tail_h)
 {
-    if (st.n == 0) return;
+    if (st.n == 0 && st.hn == 0) return;
     const int lane = lane_id();
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(tail, st.n);
-    base = (uint32_t)__shfl((int)base, 0);
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = (uint32_t)lane; i < st.n; i += kWave) q[base + i] = st.buf[i];
-    __builtin_amdgcn_wave_barrier();
-    st.n = 0;
-}
-__device__ __forceinline__ void stage_push(WaveStage &st, bool pred, int32_t val, int32_t *q, uint32_t *tail)
-{
-    const uint64_t m = __ballot(pred);
-    if (m == 0) return;
-    const uint32_t cnt = (uint32_t)__popcll(m);
-    if (st.n + cnt > (uint32_t)kStage) stage_flush(st, q, tail);
-    if (pred) st.buf[st.n + (uint32_t)__popcll(m & lanemask_lt())] = val;
-    st.n += cnt;
-}
-__device__ __forceinline__ void heavy_push(bool pred, int32_t unit, uint32_t nchunks, int2 *q, uint32_t *tail)
-{
-    // one reservation for all heavy units the wave triggered in this trip (a serial atomic per unit
-    // would put one memory round trip per unit on the step's critical path)
-    uint64_t m = __ballot(pred);
-    const int lane = lane_id();
-    const uint32_t mine = pred ? nchunks : 0u;
-    const uint32_t incl = wave_incl_scan(mine);
-    const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(tail, total);
-    base = (uint32_t)__shfl((int)base, 0);
-    const uint32_t excl = incl - mine;
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int32_t u = __shfl(unit, src);
-        const uint32_t n = (uint32_t)__shfl((int)nchunks, src);
-        const uint32_t o = base + (uint32_t)__shfl((int)excl, src);
-        for (uint32_t c = (uint32_t)lane; c < n; c += kWave) q[o + c] = make_int2(u, (int)c);
+    const int2 mine = (uint32_t)lane < st.hn ? st.hbuf[lane] : make_int2(0, 0);
+    const uint32_t incl = wave_incl_scan((uint32_t)mine.y);
+    const uint32_t total_h = (uint32_t)__shfl((int)incl, kWave - 1);
+    uint32_t r = 0;
+    if (lane == 0 && st.n) r = atomicAdd(tail_l, st.n);
+    else if (lane == 1 && total_h) r = atomicAdd(tail_h, total_h);
+    const uint32_t base_l = (uint32_t)__shfl((int)r, 0), base_h = (uint32_t)__shfl((int)r, 1);
+    for (uint32_t i = (uint32_t)lane; i < st.n; i += kWave) ql[base_l + i] = st.buf[i];
+    const uint32_t excl = incl - (uint32_t)mine.y;
+    for (uint32_t k = 0; k < st.hn; ++k) {
+        const int32_t u = __shfl(mine.x, (int)k);
+        const uint32_t n = (uint32_t)__shfl(mine.y, (int)k);
+        const uint32_t o = base_h + (uint32_t)__shfl((int)excl, (int)k);
+        for (uint32_t c = (uint32_t)lane; c < n; c += kWave) qh[o + c] = make_int2(u, (int)c);
     }
+    __builtin_amdgcn_wave_barrier();
+    st.n = 0; st.hn = 0;
+}
+__device__ __forceinline__ void stage_push(WaveStage &st, bool is_light, bool is_heavy, int32_t unit, uint32_t nchunks,
+                                           int32_t *ql, uint32_t *tail_l, int2 *qh, uint32_t *tail_h)
+{
+    const uint64_t ml = __ballot(is_light), mh = __ballot(is_heavy);
+    if ((ml | mh) == 0) return;
+    const uint32_t cl = (uint32_t)__popcll(ml), ch = (uint32_t)__popcll(mh);
+    if (st.n + cl > (uint32_t)kStage || st.hn + ch > (uint32_t)kStageH) stage_flush(st, ql, tail_l, qh, tail_h);
+    if (is_light) st.buf[st.n + (uint32_t)__popcll(ml & lanemask_lt())] = unit;
+    if (is_heavy) st.hbuf[st.hn + (uint32_t)__popcll(mh & lanemask_lt())] = make_int2(unit, (int)nchunks);
+    st.n += cl; st.hn += ch;
 }
 
 // ------------------------------------------------------- step planning / finalisation
@@ -184,11 +181,11 @@ constexpr uint32_t kMaxInKernelSteps = 8192;    // bound on steps one launch may
 // How many workgroups take part in the step described by cv, and the light batch width.
 __device__ __forceinline__ uint32_t plan_step(const CtrlView &cv, uint32_t grid, uint32_t &bsz)
 {
-    // light units per wave batch: 64 when the frontier is large, fewer (>= 4) when it would
-    // otherwise leave most of the grid's wavefronts without work
+    // light units per wave batch: 64 when the frontier is large, fewer (>= 2: two units of <= 64 items are
+    // one trip of the item loop) when it would otherwise leave most of the grid's wavefronts without work
     bsz = kWave;
     const uint64_t grid_waves = (uint64_t)grid * kPeelWaves;
-    while (bsz > 4 && (uint64_t)cv.cur_light < grid_waves * (bsz / 2)) bsz >>= 1;
+    while (bsz > 2 && (uint64_t)cv.cur_light < grid_waves * (bsz / 2)) bsz >>= 1;
     if (cv.mode == MODE_SCAN) return (cv.live_mode != 0 && cv.live_count <= kSmallScan) ? 1u : grid;
     if (cv.cur_light <= kSmallLight && cv.cur_heavy <= kSmallHeavy) {
         // small frontier: one workgroup (its 16 wavefronts share the units) -- cheaper than a
@@ -281,7 +278,14 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
     __shared__ uint32_t sh_beg[kPeelWaves][kWave];
     __shared__ int32_t sh_unit[kPeelWaves][kWave];
     __shared__ int32_t sh_stage[kPeelWaves][kStage];
+    __shared__ int2 sh_stage_h[kPeelWaves][kStageH];
 
+#ifdef KOMB_STEP_TIMERS
+    unsigned long long tk[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
+#define KOMB_TK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) tk[i] = wall_clock64(); } while (0)
+#else
+#define KOMB_TK(i) do { } while (0)
+#endif
     if (threadIdx.x == 0) {
         sh_cv.mode = ctrl->mode; sh_cv.level = ctrl->level; sh_cv.round = ctrl->round; sh_cv.done = ctrl->done;
         sh_cv.cur_sel = ctrl->cur_sel; sh_cv.cur_light = ctrl->cur_light; sh_cv.cur_heavy = ctrl->cur_heavy;
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
     __syncthreads();
     CtrlView cv = sh_cv;
     if (cv.done) return;
+    KOMB_TK(1);
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
 
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         int32_t *qn_l = Q.light[sel ^ 1];
         int2 *qn_h = Q.heavy[sel ^ 1];
         uint32_t *tail_nl = &ctrl->tail_l[sel ^ 1], *tail_nh = &ctrl->tail_h[sel ^ 1];
-        WaveStage st{sh_stage[w], 0u};
+        WaveStage st{sh_stage[w], sh_stage_h[w], 0u, 0u};
         uint32_t n_trig = 0;                                // wave-uniform
         const uint64_t gw = (uint64_t)blockIdx.x * kPeelWaves + (uint64_t)w;
         const uint64_t nw = (uint64_t)nblk * kPeelWaves;
@@ -415,8 +420,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             n_trig += (uint32_t)__popcll(m);
             const bool is_light = trig && nch == 0;
             const bool is_heavy = trig && nch != 0;
-            stage_push(st, is_light, t, qn_l, tail_nl);
-            if (__ballot(is_heavy)) heavy_push(is_heavy, t, nch, qn_h, tail_nh);
+            stage_push(st, is_light, is_heavy, t, nch, qn_l, tail_nl, qn_h, tail_nh);
         };
         // kItemU items per lane per trip: all loads first, then the decrements
         auto run_items = [&](const bool (&active)[kItemU], const int32_t (&unit)[kItemU], const uint32_t (&pos)[kItemU]) {
@@ -468,18 +472,29 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             }
             __builtin_amdgcn_wave_barrier();
         };
-        for (uint64_t bt = gw; bt < n_batches; bt += nw) {
-            const uint64_t idx = bt * bsz + (uint64_t)lane;
-            int32_t unit = -1;
-            uint32_t beg = 0, len = 0;
-            if ((uint32_t)lane < bsz && idx < cv.cur_light) { unit = Q.light[sel][idx]; p.slice((uint32_t)unit, beg, len); }
-            run_batch(unit, beg, len);
-        }
-        // heavy chunks: one entry per wave visit, kChunk items each
-        for (uint64_t h = gw; h < (uint64_t)cv.cur_heavy; h += nw) {
-            const int2 ent = Q.heavy[sel][h];
+        // One job list: the light batches, then the heavy chunks; wave g takes jobs g, g + nw, ...  (with
+        // separate strides for the two kinds the first waves got a batch AND a chunk -- three dependent
+        // trips more on the step's critical path -- while the last ones had nothing to do)
+        const uint64_t n_jobs = n_batches + (uint64_t)cv.cur_heavy;
+        for (uint64_t job = gw; job < n_jobs; job += nw) {
+            if (job < n_batches) {
+                const uint64_t idx = job * bsz + (uint64_t)lane;
+                int32_t unit = -1;
+                uint32_t beg = 0, len = 0;
+                if ((uint32_t)lane < bsz && idx < cv.cur_light) { unit = Q.light[sel][idx]; p.slice((uint32_t)unit, beg, len); }
+#ifdef KOMB_STEP_TIMERS
+                if (blockIdx.x == 0 && threadIdx.x == 0 && tk[2] == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk[2] = wall_clock64(); }
+#endif
+                run_batch(unit, beg, len);
+                continue;
+            }
+            // heavy chunk: kChunk items of one unit
+            const int2 ent = Q.heavy[sel][job - n_batches];
             uint32_t beg, len;
             p.slice((uint32_t)ent.x, beg, len);
+#ifdef KOMB_STEP_TIMERS
+            if (blockIdx.x == 0 && threadIdx.x == 0 && tk[2] == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk[2] = wall_clock64(); }
+#endif
             const uint32_t c0 = (uint32_t)ent.y * kChunk;
             const uint32_t c1 = min(len, c0 + (uint32_t)kChunk);
             for (uint32_t it0 = c0; it0 < c1; it0 += kWave * kItemU) {
@@ -511,7 +526,11 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
                 run_batch(unit, beg, len);
             }
         }
-        stage_flush(st, qn_l, tail_nl);
+        KOMB_TK(3);
+        stage_flush(st, qn_l, tail_nl, qn_h, tail_nh);
+#ifdef KOMB_STEP_TIMERS
+        if (blockIdx.x == 0 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk[4] = wall_clock64(); }
+#endif
         if (lane == 0) sh_w[w][3] = n_trig;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -523,6 +542,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
 
     // ---- end of step
     __syncthreads();
+    KOMB_TK(5);
     if (nblk > 1) {
         // several workgroups: two-level arrival ticket; the last one rewrites the control block.
         // Only ATOMICS cross workgroups inside a launch (queue cursors, acc, next_min); every plain store
@@ -558,6 +578,14 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
                 }
             }
         }
+#ifdef KOMB_STEP_TIMERS
+        if (blockIdx.x == 0 && threadIdx.x == 0 && cv.mode == MODE_PROCESS && cv.cur_light + cv.cur_heavy < 16384 && tk[2] != 0) {
+            tk[6] = wall_clock64();
+            // sums of: ctrl read, queue + slice, items, flush, barrier, ticket; and the number of steps sampled
+            for (int i = 0; i < 6; ++i) atomicAdd(&ctrl->pad1[i], (uint32_t)(tk[i + 1] - tk[i]));
+            atomicAdd(&ctrl->pad1[7], 1u);
+        }
+#endif
         last = __shfl(last, 0);
         total = (uint32_t)__shfl((int)total, 0);
         if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total);
