@@ -682,7 +682,11 @@ int main(int argc, const char **argv)
     fprintf(stdout, "GraphInfo...\n\tNumber of vertices: %d\n", (int)gnv);
     fprintf(stdout, "\tNumber of edges: %d\n", (int)gne);
 
-    const auto unitigs = read_unitigs(args.unitigs);               // src/graph.cpp:446
+    // src/graph.cpp:446 reads the unitig FASTA here; only the (disabled) truss / v1 stages use it, so it is
+    // opened now -- a missing file must fail at this point, as in the reference -- and parsed only when needed
+    if (access(args.unitigs.c_str(), R_OK) != 0) file_not_found(args.unitigs);
+    const bool need_unitigs = env_on("KOMB_TRUSS") || env_on("KOMB_V1_OUTPUTS");
+    const auto unitigs = need_unitigs ? read_unitigs(args.unitigs) : std::unordered_map<std::string, std::string>();
 
     // runCore (src/graph.cpp:455-484)
     t0 = clk::now();
