@@ -176,6 +176,7 @@ namespace komb {
 int prim_sort_u64(komb_ctx *ctx, uint64_t *keys, uint64_t *tmp_keys, int64_t n, int end_bit, uint64_t **sorted);
 int prim_unique_u64(komb_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, int64_t *n_out);
 int prim_exclusive_sum_u32(komb_ctx *ctx, const uint32_t *in, uint32_t *out, int64_t n);   // out[n-1] valid; in/out may alias
+int prim_exclusive_sum_u32_u64(komb_ctx *ctx, const uint32_t *in, unsigned long long *out, int64_t n);
 int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, uint32_t *vals, uint32_t *vals_tmp,
                              int64_t n, int end_bit, int64_t **sorted_keys, uint32_t **sorted_vals);
 

@@ -229,11 +229,11 @@ constexpr int kTriWaves = kBlock / kWave;
 
 enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
 
-template <int MODE>
+template <int MODE, class OffT = uint32_t>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
 __global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
-                                                      const uint32_t *__restrict__ off, int2 *__restrict__ inc, int ablate)
+                                                      const OffT *__restrict__ off, int2 *__restrict__ inc, int ablate)
 {
     // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all
     __shared__ int32_t sh_col[kTriWaves][kTriCap];
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restr
                     } else {
                         // slices [off[x], off[x+1]) -- capacity-bounded (single pass) or exact (after a
                         // counting pass): own-role entries grow from the front, third-role from the back
-                        uint32_t pe, pi;
+                        OffT pe, pi;
                         if (staged) {
                             pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
                             pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restr
                             pe = off[e] + atomicAdd(&own[e], 1u);
                             pi = off[i] + atomicAdd(&own[i], 1u);
                         }
-                        const uint32_t pj = off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                        const OffT pj = off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
                         inc[pe] = make_int2((int)i, (int)jj);
                         inc[pi] = make_int2((int)e, (int)jj);
                         inc[pj] = make_int2((int)e, (int)i);
@@ -496,7 +496,8 @@ __global__ __launch_bounds__(kBlock) void k_slice_caps(const int32_t *__restrict
 // Dense index from the bounded slices: 64 consecutive edges per wavefront, their entries flattened
 // over the lanes; the dense slices of consecutive edges are contiguous, so the writes are one
 // coalesced stream.  Entry k of edge x sits at offc[x]+k (k < own[x]) or offc[x+1]-1-(k-own[x]).
-__global__ __launch_bounds__(kBlock) void k_compact_inc(const uint32_t *__restrict__ offc, const uint32_t *__restrict__ own,
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void k_compact_inc(const OffT *__restrict__ offc, const uint32_t *__restrict__ own,
                                                         const uint32_t *__restrict__ off, const int2 *__restrict__ sparse,
                                                         int2 *__restrict__ dense, int64_t m)
 {
@@ -508,7 +509,8 @@ __global__ __launch_bounds__(kBlock) void k_compact_inc(const uint32_t *__restri
     const int64_t nbatches = (m + kWave - 1) / kWave;
     for (int64_t bt = wave; bt < nbatches; bt += nwaves) {
         const int64_t e = bt * kWave + lane;
-        uint32_t d0 = 0, len = 0, c0 = 0, c1 = 0, ow = 0;
+        uint32_t d0 = 0, len = 0, ow = 0;
+        OffT c0 = 0, c1 = 0;
         if (e < m) { d0 = off[e]; len = off[e + 1] - d0; c0 = offc[e]; c1 = offc[e + 1]; ow = own[e]; }
         const uint32_t incl = wave_incl_scan(len);
         const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
@@ -526,10 +528,11 @@ __global__ __launch_bounds__(kBlock) void k_compact_inc(const uint32_t *__restri
                 t = lo;
             }
             const uint32_t first = t ? s_end[t - 1] : 0u;
-            const uint32_t tc0 = (uint32_t)__shfl((int)c0, t), tc1 = (uint32_t)__shfl((int)c1, t), tow = (uint32_t)__shfl((int)ow, t);
+            const OffT tc0 = (OffT)__shfl((unsigned long long)c0, t), tc1 = (OffT)__shfl((unsigned long long)c1, t);
+            const uint32_t tow = (uint32_t)__shfl((int)ow, t);
             if (it < total) {
                 const uint32_t k = it - first;
-                const uint32_t sp = k < tow ? tc0 + k : tc1 - 1u - (k - tow);
+                const OffT sp = k < tow ? tc0 + k : tc1 - 1u - (k - tow);
                 dense[dbase + it] = sparse[sp];
             }
         }
@@ -845,6 +848,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // bounded index fits 32-bit offsets and memory; otherwise (and when the support phase is sharded over
     // ranks, which needs the counts first) the exact two-pass layout is used.
     uint32_t *d_cap = nullptr, *d_offc = nullptr;
+    unsigned long long *d_offc64 = nullptr;    // the same offsets in 64 bits when the slices exceed 2^32 entries (KOMB_OFF64=1 forces them)
     int2 *d_sparse = nullptr;
     const int ablate = getenv("KOMB_TRI_ABLATE") ? atoi(getenv("KOMB_TRI_ABLATE")) : 0;    // debug only: breaks results
     bool single = (world == 1) && !getenv("KOMB_TWO_PASS");
@@ -858,24 +862,30 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, d2h(ctx, &cap_total, d_mom + 6, sizeof(cap_total)));
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        if (cap_total > 0xFFFFFFF0ull || cap_total * sizeof(int2) > (unsigned long long)(free_b * 0.8)) single = false;
+        if (cap_total * sizeof(int2) > (unsigned long long)(free_b * 0.8)) single = false;
+        const bool wide = cap_total > 0xFFFFFFF0ull || getenv("KOMB_OFF64") != nullptr;
         if (single) {
-            KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cap, d_offc, m + 1));
-            if (bufs.alloc(&d_sparse, (size_t)cap_total) != hipSuccess) { (void)hipGetLastError(); single = false; }
+            if (wide) {
+                bufs.release(d_offc); d_offc = nullptr;
+                if (bufs.alloc(&d_offc64, (size_t)m + 1) != hipSuccess) { (void)hipGetLastError(); single = false; }
+                else KOMB_TRY(prim_exclusive_sum_u32_u64(ctx, d_cap, d_offc64, m + 1));
+            } else KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cap, d_offc, m + 1));
+            if (single && bufs.alloc(&d_sparse, (size_t)cap_total) != hipSuccess) { (void)hipGetLastError(); single = false; }
         }
         if (single) {
-            k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, ablate);
+            if (d_offc64) k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, ablate);
+            else k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, ablate);
             st.ms_tri_fill = ctx->timer.stop(s);
             st.ms_tri_count = 0.0;
         } else {
             (void)ctx->timer.stop(s);
-            bufs.release(d_cap); bufs.release(d_offc);
+            bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64); d_offc64 = nullptr;
         }
     }
     if (!single) {
         const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
         ctx->timer.start(s);
-        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr, ablate);
+        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, ablate);
         st.ms_tri_count = ctx->timer.stop(s);
     }
     k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt, d_mom + 5);
@@ -914,9 +924,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.ms_compact = 0.0;
     if (single) {
         ctx->timer.start(s);
-        k_compact_inc<<<grid_for((m + kWave - 1) / kWave, kBlock / kWave), kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_inc, m);
+        const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
+        if (d_offc64) k_compact_inc<unsigned long long><<<gc, kBlock, 0, s>>>(d_offc64, d_own, d_off, d_sparse, d_inc, m);
+        else k_compact_inc<uint32_t><<<gc, kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_inc, m);
         st.ms_compact = ctx->timer.stop(s);
-        bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc);
+        bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64);
     } else {
         // second enumeration, same writer as the single-pass layout but into the EXACT slices: own-role
         // entries from the front and third-role entries from the back meet precisely -- no compaction

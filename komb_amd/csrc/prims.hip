@@ -64,6 +64,22 @@ int prim_exclusive_sum_u32(komb_ctx *ctx, const uint32_t *in, uint32_t *out, int
     return KOMB_OK;
 }
 
+// exclusive sum of 32-bit counts into 64-bit offsets (totals beyond 2^32)
+struct WidenU32 { __host__ __device__ unsigned long long operator()(uint32_t x) const { return (unsigned long long)x; } };
+int prim_exclusive_sum_u32_u64(komb_ctx *ctx, const uint32_t *in, unsigned long long *out, int64_t n)
+{
+    if (n > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "scan: %lld items exceed the 2^31-1 primitive limit", (long long)n);
+    if (n == 0) return KOMB_OK;
+    hipcub::TransformInputIterator<unsigned long long, WidenU32, const uint32_t *> wide(in, WidenU32());
+    size_t bytes = 0;
+    KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, wide, out, (int)n, ctx->stream));
+    TempBuf t(ctx);
+    KOMB_HIP(ctx, t.get(bytes));
+    KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(t.p, bytes, wide, out, (int)n, ctx->stream));
+    KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KOMB_OK;
+}
+
 int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, uint32_t *vals, uint32_t *vals_tmp,
                              int64_t n, int end_bit, int64_t **sorted_keys, uint32_t **sorted_vals)
 {

@@ -216,8 +216,8 @@ def test_full_size_c2_properties(K, O):
 
 
 def test_index_layouts_agree(K, O, monkeypatch):
-    """Single-pass (degree-bounded slices + compaction) and two-pass (exact slices) incidence
-    builds must give the same supports and trussness."""
+    """Single-pass (degree-bounded slices + compaction, 32- and 64-bit slice offsets) and two-pass (exact
+    slices) incidence builds must give the same supports and trussness."""
     uv = K.gen_hug_edges(40000, 110000, 2.3, 21)
     with K.KombAccel() as a:
         a.from_edges(40000, uv)
@@ -227,6 +227,14 @@ def test_index_layouts_agree(K, O, monkeypatch):
         r2 = a.run_truss(with_support=True)
         assert a.stats()["ms_tri_count"] > 0
         for x, y in zip(r1, r2):
+            assert np.array_equal(x, y)
+        # the single-pass layout with 64-bit slice offsets (what graphs beyond 2^32 bounded entries use)
+        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+        monkeypatch.setenv("KOMB_OFF64", "1")
+        r3 = a.run_truss(with_support=True)
+        assert a.stats()["ms_tri_count"] == 0 and a.stats()["ms_compact"] > 0
+        monkeypatch.delenv("KOMB_OFF64", raising=False)
+        for x, y in zip(r1, r3):
             assert np.array_equal(x, y)
         rowptr, col = a.get_csr()
         assert np.array_equal(r1[2], O.trussness(rowptr, col))
