@@ -140,7 +140,7 @@ int core_run(komb_ctx *ctx)
     hipError_t e = ctx->pool.get((void **)&d_degw, (size_t)nv * sizeof(int32_t));
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.light[i], (size_t)nv * sizeof(int32_t));
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.heavy[i], heavy_cap * sizeof(int2));
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.live[i], ((size_t)nv / 4 + 64) * sizeof(int32_t));
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.live[i], ((size_t)nv / 2 + 64) * sizeof(int32_t));
     if (e == hipSuccess) e = ctx->pool.get((void **)&Q.code, (size_t)nv);
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_ctrl, sizeof(PeelCtrl));
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, (kInitOff + 2) * sizeof(uint32_t));

@@ -951,7 +951,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     for (int i = 0; i < 2; ++i) {
         KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&Q.heavy[i], heavy_cap));
-        KOMB_HIP(ctx, bufs.alloc(&Q.live[i], (size_t)m / 4 + 64));
+        KOMB_HIP(ctx, bufs.alloc(&Q.live[i], (size_t)m / 2 + 64));
     }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));

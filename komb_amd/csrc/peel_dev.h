@@ -9,7 +9,7 @@
 // One kernel, k_peel_step<P>, is launched over and over; what a launch does is
 // decided on the device from the control block its predecessor finalised:
 //   SCAN    : two passes over all units (later: over the compacted list of live
-//             units, rewritten by every SCAN once <= 1/4 of the units is left).
+//             units, rewritten by every SCAN once <= 1/2 of the units is left).
 //             Pass A classifies every unit (one byte each) and counts, per wave,
 //             the live units with key <= level; one atomic per WORKGROUP
 //             reserves queue space; pass B replays the bytes and writes the
@@ -208,7 +208,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
     const int lane = lane_id();
     const bool scan = cv.mode == MODE_SCAN;
     const int sel = cv.cur_sel;
-    const bool emitted = scan && (cv.live_mode != 0 || cv.remaining <= units / 4);
+    const bool emitted = scan && (cv.live_mode != 0 || cv.remaining <= units / 2);
     const int next_q = scan ? sel : (sel ^ 1);
     uint32_t v = 0;
     if (lane == 1) v = coherent_load(&ctrl->tail_l[next_q]);
@@ -314,9 +314,9 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
 
     if (cv.mode == MODE_SCAN) {
         // ---- input: every unit, or the compacted live list; survivors are compacted into the
-        // other live buffer once at most a quarter of the units is left
+        // other live buffer once at most half of the units is left
         const bool from_list = cv.live_mode != 0;
-        const bool emit = from_list || cv.remaining <= p.units / 4;
+        const bool emit = from_list || cv.remaining <= p.units / 2;
         const uint32_t n_in = from_list ? cv.live_count : p.units;
         const int32_t *live_in = Q.live[cv.live_sel];
         int32_t *live_out = Q.live[cv.live_sel ^ 1];
