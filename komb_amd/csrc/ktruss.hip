@@ -50,9 +50,13 @@ struct PredMask {                       // keep slot (a,b) when both endpoints a
 };
 struct PredOrient {                     // keep slot (a,b) when a precedes b in (degree,id) order
     const int32_t *deg;
+    const uint8_t *deg8;                // min(deg, 255): a 1-byte-per-vertex table that the L2s and the Infinity Cache hold,
+                                        // so the one random gather per slot rarely goes to HBM; exact degrees only
+                                        // when both endpoints saturate
     __device__ bool operator()(int32_t a, int32_t b) const
     {
-        const int32_t da = deg[a], db = deg[b];
+        int32_t da = deg8[a], db = deg8[b];
+        if (da == 255 && db == 255) { da = deg[a]; db = deg[b]; }
         return da < db || (da == db && a < b);
     }
 };
@@ -190,10 +194,14 @@ __global__ __launch_bounds__(kBlock) void k_upper_count(const uint32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ rowptr, int64_t nv, int32_t *__restrict__ deg)
+__global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ rowptr, int64_t nv, int32_t *__restrict__ deg,
+                                                   uint8_t *__restrict__ deg8)
 {
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock)
-        deg[v] = (int32_t)(rowptr[v + 1] - rowptr[v]);
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
+        const int32_t d = (int32_t)(rowptr[v + 1] - rowptr[v]);
+        deg[v] = d;
+        deg8[v] = (uint8_t)min(d, 255);
+    }
 }
 
 // ------------------------------------------------------ triangle enumeration
@@ -820,12 +828,14 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&d_deg, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_orow, (size_t)nv + 1));
     ctx->timer.start(s);
-    k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg);
+    uint8_t *d_deg8 = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_deg8, (size_t)nv));
+    k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg, d_deg8);
     int32_t *d_ocol = nullptr, *d_osrc = nullptr;
     int64_t m = 0;
     unsigned long long *d_obits = nullptr;                           // bit j: working slot j is the oriented copy of its edge
     uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
-    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank));
+    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank));
     st.ms_orient = ctx->timer.stop(s);
 
     // ---- triangle support + incidence index
