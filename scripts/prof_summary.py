@@ -26,8 +26,8 @@ def short(name):
     n = name.replace("komb::(anonymous namespace)::", "").replace("komb::", "").replace("void ", "")
     if n.startswith("k_peel_step<"):
         return "k_peel_step<Truss>" if "TrussProblem" in n else "k_peel_step<Core>"
-    for key, nice in (("k_triangles<0>", "k_triangles<count>"), ("k_triangles<1>", "k_triangles<fill>"),
-                      ("k_triangles<2>", "k_triangles<single>")):
+    for key, nice in (("k_triangles<0", "k_triangles<count>"), ("k_triangles<1", "k_triangles<fill>"),
+                      ("k_triangles<2", "k_triangles<single>"), ("k_compact_inc<", "k_compact_inc")):
         if n.startswith(key):
             return nice
     if n.startswith("k_slot_filter<"):
