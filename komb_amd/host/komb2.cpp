@@ -19,6 +19,7 @@
 //   KOMB_STRICT_SAM=1   parse every SAM line (the reference drops the line that
 //                       straddles each OpenMP byte-chunk boundary, see readSAM)
 //   KOMB_DEVICE=<n>     HIP device ordinal (default 0)
+//   KOMB_HOST_TIMES=1   stage times of the SAM -> edge list pipeline on stderr
 //   KOMB_STOP_AFTER_EDGES=1  write edgelist.txt + vertex_names.txt and stop
 //                       before touching the device (host-logic tests)
 #include <algorithm>
