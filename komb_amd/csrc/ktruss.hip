@@ -237,7 +237,9 @@ constexpr int kTriWaves = kBlock / kWave;
 
 enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
 
-template <int MODE, class OffT = uint32_t>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
+// BACK: other_or_cursor[x] starts at off[x+1]-1, the last position of x's slice, and is counted DOWN: the
+// returning atomic is the third-role write position itself (no load of off[x+1] from a second random line)
+template <int MODE, class OffT = uint32_t, bool BACK = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
 __global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restr
                             pe = off[e] + atomicAdd(&own[e], 1u);
                             pi = off[i] + atomicAdd(&own[i], 1u);
                         }
-                        const OffT pj = off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                        const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
                         inc[pe] = make_int2((int)i, (int)jj);
                         inc[pi] = make_int2((int)e, (int)jj);
                         inc[pj] = make_int2((int)e, (int)i);
@@ -473,13 +475,22 @@ __global__ __launch_bounds__(kBlock) void k_total_u32(const uint32_t *__restrict
     if (lane_id() == 0 && t) atomicAdd(total, t);
 }
 
-// sup = own + other (64-bit total on the side)
+__global__ __launch_bounds__(kBlock) void k_back_cursors(const uint32_t *__restrict__ off, int64_t m, uint32_t *__restrict__ cursor)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e <= m; e += (int64_t)gridDim.x * kBlock)
+        cursor[e] = e < m ? off[e + 1] - 1u : 0u;
+}
+
+// sup = own + other (64-bit total on the side).  back_off: other[] holds back cursors that started at
+// back_off[e+1]-1 (k_back_cursors), so the third-role count is how far they moved.
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restrict__ own, const uint32_t *__restrict__ other,
+                                                       const uint32_t *__restrict__ back_off,
                                                        int64_t m1, uint32_t *__restrict__ sum, unsigned long long *__restrict__ total)
 {
     unsigned long long t = 0;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m1; e += (int64_t)gridDim.x * kBlock) {
-        const uint32_t c = own[e] + other[e];
+        const uint32_t oth = back_off == nullptr ? other[e] : (e + 1 < m1 ? back_off[e + 1] - 1u - other[e] : 0u);
+        const uint32_t c = own[e] + oth;
         sum[e] = c;
         t += c;
     }
@@ -884,7 +895,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
         if (single) {
             if (d_offc64) k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, ablate);
-            else k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, ablate);
+            else {
+                k_back_cursors<<<ge, kBlock, 0, s>>>(d_offc, m, d_other);
+                k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, ablate);
+            }
             st.ms_tri_fill = ctx->timer.stop(s);
             st.ms_tri_count = 0.0;
         } else {
@@ -898,7 +912,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, ablate);
         st.ms_tri_count = ctx->timer.stop(s);
     }
-    k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, m + 1, d_cnt, d_mom + 5);
+    k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, (single && !d_offc64) ? d_offc : nullptr, m + 1, d_cnt, d_mom + 5);
     if (!single && world > 1) {
         // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
         ctx->timer.start(s);
@@ -942,9 +956,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     } else {
         // second enumeration, same writer as the single-pass layout but into the EXACT slices: own-role
         // entries from the front and third-role entries from the back meet precisely -- no compaction
-        KOMB_HIP(ctx, hipMemsetAsync(d_other, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
         ctx->timer.start(s);
-        k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, ablate);
+        k_back_cursors<<<ge, kBlock, 0, s>>>(d_off, m, d_other);
+        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, ablate);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;
