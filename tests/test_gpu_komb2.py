@@ -106,3 +106,26 @@ def test_komb2_missing_input_is_fatal(tmp_path):
     r = subprocess.run([KOMB2, "-t", "1", "-o", str(tmp_path), "-i", "/nonexistent.sam", "-j", "x", "-u", "y"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "could not be opened" in r.stderr
+
+
+@pytest.mark.parametrize("mode", ["1", "fixed"])
+def test_komb2_v1_outputs_in_the_full_run(fixture, tmp_path, mode):
+    """KOMB_V1_OUTPUTS in the complete pipeline (combineFile after the k-core, splitAnomalousUnitigs after CoreA,
+    src/komb2.cpp:126,139): the three files follow from the kcore.tsv / CoreA_anomaly.txt of the same run."""
+    d, fasta, s1, s2 = fixture
+    out = tmp_path / "out"
+    out.mkdir()
+    cmd = f"{KOMB2} -t 4 -l -1 -o {out} -i {d}/reads1.fastq.sam -j {d}/reads2.fastq.sam -u {d}/unitigs.l-1.fasta"
+    r = subprocess.run(cmd, shell=True, executable="/bin/bash", capture_output=True, text=True,
+                       env=dict(os.environ, KOMB_V1_OUTPUTS=mode))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.index("Time elapsed for combineFile") < r.stdout.index("Identified anomalous unitigs") < r.stdout.index("Created anomalouss")
+    unitigs = samgraph.read_unitigs(fasta)
+    kcore = (out / "kcore.tsv").read_text()
+    corea = (out / "CoreA_anomaly.txt").read_text()
+    assert (out / "combined.fasta").read_text() == samgraph.combined_fasta(kcore, unitigs)
+    names = [ln.split("\t")[1] for ln in kcore.splitlines()[1:]]
+    top, low, _ = samgraph.split_anomalous(corea, unitigs, names if mode == "fixed" else None)
+    assert (out / "top_scoring_anomalous_unitigs.txt").read_text() == top
+    assert (out / "low_scoring_anomalous_unitigs.txt").read_text() == low
+    assert top and low
