@@ -251,7 +251,7 @@ def main():
             "setup_s": {"generate": t_gen, "graph_build_incl_h2d": t_build, "device_build_ms": st["ms_build"]},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     acc.close()
