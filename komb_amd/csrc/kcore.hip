@@ -12,6 +12,9 @@
 // Coreness is a unique integer per vertex, so peeling order inside a level
 // does not matter; results equal Batagelj-Zaversnik's.
 #include "peel_dev.h"
+#include "core_tail.h"
+
+#include <cstdlib>
 
 namespace komb {
 
@@ -132,8 +135,10 @@ int core_run(komb_ctx *ctx)
 
     const size_t heavy_cap = (size_t)(2 * ctx->ne) / 32 + 64;    // sum over units with > kLight items of ceil(items / kChunk) <= 3/128 of all items
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
+    CoreTailBufs T{};
     PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     auto cleanup = [&]() {
+        ctx->pool.put(T.livebits); ctx->pool.put(T.vnum); ctx->pool.put(T.cnt); ctx->pool.put(T.vlist); ctx->pool.put(T.rows);
         ctx->pool.put(d_degw); ctx->pool.put(d_ctrl); ctx->pool.put(d_grp); ctx->pool.put(Q.code);
         for (int i = 0; i < 2; ++i) { ctx->pool.put(Q.light[i]); ctx->pool.put(Q.heavy[i]); ctx->pool.put(Q.live[i]); }
     };
@@ -144,6 +149,18 @@ int core_run(komb_ctx *ctx)
     if (e == hipSuccess) e = ctx->pool.get((void **)&Q.code, (size_t)nv);
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_ctrl, sizeof(PeelCtrl));
     if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, (kInitOff + 2) * sizeof(uint32_t));
+    // hand-over threshold of the LDS tail (core_tail.h); KOMB_CORE_TAIL=0 keeps the whole peel in the general engine
+    uint32_t tail_limit = kCoreTailV;
+    if (const char *tl = getenv("KOMB_CORE_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
+    if (tail_limit > kCoreTailV) tail_limit = kCoreTailV;
+    const size_t live_words = ((size_t)nv + 63) / 64;
+    if (tail_limit) {
+        if (e == hipSuccess) e = ctx->pool.get((void **)&T.livebits, live_words * sizeof(unsigned long long));
+        if (e == hipSuccess) e = ctx->pool.get((void **)&T.vnum, (size_t)nv * sizeof(int32_t));
+        if (e == hipSuccess) e = ctx->pool.get((void **)&T.cnt, 4 * sizeof(uint32_t));
+        if (e == hipSuccess) e = ctx->pool.get((void **)&T.vlist, kCoreTailV * sizeof(int32_t));
+        if (e == hipSuccess) e = ctx->pool.get((void **)&T.rows, (size_t)kCoreTailV * kCoreTailWords * sizeof(unsigned long long));
+    }
     if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
 
     int64_t g = (nv + kBlock - 1) / kBlock;
@@ -153,12 +170,45 @@ int core_run(komb_ctx *ctx)
     ctx->timer.start(s);
     peel_ctrl_pre(s, d_grp);
     k_core_init<<<grid_init, kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_deg, d_degw, ctx->d_core, d_grp + kInitOff);
-    peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)nv);
-    int launches = 0;
-    int st = drive_peel(ctx, d_ctrl, nv, [&]() {
-        k_peel_step<CoreProblem><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
-    }, &launches);
+    peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)nv, tail_limit);
+    // the live vertices are those of `list` (or all nv when list is null) whose core[] is still an alive marker
+    auto run_tail = [&](const int32_t *list, uint32_t n_in) -> hipError_t {
+        hipError_t te = hipMemsetAsync(T.livebits, 0, live_words * sizeof(unsigned long long), s);
+        if (te == hipSuccess) te = hipMemsetAsync(T.cnt, 0, 4 * sizeof(uint32_t), s);
+        if (te != hipSuccess) return te;
+        int64_t gm = ((int64_t)n_in + kBlock - 1) / kBlock;
+        k_ctail_mark<<<(int)(gm < 1 ? 1 : (gm > 1024 ? 1024 : gm)), kBlock, 0, s>>>(list, n_in, ctx->d_core, T);
+        k_ctail_rows<<<(int)kCoreTailV, kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, T);
+        k_core_tail<<<1, 1024, 0, s>>>(d_ctrl, T, d_degw, ctx->d_core);
+        te = hipMemcpyAsync(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, s);
+        return te == hipSuccess ? hipStreamSynchronize(s) : te;
+    };
+    int launches = 0, st = KOMB_OK, tail_runs = 0;
+    hipError_t te = hipSuccess;
+    if (tail_limit && (uint64_t)nv <= tail_limit) {
+        // small graph: the tail takes the whole peel (unless nothing is left to peel)
+        te = hipMemcpyAsync(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, s);
+        if (te == hipSuccess) te = hipStreamSynchronize(s);
+        if (te == hipSuccess && !ctx->h_ctrl[0].done) { te = run_tail(nullptr, (uint32_t)nv); ++tail_runs; }
+    } else {
+        ctx->h_ctrl[0].done = 0;
+    }
+    for (int guard = 0; te == hipSuccess && st == KOMB_OK && ctx->h_ctrl[0].done != 1 && ctx->h_ctrl[0].done != 2 && guard < 64; ++guard) {
+        if (ctx->h_ctrl[0].done == 3) {
+            const PeelCtrl &c = ctx->h_ctrl[0];
+            te = c.live_mode ? run_tail(Q.live[c.live_sel], c.live_count) : run_tail(nullptr, (uint32_t)nv);
+            ++tail_runs;
+            continue;
+        }
+        int batch = 0;
+        st = drive_peel(ctx, d_ctrl, nv, [&]() {
+            k_peel_step<CoreProblem><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
+        }, &batch);
+        launches += batch;
+    }
     ctx->stats.ms_core = ctx->timer.stop(s);
+    (void)tail_runs;
+    if (te != hipSuccess) { cleanup(); KOMB_HIP(ctx, te); }
 #ifdef KOMB_STEP_TIMERS
     {
         const PeelCtrl &c = ctx->h_ctrl[0];

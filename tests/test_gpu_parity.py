@@ -409,3 +409,32 @@ def test_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
                 ran += st["truss_tail_runs"]
             assert ran > 0 or want.max() <= 2, nv
     monkeypatch.delenv("KOMB_TAIL", raising=False)
+
+
+def test_core_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
+    """The single-workgroup LDS tail of the k-core peel (core_tail.h) against the general engine
+    (KOMB_CORE_TAIL=0) and the oracle: whole small graphs, hand-over in mid-peel at several thresholds."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for nv, ne in ((50, 400), (700, 20000), (1024, 60000), (5000, 100000)):
+        cases.append((nv, rng.integers(0, nv, (ne, 2)).astype(np.int64)))
+    cases.append((60000, K.gen_hug_edges(60000, 160000, 2.3, 12)))
+    cases.append((300000, K.gen_hug_edges(300000, 740000, 2.6, 13)))
+    for n in (30, 500):
+        cases.append((n, np.stack(np.triu_indices(n, 1), axis=1).astype(np.int64)))
+    star = np.stack([np.zeros(3000, np.int64), np.arange(1, 3001)], axis=1)            # a hub row far longer than the tail
+    cases.append((3001, np.concatenate([star, np.stack(np.triu_indices(40, 1), axis=1) + 1]).astype(np.int64)))
+    for nv, uv in cases:
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            rowptr, col = a.get_csr()
+            want = O.coreness(rowptr, col)
+            for limit in ("0", None, "300", "17"):
+                if limit is None:
+                    monkeypatch.delenv("KOMB_CORE_TAIL", raising=False)
+                else:
+                    monkeypatch.setenv("KOMB_CORE_TAIL", limit)
+                deg, core = a.run_core()
+                assert np.array_equal(core, want), (nv, limit)
+                assert a.stats()["max_coreness"] == want.max()
+    monkeypatch.delenv("KOMB_CORE_TAIL", raising=False)
