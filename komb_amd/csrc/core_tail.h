@@ -43,26 +43,33 @@ __global__ __launch_bounds__(kBlock) void k_ctail_mark(const int32_t *__restrict
     }
 }
 
-// ---- setup 2: one workgroup per live vertex scans its CSR row against the live bitmap
+// ---- setup 2: the CSR rows of the live vertices against the live bitmap.  blockIdx.x = live vertex,
+// blockIdx.y = which share of the row's 4096-slot pieces (a 134k-slot hub row is the critical path of the
+// hand-over when one workgroup walks it alone); the pieces' bits are OR-ed into the zeroed global rows
+constexpr uint32_t kCtailPiece = 4096;
 __global__ __launch_bounds__(kBlock) void k_ctail_rows(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, CoreTailBufs T)
 {
     __shared__ unsigned long long row[kCoreTailWords];
     const uint32_t n = T.cnt[0];
     if (n > kCoreTailV) return;
     for (uint32_t id = blockIdx.x; id < n; id += gridDim.x) {
-        if (threadIdx.x < kCoreTailWords) row[threadIdx.x] = 0ull;
-        __syncthreads();
         const int32_t v = T.vlist[id];
         const uint32_t b = rowptr[v], e = rowptr[v + 1];
-        for (uint32_t j = b + threadIdx.x; j < e; j += kBlock) {
-            const uint32_t w = (uint32_t)col[j];
-            if ((T.livebits[w >> 6] >> (w & 63)) & 1ull) {
-                const uint32_t x = (uint32_t)T.vnum[w] - 1u;
-                atomicOr(&row[x >> 6], 1ull << (x & 63));
+        if (b + blockIdx.y * kCtailPiece >= e) continue;                 // uniform for the workgroup
+        if (threadIdx.x < kCoreTailWords) row[threadIdx.x] = 0ull;
+        __syncthreads();
+        for (uint32_t p0 = b + blockIdx.y * kCtailPiece; p0 < e; p0 += gridDim.y * kCtailPiece) {
+            const uint32_t p1 = min(e, p0 + kCtailPiece);
+            for (uint32_t j = p0 + threadIdx.x; j < p1; j += kBlock) {
+                const uint32_t w = (uint32_t)col[j];
+                if ((T.livebits[w >> 6] >> (w & 63)) & 1ull) {
+                    const uint32_t x = (uint32_t)T.vnum[w] - 1u;
+                    atomicOr(&row[x >> 6], 1ull << (x & 63));
+                }
             }
         }
         __syncthreads();
-        if (threadIdx.x < kCoreTailWords) T.rows[(size_t)id * kCoreTailWords + threadIdx.x] = row[threadIdx.x];
+        if (threadIdx.x < kCoreTailWords && row[threadIdx.x]) atomicOr(&T.rows[(size_t)id * kCoreTailWords + threadIdx.x], row[threadIdx.x]);
         __syncthreads();
     }
 }

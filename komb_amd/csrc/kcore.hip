@@ -175,10 +175,11 @@ int core_run(komb_ctx *ctx)
     auto run_tail = [&](const int32_t *list, uint32_t n_in) -> hipError_t {
         hipError_t te = hipMemsetAsync(T.livebits, 0, live_words * sizeof(unsigned long long), s);
         if (te == hipSuccess) te = hipMemsetAsync(T.cnt, 0, 4 * sizeof(uint32_t), s);
+        if (te == hipSuccess) te = hipMemsetAsync(T.rows, 0, (size_t)kCoreTailV * kCoreTailWords * sizeof(unsigned long long), s);
         if (te != hipSuccess) return te;
         int64_t gm = ((int64_t)n_in + kBlock - 1) / kBlock;
         k_ctail_mark<<<(int)(gm < 1 ? 1 : (gm > 1024 ? 1024 : gm)), kBlock, 0, s>>>(list, n_in, ctx->d_core, T);
-        k_ctail_rows<<<(int)kCoreTailV, kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, T);
+        k_ctail_rows<<<dim3(kCoreTailV, 8), kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, T);
         k_core_tail<<<1, 1024, 0, s>>>(d_ctrl, T, d_degw, ctx->d_core);
         te = hipMemcpyAsync(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, s);
         return te == hipSuccess ? hipStreamSynchronize(s) : te;
