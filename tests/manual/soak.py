@@ -1,0 +1,59 @@
+"""Randomised soak: many graphs of assorted shapes, k-core and k-truss (with support) against the CPU oracle,
+each under a random choice of the hand-over thresholds of the two LDS tails and of the index layout.
+    python tests/manual/soak.py [n_graphs] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import komb_amd
+from oracle import oracle as O
+
+n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+t0 = time.time()
+bad = 0
+with komb_amd.KombAccel() as a:
+    for g in range(n_graphs):
+        kind = rng.integers(0, 5)
+        if kind == 0:                                   # sparse random
+            nv = int(rng.integers(2, 4000)); ne = int(rng.integers(1, 6 * nv))
+            uv = rng.integers(0, nv, (ne, 2))
+        elif kind == 1:                                 # dense random
+            nv = int(rng.integers(3, 400)); ne = int(rng.integers(nv, nv * nv // 3 + 2))
+            uv = rng.integers(0, nv, (ne, 2))
+        elif kind == 2:                                 # union of cliques + noise (unitig-graph like)
+            nv = int(rng.integers(20, 3000)); parts = []
+            for _ in range(int(rng.integers(1, 60))):
+                k = int(rng.integers(2, 40)); vs = rng.choice(nv, size=min(k, nv), replace=False)
+                iu = np.triu_indices(len(vs), 1); parts.append(np.stack([vs[iu[0]], vs[iu[1]]], axis=1))
+            parts.append(rng.integers(0, nv, (int(rng.integers(0, 2 * nv)), 2)))
+            uv = np.concatenate(parts)
+        elif kind == 3:                                 # generator of the benchmark
+            nv = int(rng.integers(100, 30000))
+            uv = np.asarray(komb_amd.gen_hug_edges(nv, int(nv * rng.uniform(1.0, 4.0)), float(rng.uniform(2.1, 3.0)), int(rng.integers(1, 1 << 30)))).reshape(-1, 2)
+        else:                                           # hub + core: a star over a dense core
+            nv = int(rng.integers(50, 5000)); c = int(rng.integers(5, min(nv, 300)))
+            iu = np.triu_indices(c, 1); core = np.stack(iu, axis=1)
+            keep = rng.random(len(core)) < rng.uniform(0.2, 1.0)
+            star = np.stack([np.zeros(nv - 1, np.int64), np.arange(1, nv)], axis=1)
+            uv = np.concatenate([core[keep], star, rng.integers(0, nv, (nv, 2))])
+        uv = np.ascontiguousarray(uv, dtype=np.int64)
+        os.environ["KOMB_TAIL"] = str(rng.choice([0, 50, 700, 5000, 32768, 65534]))
+        os.environ["KOMB_CORE_TAIL"] = str(rng.choice([0, 9, 200, 1024]))
+        for k, on in (("KOMB_TWO_PASS", rng.random() < 0.3), ("KOMB_OFF64", rng.random() < 0.3)):
+            if on: os.environ[k] = "1"
+            else: os.environ.pop(k, None)
+        a.from_edges(nv, uv)
+        rowptr, col = a.get_csr()
+        deg, core = a.run_core()
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        ok = (np.array_equal(core, O.coreness(rowptr, col)) and np.array_equal(sup, O.support(rowptr, col)[0])
+              and np.array_equal(tr, O.trussness(rowptr, col)))
+        if not ok:
+            bad += 1
+            np.save(f"gpurun_out/soak_fail_{g}.npy", uv)
+            print(f"MISMATCH graph {g} kind {kind} nv {nv} env TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
+                  f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')}", flush=True)
+        if g % 100 == 99:
+            print(f"{g + 1} graphs, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {n_graphs} graphs, {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
