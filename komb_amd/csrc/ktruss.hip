@@ -988,7 +988,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     TailBufs T{};
     if (tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
-        KOMB_HIP(ctx, bufs.alloc(&T.cnt, 16));
+        KOMB_HIP(ctx, bufs.alloc(&T.cnt, 64));
         KOMB_HIP(ctx, bufs.alloc(&T.vlist, (size_t)kTailMaxV));
         KOMB_HIP(ctx, bufs.alloc(&T.rows, (size_t)kTailMaxV * kTailRowWords));
         KOMB_HIP(ctx, bufs.alloc(&T.pair, (size_t)tail_limit));
@@ -1004,7 +1004,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // the live edges are those of `list` (or all m when list is null) whose stamp is still an alive marker
     auto run_tail = [&](const int32_t *list, uint32_t n_in) -> int {
         KOMB_HIP(ctx, hipMemsetAsync(T.vmap, 0, (size_t)nv * sizeof(int32_t), s));
-        KOMB_HIP(ctx, hipMemsetAsync(T.cnt, 0, 8 * sizeof(uint32_t), s));
+        KOMB_HIP(ctx, hipMemsetAsync(T.cnt, 0, 64 * sizeof(uint32_t), s));
         KOMB_HIP(ctx, hipMemsetAsync(T.rows, 0, (size_t)kTailMaxV * kTailRowWords * sizeof(unsigned long long), s));
         const int g = grid_for(n_in, kBlock, 256);
         // KOMB_TAIL_DEBUG=1: one line per hand-over on stderr (HIP-event times; building with -DKOMB_TAIL_TIMERS

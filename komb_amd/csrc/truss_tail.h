@@ -35,7 +35,8 @@ constexpr uint32_t kTFrontier = 0xFFFFu, kTDead = 0xFFFEu;   // support values a
 
 struct TailBufs {
     int32_t *vmap;                 // [nv]        0, or tail vertex number + 1
-    uint32_t *cnt;                 // [8]         0: vertices, 1: live edges, 2: refused, 3: edges written
+    uint32_t *cnt;                 // [64]        0: vertices, 1: live edges, 2: refused, 3: edges written, 4-5: sum of the live
+                                   //             supports (64-bit), 8-15: timers, 16-47: which support values occur (1024 bits)
     int32_t *vlist;                // [kTailMaxV] original ids of the tail vertices
     unsigned long long *rows;      // [kTailMaxV * kTailRowWords] adjacency bits, stride kTailRowWords
     uint32_t *pair;                // [E] (lo << 16) | hi, tail vertex numbers
@@ -49,15 +50,22 @@ struct TailBufs {
 };
 
 // ---- setup 1: number the endpoints of the live edges, count the edges
-__global__ __launch_bounds__(kBlock) void k_tail_mark(const int32_t *__restrict__ list, uint32_t n_in, const int32_t *__restrict__,
+__global__ __launch_bounds__(kBlock) void k_tail_mark(const int32_t *__restrict__ list, uint32_t n_in, const int32_t *__restrict__ sup,
                                                       const int32_t *__restrict__ stamp,
                                                       const int32_t *__restrict__ osrc, const int32_t *__restrict__ ocol, TailBufs T)
 {
+    __shared__ uint32_t seen[32];                       // which support values this workgroup met (1024 bits)
+    if (threadIdx.x < 32) seen[threadIdx.x] = 0u;
+    __syncthreads();
     uint32_t live = 0;
+    unsigned long long work = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_in; i += gridDim.x * kBlock) {
         const int32_t e = list ? list[i] : (int32_t)i;
         if (!marker_alive(stamp[e])) continue;
         ++live;
+        const uint32_t sv = (uint32_t)sup[e];
+        work += sv;
+        atomicOr(&seen[min(sv, 1023u) >> 5], 1u << (min(sv, 1023u) & 31u));
         const int32_t ab[2] = {osrc[e], ocol[e]};
         for (int k = 0; k < 2; ++k)
             if (atomicExch(&T.vmap[ab[k]], 1) == 0) {
@@ -66,16 +74,38 @@ __global__ __launch_bounds__(kBlock) void k_tail_mark(const int32_t *__restrict_
             }
     }
     live = wave_sum(live);
-    if (lane_id() == 0 && live) atomicAdd(&T.cnt[1], live);
+    for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
+    if (lane_id() == 0 && live) {
+        atomicAdd(&T.cnt[1], live);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&T.cnt[4]), work);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && seen[threadIdx.x]) atomicOr(&T.cnt[16 + threadIdx.x], seen[threadIdx.x]);
 }
 
 // ---- setup 2 (one workgroup): vertex numbers in ascending original id (deterministic whatever order
-// setup 1's atomics ran in), or refusal
+// setup 1's atomics ran in), or refusal.
+// Refusal also when one workgroup would be the slower choice.  The tail visits every live triangle from each of
+// its edges once (the sum S of the live supports) at ~0.8 M per ms and pays ~5 us per sub-round; the general engine
+// pays ~20 us per sub-round but has the whole chip for the triangles (~13 G per s).  With D distinct live support
+// values (about the number of levels left, ~12-14 sub-rounds each) the tail wins when S / 800 + 70 D < 240 D + S / 13000
+// (microseconds), i.e. S < ~145 000 D: a clique-like remainder (K_250: S = 7.7 M, D = 1 -- 9 ms here, 0.3 ms
+// there) stays with the general engine, the many-level dense cores of power-law graphs do not.
+constexpr unsigned long long kTailWorkPerLevel = 145000ull;
 __global__ __launch_bounds__(kTailMaxV) void k_tail_number(TailBufs T)
 {
     __shared__ int32_t ids[kTailMaxV];
+    __shared__ uint32_t distinct;
     const uint32_t n = T.cnt[0], ne = T.cnt[1];
-    if (n > kTailMaxV || ne > kTailMaxEdges || ne > T.max_edges || ne == 0) { if (threadIdx.x == 0) T.cnt[2] = 1u; return; }
+    if (threadIdx.x == 0) distinct = 0;
+    __syncthreads();
+    if (threadIdx.x < 32) atomicAdd(&distinct, (uint32_t)__popc(T.cnt[16 + threadIdx.x]));
+    __syncthreads();
+    const unsigned long long work = *reinterpret_cast<const unsigned long long *>(&T.cnt[4]);
+    if (n > kTailMaxV || ne > kTailMaxEdges || ne > T.max_edges || ne == 0 || work > kTailWorkPerLevel * distinct) {
+        if (threadIdx.x == 0) T.cnt[2] = 1u;
+        return;
+    }
     const uint32_t t = threadIdx.x;
     if (t < n) ids[t] = T.vlist[t];
     __syncthreads();

@@ -373,8 +373,9 @@ def test_full_size_c3_known_answer(K, O):
 
 def test_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
     """The single-workgroup LDS tail (truss_tail.h) against the general engine (KOMB_TAIL=0) and the oracle:
-    whole small graphs, hand-over in mid-peel at several thresholds, refusal (too many vertices),
-    frontier spill beyond the LDS queues (a clique peels all its edges in one sub-round)."""
+    whole small graphs, hand-over in mid-peel at several thresholds, refusal (too many vertices; or a clique-like
+    remainder, which the tail's cost model leaves to the general engine).  The spill of a frontier beyond the LDS
+    queues is exercised by the full-size C3 run (656 LDS queue entries there)."""
     rng = np.random.default_rng(5)
     cases = []
     for nv, ne in ((60, 900), (400, 14000), (900, 30000), (3000, 90000)):
@@ -407,7 +408,8 @@ def test_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
                 assert np.array_equal(tr, want), (nv, limit)
                 assert st["max_trussness"] == want.max()
                 ran += st["truss_tail_runs"]
-            assert ran > 0 or want.max() <= 2, nv
+            clique = len(want) == nv * (nv - 1) // 2
+            assert ran > 0 or want.max() <= 2 or clique, nv
     monkeypatch.delenv("KOMB_TAIL", raising=False)
 
 
