@@ -82,21 +82,42 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-build", action="store_true",
+                    help="load the prebuilt libkomb_accel.so, spawn no compiler (use under rocprofv3)")
     ap.add_argument("--faithful", action="store_true",
                     help="also time the runTruss-faithful variant (max-core induced subgraph); off by default so that a "
                          "rocprofv3 run of the default command sees only the timed workload's launches")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as entry
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: start one rank per GPU ourselves -- as a CHILD process and
+        # before anything in this one has touched the GPU -- and leave with its exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # the native pieces are built first: nothing has initialised the GPU yet, so the compiler children are
+    # not spawned from a GPU-holding (or, under rocprofv3, profiler-preloaded: use --no-build there) process
+    import __graft_entry__ as entry
+    if rank == 0 and not args.no_build:
+        entry.build()
+
+    import datetime
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the komb_accel path has no CPU fallback")
     # rehearsal hook (tests only): several ranks on ONE GPU, collectives over gloo
@@ -105,31 +126,33 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     exchange = "single GPU"
+    data_group = None                       # the group the support vectors are summed over
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            exchange = "gloo through host memory (one-device rehearsal)"
-        else:
+        # control plane (barriers, the max over the ranks' times) on gloo; the data exchange on RCCL when every
+        # rank can use it -- the choice is made collectively (MIN over the ranks' flags), never rank by rank
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # ranks != 0 wait here for rank 0's build
+        ok = 0
+        why = "one-device rehearsal"
+        if not one_device:
             try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
                 probe = torch.ones(1, dtype=torch.int32, device="cuda")
-                dist.all_reduce(probe)
+                dist.all_reduce(probe, group=data_group)
                 torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"RCCL probe all-reduce returned {int(probe.item())}, expected {world}")
-                exchange = "RCCL all-reduce in place on the device buffer"
-            except Exception as exc:  # noqa: BLE001 - keep the scaling run alive, say what happened
-                print(f"bench.py: RCCL unavailable ({exc!r}); falling back to gloo through host memory", file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-                exchange = f"gloo through host memory (RCCL unavailable: {type(exc).__name__})"
-    host_exchange = world > 1 and dist.get_backend() == "gloo"
-    if rank == 0:
-        entry.build()
+                ok = 1 if int(probe.item()) == world else 0
+                why = "" if ok else f"probe all-reduce returned {int(probe.item())}"
+            except (RuntimeError, dist.DistBackendError) as exc:
+                why = f"{type(exc).__name__}: {exc}"
+                print(f"bench.py rank {rank}: RCCL unavailable ({why})", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            exchange = "RCCL all-reduce in place on the device buffer"
+        else:
+            data_group = None
+            exchange = f"gloo through host memory ({why or 'RCCL unavailable on another rank'})"
+    host_exchange = world > 1
     if world > 1:
         dist.barrier()
     import komb_amd
@@ -156,7 +179,7 @@ def main():
 
     def step():
         if world > 1:
-            kd.truss_run_sharded(acc)            # support phase sharded by vertex range + RCCL all-reduce
+            kd.truss_run_sharded(acc, group=data_group)   # support phase sharded by vertex range + all-reduce
         else:
             acc.truss_run()
 
@@ -164,7 +187,8 @@ def main():
         step()
     barrier_sync()
     t0 = time.perf_counter()
-    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_compact", "ms_peel", "ms_tail", "ms_gather")}
+    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_compact", "ms_peel", "ms_tail",
+                              "ms_truss_local", "ms_gather")}
     for _ in range(args.steps):
         step()
         s = acc.stats()
@@ -173,7 +197,7 @@ def main():
     barrier_sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_exchange else "cuda")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = acc.stats()
@@ -205,9 +229,11 @@ def main():
         ab = algorithmic_bytes(st)
         # the peel = the launches of k_peel_step<Truss> (all of them, including the no-op launches of the last blind
         # batch, as rocprofv3 counts them) + the single-workgroup LDS tail (setup kernels + k_truss_tail)
-        kernels = {"k_peel_step<Truss>": (phase["ms_peel"] - phase["ms_tail"], st["truss_launches"], ab["peel"])}
+        kernels = {"k_peel_step<Truss>": (phase["ms_peel"] - phase["ms_tail"] - phase["ms_truss_local"], st["truss_launches"], ab["peel"])}
         if st["truss_tail_runs"]:
             kernels["k_truss_tail"] = (phase["ms_tail"], st["truss_tail_runs"], 0)
+        if st["truss_local_units"]:
+            kernels["local finish (number + collect + k_local_step sweeps)"] = (phase["ms_truss_local"], st["truss_local_sweeps"], 0)
         if phase["ms_tri_count"] > 0:            # exact two-pass layout (sharded runs, or bounded index too large)
             kernels["k_triangles<count>"] = (phase["ms_tri_count"], 1, ab["tri_count"])
             kernels["k_triangles<single> (exact slices)"] = (phase["ms_tri_fill"], 1, ab["tri_fill"])
@@ -229,6 +255,13 @@ def main():
             "per_kernel": {k: {"ms_per_step": v[0], "launches": v[1], "alg_bytes": v[2],
                                "GBps": (v[2] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in kernels.items()},
             "survey_formula_peel_bytes": ab["survey_peel"],
+            # SURVEY 8(d) verbatim: B_sup over the enumeration's time, and the whole step's algorithmic bytes
+            # (B_sup + index stores + compaction + peel) over the whole step
+            "survey_B_sup_bytes": ab["tri_count"],
+            "survey_B_sup_frac": (ab["tri_count"] / ((phase["ms_tri_fill"] + phase["ms_tri_count"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                  if phase["ms_tri_fill"] + phase["ms_tri_count"] > 0 else None),
+            "whole_step_bytes": sum(v[2] for v in kernels.values()),
+            "whole_step_frac": sum(v[2] for v in kernels.values()) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }
         out = {
             "metric": "peeled edges/sec (k-truss)", "value": ne * args.steps / dt,
@@ -240,11 +273,15 @@ def main():
                        "max_coreness": core_stats["max_coreness"],
                        "truss_levels": st["truss_levels"], "truss_subrounds": st["truss_subrounds"],
                        "truss_scans": st["truss_scans"], "truss_launches": st["truss_launches"],
+                       "truss_local": {"edges": st["truss_local_units"], "index_entries": st["truss_local_items"],
+                                       "sweeps": st["truss_local_sweeps"]},
                        "parallelism": "single" if world == 1 else
                        f"same graph on {world} ranks: support phase sharded by source-vertex range + one all-reduce ({exchange}), index/peel replicated"},
             "phases_ms": phase,
             "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
                       "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],
+                      "local": {"vertices": core_stats["core_local_units"], "index_entries": core_stats["core_local_items"],
+                                "sweeps": core_stats["core_local_sweeps"], "ms": core_stats["ms_core_local"]},
                       "alg_bytes": 16 * nv + 24 * ne,
                       "GBps": (16 * nv + 24 * ne) / (core_ms * 1e-3) / 1e9 if core_ms > 0 else None},
             "runtruss_faithful": faithful,

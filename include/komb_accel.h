@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KOMB_ACCEL_ABI_VERSION 1
+#define KOMB_ACCEL_ABI_VERSION 2
 
 typedef enum komb_status {
     KOMB_OK          =  0,
@@ -69,6 +69,12 @@ typedef struct komb_stats {
     double  ms_gather;              /* truss: canonical-order result gather           */
     double  ms_corea;               /* a9/a10: CoreA rank kernels                     */
     double  ms_tail;                /* truss: setup + LDS tail kernel, part of ms_peel */
+    /* local finish (h-index fixed point on the remainder the peel hands over; ABI version 2) */
+    int64_t core_local_items, truss_local_items;   /* entries of the compact index            */
+    int32_t core_local_units, core_local_sweeps;   /* vertices handed over; sweeps to the fixed point */
+    int32_t truss_local_units, truss_local_sweeps; /* edges handed over; sweeps                */
+    double  ms_core_local;          /* part of ms_core: numbering + collect + sweeps + scatter */
+    double  ms_truss_local;         /* part of ms_peel                                         */
 } komb_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -35,6 +35,10 @@ class KombStats(ctypes.Structure):
         ("ms_support", ctypes.c_double),
         ("ms_allreduce", ctypes.c_double),
         ("ms_peel", ctypes.c_double), ("ms_gather", ctypes.c_double), ("ms_corea", ctypes.c_double), ("ms_tail", ctypes.c_double),
+        ("core_local_items", ctypes.c_int64), ("truss_local_items", ctypes.c_int64),
+        ("core_local_units", ctypes.c_int32), ("core_local_sweeps", ctypes.c_int32),
+        ("truss_local_units", ctypes.c_int32), ("truss_local_sweeps", ctypes.c_int32),
+        ("ms_core_local", ctypes.c_double), ("ms_truss_local", ctypes.c_double),
     ]
 
 

@@ -50,6 +50,7 @@ komb_ctx *komb_create(const komb_opts *opts)
     }
     e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctrl, 2 * sizeof(PeelCtrl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_local, 2 * sizeof(LocalCtrl), hipHostMallocDefault);
     if (e == hipSuccess && !ctx->timer.init()) e = hipErrorUnknown;
     if (e != hipSuccess) {
         ctx->err = std::string("device initialisation failed: ") + hipGetErrorString(e);
@@ -69,6 +70,7 @@ void komb_destroy(komb_ctx *ctx)
         ctx->pool.clear();
         ctx->timer.destroy();
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
+        if (ctx->h_local) (void)hipHostFree(ctx->h_local);
     }
     delete ctx;
 }

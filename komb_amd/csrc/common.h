@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,42 @@ struct PeelCtrl {
     uint32_t pad1[8];
 };
 static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
+
+// Device-side control block of the local finish (local_dev.h): an h-index fixed point on the remainder
+// the peel hands over.  64 bytes, device resident; the host keeps two pinned mirrors.
+struct LocalCtrl {
+    int32_t  done;           // 1 once a sweep changed nothing
+    int32_t  iters;          // sweeps run (including the one that changed nothing)
+    uint32_t chg[3];         // units whose value dropped in sweep k: chg[k % 3]
+    uint32_t bad;            // consistency failures (a compact slice whose fill differs from the live key, ...)
+    int32_t  max_val;        // largest final value (k_local_finish)
+    uint32_t levels;         // distinct final values (k_local_levels)
+    uint32_t evals;          // unit evaluations, all sweeps
+    uint32_t n_light, n_heavy;   // numbering counters (k_local_number)
+    uint32_t pad[5];
+};
+static_assert(sizeof(LocalCtrl) == 64, "LocalCtrl layout");
+
+// How a peel ends (KOMB_FINISH): "local" (default) hands the remainder to the h-index fixed point of
+// local_dev.h once at most KOMB_LOCAL_LIMIT units (default: a fraction of all units) are left at a level
+// boundary; "lds" uses the single-workgroup LDS tails (truss_tail.h, core_tail.h; thresholds KOMB_TAIL /
+// KOMB_CORE_TAIL); "none" keeps the whole peel in the general engine.  None of them changes a result.
+enum FinishMode : int { FIN_LOCAL = 0, FIN_LDS = 1, FIN_NONE = 2 };
+inline FinishMode finish_mode()
+{
+    const char *e = getenv("KOMB_FINISH");
+    if (e && !strcmp(e, "lds")) return FIN_LDS;
+    if (e && !strcmp(e, "none")) return FIN_NONE;
+    return FIN_LOCAL;
+}
+inline uint32_t local_limit(uint64_t units, uint64_t divisor)
+{
+    uint64_t l = units / divisor;
+    if (l < 4096) l = 4096;                  // small inputs go to the fixed point whole
+    if (const char *e = getenv("KOMB_LOCAL_LIMIT")) l = strtoull(e, nullptr, 10);
+    if (l > units) l = units;
+    return (uint32_t)l;
+}
 
 struct Timer {                               // HIP-event stopwatch on one stream
     hipEvent_t a = nullptr, b = nullptr;
@@ -139,10 +176,32 @@ struct komb_ctx {
     int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr; // canonical order
     bool truss_done = false;
 
-    // ---- pinned host mirror of the control block (double buffered)
+    // ---- pinned host mirrors of the control blocks (double buffered)
     komb::PeelCtrl *h_ctrl = nullptr;        // [2]
+    komb::LocalCtrl *h_local = nullptr;      // [2]
 
     komb_stats stats{};
+};
+
+// Scratch buffers of one stage: everything still owned goes back to the context's pool on scope exit.
+struct DevBufs {
+    komb_ctx *ctx;
+    std::vector<void *> owned;
+    explicit DevBufs(komb_ctx *c) : ctx(c) {}
+    DevBufs(const DevBufs &) = delete;
+    DevBufs &operator=(const DevBufs &) = delete;
+    template <class T> hipError_t alloc(T **out, size_t count)
+    {
+        void *q = nullptr;
+        hipError_t e = ctx->pool.get(&q, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) { owned.push_back(q); *out = (T *)q; }
+        return e;
+    }
+    void release(void *q)
+    {
+        for (auto &p : owned) if (p == q && q) { ctx->pool.put(q); p = nullptr; }
+    }
+    ~DevBufs() { for (void *p : owned) if (p) ctx->pool.put(p); }
 };
 
 // ---- error plumbing -------------------------------------------------------
@@ -171,6 +230,13 @@ struct komb_ctx {
         if (_s != KOMB_OK) return _s;          \
     } while (0)
 
+// small blocking device-to-host read, ordered on the context's stream
+inline hipError_t d2h(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+}
+
 // ---- primitives implemented in prims.hip (rocPRIM/hipCUB behind plain signatures)
 namespace komb {
 int prim_sort_u64(komb_ctx *ctx, uint64_t *keys, uint64_t *tmp_keys, int64_t n, int end_bit, uint64_t **sorted);
@@ -189,6 +255,7 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
 void graph_free(komb_ctx *ctx);
 void truss_free(komb_ctx *ctx);
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done);
+void peel_collect_ctrl(hipStream_t s, PeelCtrl *d_collect, const PeelCtrl *d_from);
 void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units, uint32_t tail_limit = 0);
 int peel_grid(int64_t units);
 
@@ -201,16 +268,21 @@ template <typename F>
 int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *launches_out)
 {
     constexpr int kBatch = 24;
+#ifdef KOMB_DEBUG_SWITCHES
     if (const char *tr = getenv("KOMB_PEEL_TRACE")) {
         // debug: one launch at a time; append "mode level round light heavy live_mode live_count remaining us" per step
         FILE *f = fopen(tr, "a");
-        hipEvent_t a, b;
-        KOMB_HIP(ctx, hipEventCreate(&a)); KOMB_HIP(ctx, hipEventCreate(&b));
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            if (f) fclose(f);
+            if (a) (void)hipEventDestroy(a);
+            KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel trace: hipEventCreate failed");
+        }
         int launches = 0;
         if (f) fprintf(f, "# peel units=%lld\n", (long long)units);
         for (int64_t i = 0; i < 4 * units + 4096; ++i) {
             PeelCtrl before;
-            KOMB_HIP(ctx, hipMemcpy(&before, d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost));
+            if (hipMemcpy(&before, d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost) != hipSuccess) break;
             if (before.done) break;
             (void)hipEventRecord(a, ctx->stream);
             launch(); ++launches;
@@ -227,6 +299,7 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
         KOMB_HIP(ctx, hipMemcpy(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost));
         return KOMB_OK;
     }
+#endif
     hipEvent_t ev[2] = {nullptr, nullptr};
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));

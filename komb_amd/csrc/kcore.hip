@@ -13,6 +13,7 @@
 // does not matter; results equal Batagelj-Zaversnik's.
 #include "peel_dev.h"
 #include "core_tail.h"
+#include "local_dev.h"
 
 #include <cstdlib>
 
@@ -79,6 +80,92 @@ struct CoreProblem {
     }
 };
 
+// ---- hand-over to the local finish (local_dev.h)
+// Collect pass: the peel engine run once over all live vertices; a live neighbour of a live vertex becomes an
+// entry of the compact row (ids of the remainder).  Liveness of the neighbour comes from a bitmap (nv / 8 bytes,
+// L2-resident) instead of a gather into core[].
+struct CoreCollect {
+    static constexpr bool kChain = false;
+    uint32_t units;
+    const uint32_t *rowptr;
+    const int32_t *col;
+    const int32_t *core;                 // alive markers
+    const unsigned long long *livebits;
+    const int32_t *num;                  // [nv] id in the remainder (live vertices only)
+    const uint32_t *off;                 // [n+1] compact row offsets
+    uint32_t *cur;                       // [n] fill cursors
+    uint32_t *nbr;                       // compact rows
+
+    __device__ __forceinline__ bool scan_probe(uint32_t v, int32_t &key, uint32_t &nch) const
+    {
+        const int32_t c = core[v];
+        key = 0;                         // every live vertex enters the one frontier of this pass
+        nch = marker_chunks(c);
+        return marker_alive(c);
+    }
+    __device__ __forceinline__ void mark_scanned(uint32_t, const CtrlView &) const {}
+    __device__ __forceinline__ void slice(uint32_t v, uint32_t &b, uint32_t &len) const
+    {
+        b = rowptr[v];
+        len = rowptr[v + 1] - b;
+    }
+    struct Loaded { int32_t me, u; bool live; };
+    __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
+    {
+        Loaded ld;
+        ld.me = me;
+        ld.u = col[pos];
+        ld.live = (livebits[(uint32_t)ld.u >> 6] >> ((uint32_t)ld.u & 63u)) & 1ull;
+        return ld;
+    }
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &, int32_t &, int32_t &, uint32_t &, uint32_t &) const
+    {
+        if (!ld.live) return;
+        const uint32_t id = (uint32_t)num[ld.me];
+        nbr[off[id] + atomicAdd(&cur[id], 1u)] = (uint32_t)num[ld.u];
+    }
+};
+
+// Fixed-point problem: item = a live neighbour, value = its current bound.
+struct CoreLocal {
+    static constexpr int kU = 4;         // light unit: <= 256 live neighbours
+    const uint32_t *nbr;
+    struct Item { uint32_t a; int32_t va; };
+    __device__ __forceinline__ Item load(uint32_t pos, const int32_t *val) const
+    {
+        Item it;
+        it.a = nbr[pos];
+        it.va = val[it.a];
+        return it;
+    }
+    static __device__ __forceinline__ int32_t value(const Item &it) { return it.va; }
+    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t *mark, int32_t next)
+    {
+        if (it.va > h) mark[it.a] = next;
+    }
+};
+
+__global__ void k_live_bits(const int32_t *__restrict__ gid, uint32_t n, unsigned long long *__restrict__ bits)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = (uint32_t)gid[i];
+        atomicOr(&bits[v >> 6], 1ull << (v & 63u));
+    }
+}
+
+// control block of a collect pass: one SCAN over the live units of `from` (everything is a hit), one PROCESS
+__global__ void k_collect_ctrl(PeelCtrl *c2, const PeelCtrl *from)
+{
+    if (threadIdx.x == 0) {
+        PeelCtrl c{};
+        c.mode = MODE_SCAN; c.round = 1; c.level = 0x3FFFFFFF;
+        c.remaining = from->remaining;
+        c.live_mode = from->live_mode; c.live_sel = from->live_sel; c.live_count = from->live_count;
+        c.next_min = 0x7FFFFFFF;
+        *c2 = c;
+    }
+}
+
 // grp_done[kInitOff] = #units peeled by the init kernel, grp_done[kInitOff+1] = min live key
 __global__ void k_ctrl_pre(uint32_t *grp_done)
 {
@@ -105,6 +192,7 @@ __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t u
 } // namespace
 
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done) { k_ctrl_pre<<<1, 128, 0, s>>>(d_grp_done); }
+void peel_collect_ctrl(hipStream_t s, PeelCtrl *d_collect, const PeelCtrl *d_from) { k_collect_ctrl<<<1, 64, 0, s>>>(d_collect, d_from); }
 
 void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units, uint32_t tail_limit)
 {
@@ -129,39 +217,46 @@ int core_run(komb_ctx *ctx)
         KOMB_HIP(ctx, hipMalloc(&ctx->d_deg, (size_t)(nv > 0 ? nv : 1) * sizeof(int32_t)));
         KOMB_HIP(ctx, hipMalloc(&ctx->d_core, (size_t)(nv > 0 ? nv : 1) * sizeof(int32_t)));
     }
-    ctx->stats.core_levels = ctx->stats.core_subrounds = ctx->stats.core_launches = 0;
-    ctx->stats.max_coreness = 0; ctx->stats.ms_core = 0.0;
+    komb_stats &stt = ctx->stats;
+    stt.core_levels = stt.core_subrounds = stt.core_launches = 0;
+    stt.max_coreness = 0; stt.ms_core = 0.0;
+    stt.core_local_units = 0; stt.core_local_sweeps = 0; stt.core_local_items = 0; stt.ms_core_local = 0.0;
     if (nv == 0) { ctx->core_done = true; return KOMB_OK; }
 
+    DevBufs bufs(ctx);
     const size_t heavy_cap = (size_t)(2 * ctx->ne) / 32 + 64;    // sum over units with > kLight items of ceil(items / kChunk) <= 3/128 of all items
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
     CoreTailBufs T{};
     PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    auto cleanup = [&]() {
-        ctx->pool.put(T.livebits); ctx->pool.put(T.vnum); ctx->pool.put(T.cnt); ctx->pool.put(T.vlist); ctx->pool.put(T.rows);
-        ctx->pool.put(d_degw); ctx->pool.put(d_ctrl); ctx->pool.put(d_grp); ctx->pool.put(Q.code);
-        for (int i = 0; i < 2; ++i) { ctx->pool.put(Q.light[i]); ctx->pool.put(Q.heavy[i]); ctx->pool.put(Q.live[i]); }
-    };
-    hipError_t e = ctx->pool.get((void **)&d_degw, (size_t)nv * sizeof(int32_t));
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.light[i], (size_t)nv * sizeof(int32_t));
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.heavy[i], heavy_cap * sizeof(int2));
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ctx->pool.get((void **)&Q.live[i], ((size_t)nv / 2 + 64) * sizeof(int32_t));
-    if (e == hipSuccess) e = ctx->pool.get((void **)&Q.code, (size_t)nv);
-    if (e == hipSuccess) e = ctx->pool.get((void **)&d_ctrl, sizeof(PeelCtrl));
-    if (e == hipSuccess) e = ctx->pool.get((void **)&d_grp, (kInitOff + 2) * sizeof(uint32_t));
-    // hand-over threshold of the LDS tail (core_tail.h); KOMB_CORE_TAIL=0 keeps the whole peel in the general engine
-    uint32_t tail_limit = kCoreTailV;
-    if (const char *tl = getenv("KOMB_CORE_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
-    if (tail_limit > kCoreTailV) tail_limit = kCoreTailV;
-    const size_t live_words = ((size_t)nv + 63) / 64;
-    if (tail_limit) {
-        if (e == hipSuccess) e = ctx->pool.get((void **)&T.livebits, live_words * sizeof(unsigned long long));
-        if (e == hipSuccess) e = ctx->pool.get((void **)&T.vnum, (size_t)nv * sizeof(int32_t));
-        if (e == hipSuccess) e = ctx->pool.get((void **)&T.cnt, 4 * sizeof(uint32_t));
-        if (e == hipSuccess) e = ctx->pool.get((void **)&T.vlist, kCoreTailV * sizeof(int32_t));
-        if (e == hipSuccess) e = ctx->pool.get((void **)&T.rows, (size_t)kCoreTailV * kCoreTailWords * sizeof(unsigned long long));
+    KOMB_HIP(ctx, bufs.alloc(&d_degw, (size_t)nv));
+    for (int i = 0; i < 2; ++i) {
+        KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)nv));
+        KOMB_HIP(ctx, bufs.alloc(&Q.heavy[i], heavy_cap));
+        KOMB_HIP(ctx, bufs.alloc(&Q.live[i], (size_t)nv / 2 + 64));
     }
-    if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
+    KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)nv));
+    KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
+    // how the peel ends (common.h): local fixed point (default), LDS tail, or the general engine alone
+    const FinishMode fin = finish_mode();
+    uint32_t tail_limit = 0;
+    const size_t live_words = ((size_t)nv + 63) / 64;
+    unsigned long long *d_livebits = nullptr;
+    if (fin == FIN_LDS) {
+        tail_limit = kCoreTailV;
+        if (const char *tl = getenv("KOMB_CORE_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
+        if (tail_limit > kCoreTailV) tail_limit = kCoreTailV;
+        if (tail_limit) {
+            KOMB_HIP(ctx, bufs.alloc(&T.livebits, live_words));
+            KOMB_HIP(ctx, bufs.alloc(&T.vnum, (size_t)nv));
+            KOMB_HIP(ctx, bufs.alloc(&T.cnt, 4));
+            KOMB_HIP(ctx, bufs.alloc(&T.vlist, (size_t)kCoreTailV));
+            KOMB_HIP(ctx, bufs.alloc(&T.rows, (size_t)kCoreTailV * kCoreTailWords));
+        }
+    } else if (fin == FIN_LOCAL) {
+        tail_limit = local_limit((uint64_t)nv, 8);
+        if (tail_limit) KOMB_HIP(ctx, bufs.alloc(&d_livebits, live_words));
+    }
 
     int64_t g = (nv + kBlock - 1) / kBlock;
     const int grid_init = (int)(g > 1024 ? 1024 : g);
@@ -171,34 +266,65 @@ int core_run(komb_ctx *ctx)
     peel_ctrl_pre(s, d_grp);
     k_core_init<<<grid_init, kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_deg, d_degw, ctx->d_core, d_grp + kInitOff);
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)nv, tail_limit);
-    // the live vertices are those of `list` (or all nv when list is null) whose core[] is still an alive marker
-    auto run_tail = [&](const int32_t *list, uint32_t n_in) -> hipError_t {
-        hipError_t te = hipMemsetAsync(T.livebits, 0, live_words * sizeof(unsigned long long), s);
-        if (te == hipSuccess) te = hipMemsetAsync(T.cnt, 0, 4 * sizeof(uint32_t), s);
-        if (te == hipSuccess) te = hipMemsetAsync(T.rows, 0, (size_t)kCoreTailV * kCoreTailWords * sizeof(unsigned long long), s);
-        if (te != hipSuccess) return te;
+    // LDS tail: the live vertices are those of `list` (or all nv when list is null) whose core[] is still an alive marker
+    auto run_tail = [&](const int32_t *list, uint32_t n_in) -> int {
+        KOMB_HIP(ctx, hipMemsetAsync(T.livebits, 0, live_words * sizeof(unsigned long long), s));
+        KOMB_HIP(ctx, hipMemsetAsync(T.cnt, 0, 4 * sizeof(uint32_t), s));
+        KOMB_HIP(ctx, hipMemsetAsync(T.rows, 0, (size_t)kCoreTailV * kCoreTailWords * sizeof(unsigned long long), s));
         int64_t gm = ((int64_t)n_in + kBlock - 1) / kBlock;
         k_ctail_mark<<<(int)(gm < 1 ? 1 : (gm > 1024 ? 1024 : gm)), kBlock, 0, s>>>(list, n_in, ctx->d_core, T);
         k_ctail_rows<<<dim3(kCoreTailV, 8), kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, T);
         k_core_tail<<<1, 1024, 0, s>>>(d_ctrl, T, d_degw, ctx->d_core);
-        te = hipMemcpyAsync(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, s);
-        return te == hipSuccess ? hipStreamSynchronize(s) : te;
+        KOMB_HIP(ctx, d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)));
+        return KOMB_OK;
     };
-    int launches = 0, st = KOMB_OK, tail_runs = 0;
-    hipError_t te = hipSuccess;
+    // local finish: compact the live subgraph, sweep the h-index operator to its fixed point (local_dev.h)
+    auto run_local = [&]() -> int {
+        const PeelCtrl hc = ctx->h_ctrl[0];
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        for (auto &e : ev) KOMB_HIP(ctx, hipEventCreate(&e));
+        (void)hipEventRecord(ev[0], s);
+        KOMB_HIP(ctx, hipMemsetAsync(d_livebits, 0, live_words * sizeof(unsigned long long), s));
+        LocalStats ls;
+        const int rc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)nv, ctx->d_core, d_degw, Q.live[hc.live_sel],
+            (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), 0, ctx->d_core,
+            [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl) {
+                CoreCollect C{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, ctx->d_core, d_livebits, num, lg.off, lg.cur, (uint32_t *)items};
+                k_peel_step<CoreCollect><<<grid, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C);
+            },
+            [&](const LocalGraph &lg, void *items, uint64_t total, LocalCtrl *d_lctrl, int *launches) -> int {
+                return local_fixpoint(ctx, d_lctrl, lg, CoreLocal{(const uint32_t *)items}, total, launches);
+            },
+            &ls,
+            [&](const LocalGraph &lg) { k_live_bits<<<(int)((lg.n + 255) / 256 > 1024 ? 1024 : (lg.n + 255) / 256), 256, 0, s>>>(lg.gid, lg.n, d_livebits); });
+        (void)hipEventRecord(ev[1], s);
+        (void)hipEventSynchronize(ev[1]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        KOMB_TRY(rc);
+        stt.core_local_units = (int32_t)ls.units; stt.core_local_sweeps = ls.sweeps; stt.core_local_items = (int64_t)ls.items;
+        stt.ms_core_local = (double)ms;
+        PeelCtrl done = hc;
+        done.done = 1; done.remaining = 0;
+        done.n_levels += (int32_t)ls.levels;
+        done.max_level = ls.max_val > done.max_level ? ls.max_val : done.max_level;
+        ctx->h_ctrl[0] = done;
+        return KOMB_OK;
+    };
+    int launches = 0, st = KOMB_OK;
     if (tail_limit && (uint64_t)nv <= tail_limit) {
-        // small graph: the tail takes the whole peel (unless nothing is left to peel)
-        te = hipMemcpyAsync(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, s);
-        if (te == hipSuccess) te = hipStreamSynchronize(s);
-        if (te == hipSuccess && !ctx->h_ctrl[0].done) { te = run_tail(nullptr, (uint32_t)nv); ++tail_runs; }
+        // small graph: the finish takes the whole peel (unless nothing is left to peel)
+        st = d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) == hipSuccess ? KOMB_OK : KOMB_ERR_DEVICE;
+        if (st == KOMB_OK && !ctx->h_ctrl[0].done) st = (fin == FIN_LOCAL) ? run_local() : run_tail(nullptr, (uint32_t)nv);
     } else {
         ctx->h_ctrl[0].done = 0;
     }
-    for (int guard = 0; te == hipSuccess && st == KOMB_OK && ctx->h_ctrl[0].done != 1 && ctx->h_ctrl[0].done != 2 && guard < 64; ++guard) {
+    for (int guard = 0; st == KOMB_OK && ctx->h_ctrl[0].done != 1 && ctx->h_ctrl[0].done != 2 && guard < 64; ++guard) {
         if (ctx->h_ctrl[0].done == 3) {
             const PeelCtrl &c = ctx->h_ctrl[0];
-            te = c.live_mode ? run_tail(Q.live[c.live_sel], c.live_count) : run_tail(nullptr, (uint32_t)nv);
-            ++tail_runs;
+            if (fin == FIN_LOCAL) st = run_local();
+            else st = c.live_mode ? run_tail(Q.live[c.live_sel], c.live_count) : run_tail(nullptr, (uint32_t)nv);
             continue;
         }
         int batch = 0;
@@ -207,9 +333,7 @@ int core_run(komb_ctx *ctx)
         }, &batch);
         launches += batch;
     }
-    ctx->stats.ms_core = ctx->timer.stop(s);
-    (void)tail_runs;
-    if (te != hipSuccess) { cleanup(); KOMB_HIP(ctx, te); }
+    stt.ms_core = ctx->timer.stop(s);
 #ifdef KOMB_STEP_TIMERS
     {
         const PeelCtrl &c = ctx->h_ctrl[0];
@@ -218,13 +342,12 @@ int core_run(komb_ctx *ctx)
                 c.pad1[7], c.pad1[0] / n / 100.0, c.pad1[1] / n / 100.0, c.pad1[2] / n / 100.0, c.pad1[3] / n / 100.0, c.pad1[4] / n / 100.0, c.pad1[5] / n / 100.0);
     }
 #endif
-    cleanup();
     KOMB_TRY(st);
     if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-core peel ended in an inconsistent state");
-    ctx->stats.core_levels = ctx->h_ctrl[0].n_levels;
-    ctx->stats.core_subrounds = ctx->h_ctrl[0].n_rounds;
-    ctx->stats.core_launches = launches;
-    ctx->stats.max_coreness = ctx->h_ctrl[0].max_level;
+    stt.core_levels = ctx->h_ctrl[0].n_levels;
+    stt.core_subrounds = ctx->h_ctrl[0].n_rounds;
+    stt.core_launches = launches;
+    stt.max_coreness = ctx->h_ctrl[0].max_level;
     ctx->core_done = true;
     return KOMB_OK;
 }

@@ -28,6 +28,7 @@
 //      ORIGINAL vertex ids -- the identity the C ABI promises.
 #include "peel_dev.h"
 #include "truss_tail.h"
+#include "local_dev.h"
 
 #include <cstdlib>
 
@@ -640,6 +641,71 @@ struct TrussProblem {
     }
 };
 
+// ---- hand-over to the local finish (local_dev.h)
+// Collect pass: the peel engine run once over all live edges; a triangle whose other two edges are both live
+// becomes an entry of the compact slice (ids of the remainder).
+struct TrussCollect {
+    static constexpr bool kChain = false;
+    uint32_t units;
+    const uint32_t *off;                 // the peel's incidence index
+    const int2 *inc;
+    const int32_t *stamp;                // alive markers
+    const int32_t *num;                  // [m] id in the remainder (live edges only)
+    const uint32_t *coff;                // [n+1] compact slice offsets
+    uint32_t *cur;                       // [n] fill cursors
+    uint2 *cpair;                        // compact slices
+
+    __device__ __forceinline__ bool scan_probe(uint32_t e, int32_t &key, uint32_t &nch) const
+    {
+        const int32_t st = stamp[e];
+        key = 0;                         // every live edge enters the one frontier of this pass
+        nch = marker_chunks(st);
+        return marker_alive(st);
+    }
+    __device__ __forceinline__ void mark_scanned(uint32_t, const CtrlView &) const {}
+    __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
+    {
+        b = off[e];
+        len = off[e + 1] - b;
+    }
+    struct Loaded { int32_t me, x, y, sx, sy; };
+    __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
+    {
+        Loaded ld;
+        const int2 p = inc[pos];
+        ld.me = me; ld.x = p.x; ld.y = p.y;
+        ld.sx = stamp[p.x]; ld.sy = stamp[p.y];
+        return ld;
+    }
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &, int32_t &, int32_t &, uint32_t &, uint32_t &) const
+    {
+        if (!marker_alive(ld.sx) || !marker_alive(ld.sy)) return;
+        const uint32_t id = (uint32_t)num[ld.me];
+        cpair[coff[id] + atomicAdd(&cur[id], 1u)] = make_uint2((uint32_t)num[ld.x], (uint32_t)num[ld.y]);
+    }
+};
+
+// Fixed-point problem: item = a live triangle, value = the smaller bound of its other two edges.
+struct TrussLocal {
+    static constexpr int kU = 4;         // light unit: <= 256 live triangles
+    const uint2 *cpair;
+    struct Item { uint32_t x, y; int32_t vx, vy; };
+    __device__ __forceinline__ Item load(uint32_t pos, const int32_t *val) const
+    {
+        Item it;
+        const uint2 p = cpair[pos];
+        it.x = p.x; it.y = p.y;
+        it.vx = val[p.x]; it.vy = val[p.y];
+        return it;
+    }
+    static __device__ __forceinline__ int32_t value(const Item &it) { return min(it.vx, it.vy); }
+    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t *mark, int32_t next)
+    {
+        if (it.vx > h) mark[it.x] = next;
+        if (it.vy > h) mark[it.y] = next;
+    }
+};
+
 // -------------------------------------------------------------- result gather
 // One thread per slot of the working CSR.  Upper slots (u < v) are the canonical
 // copies of the edges; they are the suffix of their (ascending) row, so the
@@ -715,31 +781,6 @@ __global__ __launch_bounds__(kBlock) void k_graph_moments(const int32_t *__restr
         const unsigned long long t = __shfl_xor(mx, o); mx = t > mx ? t : mx;
     }
     if (lane_id() == 0) { atomicAdd(&out[0], s2); atomicAdd(&out[1], smin); atomicMax(&out[2], mx); atomicAdd(&out[3], sc); atomicAdd(&out[4], so); }
-}
-
-struct DevBufs {                                    // returns everything it still owns to the context's pool
-    komb_ctx *ctx;
-    std::vector<void *> owned;
-    explicit DevBufs(komb_ctx *c) : ctx(c) {}
-    template <class T> hipError_t alloc(T **out, size_t count)
-    {
-        void *q = nullptr;
-        hipError_t e = ctx->pool.get(&q, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) { owned.push_back(q); *out = (T *)q; }
-        return e;
-    }
-    void release(void *q)
-    {
-        for (auto &p : owned) if (p == q && q) { ctx->pool.put(q); p = nullptr; }
-    }
-    ~DevBufs() { for (void *p : owned) if (p) ctx->pool.put(p); }
-};
-
-// small blocking device-to-host read, ordered on the context's stream
-inline hipError_t d2h(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
-{
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
 }
 
 } // namespace
@@ -871,7 +912,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     uint32_t *d_cap = nullptr, *d_offc = nullptr;
     unsigned long long *d_offc64 = nullptr;    // the same offsets in 64 bits when the slices exceed 2^32 entries (KOMB_OFF64=1 forces them)
     int2 *d_sparse = nullptr;
-    const int ablate = getenv("KOMB_TRI_ABLATE") ? atoi(getenv("KOMB_TRI_ABLATE")) : 0;    // debug only: breaks results
+#ifdef KOMB_DEBUG_SWITCHES
+    const int ablate = getenv("KOMB_TRI_ABLATE") ? atoi(getenv("KOMB_TRI_ABLATE")) : 0;    // breaks results on purpose: debug builds only
+#else
+    const int ablate = 0;
+#endif
     bool single = (world == 1) && !getenv("KOMB_TWO_PASS");
     if (single) {
         KOMB_HIP(ctx, bufs.alloc(&d_cap, (size_t)m + 1));
@@ -981,12 +1026,16 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
-    // hand-over threshold of the LDS tail (truss_tail.h); KOMB_TAIL=0 keeps the whole peel in the general engine
-    uint32_t tail_limit = kTailEdges;
-    if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
-    if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
+    // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
+    const FinishMode fin = finish_mode();
+    uint32_t tail_limit = 0;
+    if (fin == FIN_LDS) {
+        tail_limit = kTailEdges;
+        if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
+        if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
+    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 16);
     TailBufs T{};
-    if (tail_limit) {
+    if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
         KOMB_HIP(ctx, bufs.alloc(&T.cnt, 64));
         KOMB_HIP(ctx, bufs.alloc(&T.vlist, (size_t)kTailMaxV));
@@ -1037,24 +1086,58 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
         return KOMB_OK;
     };
+    const int gp = peel_grid(m);
+    // local finish: compact the live sub-index, sweep the h-index operator to its fixed point (local_dev.h)
+    auto run_local = [&]() -> int {
+        const PeelCtrl hc = ctx->h_ctrl[0];
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        for (auto &e : ev) KOMB_HIP(ctx, hipEventCreate(&e));
+        (void)hipEventRecord(ev[0], s);
+        LocalStats ls;
+        const int lrc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)m, d_stamp, d_sup, Q.live[hc.live_sel],
+            (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), 2, d_truss,
+            [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl) {
+                TrussCollect C{(uint32_t)m, d_off, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
+                k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C);
+            },
+            [&](const LocalGraph &lg, void *items, uint64_t total_items, LocalCtrl *d_lctrl, int *nl) -> int {
+                return local_fixpoint(ctx, d_lctrl, lg, TrussLocal{(const uint2 *)items}, total_items, nl);
+            },
+            &ls, [](const LocalGraph &) {});
+        (void)hipEventRecord(ev[1], s);
+        (void)hipEventSynchronize(ev[1]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        KOMB_TRY(lrc);
+        st.truss_local_units = (int32_t)ls.units; st.truss_local_sweeps = ls.sweeps; st.truss_local_items = (int64_t)ls.items;
+        st.ms_truss_local = (double)ms;
+        PeelCtrl fin_c = hc;
+        fin_c.done = 1; fin_c.remaining = 0;
+        fin_c.n_levels += (int32_t)ls.levels;
+        fin_c.max_level = ls.max_val > fin_c.max_level ? ls.max_val : fin_c.max_level;
+        ctx->h_ctrl[0] = fin_c;
+        return KOMB_OK;
+    };
     ctx->timer.start(s);
     peel_ctrl_pre(s, d_grp);
     k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff);
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
-    const int gp = peel_grid(m);
     int launches = 0, rc = KOMB_OK;
     st.truss_tail_runs = 0; st.ms_tail = 0.0;
+    st.truss_local_units = 0; st.truss_local_sweeps = 0; st.truss_local_items = 0; st.ms_truss_local = 0.0;
     if (tail_limit && (uint64_t)m <= tail_limit) {
-        // small graph: the tail takes the whole peel (unless it is refused, or nothing is left to peel)
+        // small graph: the finish takes the whole peel (unless it is refused, or nothing is left to peel)
         rc = d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) == hipSuccess ? KOMB_OK : KOMB_ERR_DEVICE;
-        if (rc == KOMB_OK && !ctx->h_ctrl[0].done) rc = run_tail(nullptr, (uint32_t)m);
+        if (rc == KOMB_OK && !ctx->h_ctrl[0].done) rc = (fin == FIN_LOCAL) ? run_local() : run_tail(nullptr, (uint32_t)m);
     } else {
         ctx->h_ctrl[0].done = 0;
     }
     for (int guard = 0; rc == KOMB_OK && ctx->h_ctrl[0].done != 1 && ctx->h_ctrl[0].done != 2 && guard < 64; ++guard) {
         if (ctx->h_ctrl[0].done == 3) {
             const PeelCtrl &c = ctx->h_ctrl[0];
-            rc = c.live_mode ? run_tail(Q.live[c.live_sel], c.live_count) : run_tail(nullptr, (uint32_t)m);
+            if (fin == FIN_LOCAL) rc = run_local();
+            else rc = c.live_mode ? run_tail(Q.live[c.live_sel], c.live_count) : run_tail(nullptr, (uint32_t)m);
             continue;
         }
         int batch = 0;

@@ -1,0 +1,452 @@
+// local_dev.h -- the "local" finish of a peel: an h-index fixed point on the compacted remainder.
+//
+// A level-synchronous peel spends most of its steps where almost nothing is left: at |E| = 100M the
+// truss peel removes 99 % of the edges in four levels, then needs ~450 more dependent sub-rounds for
+// the last 1 %; the k-core peel is the same story with hub vertices.  Each of those steps is a chain of
+// dependent trips to memory however few units it peels (peel_dev.h).  Coreness and trussness are also the
+// unique greatest fixed point of the h-index operator (Lu et al. 2016 for k-core; Sariyuce, Seshadhri,
+// Pinar 2017 "Local algorithms for hierarchical dense subgraph discovery" for k-truss / nuclei):
+//       tau(u) <- H{ value(item) : item in slice(u) }   (capped at tau(u)),
+//       value = tau(neighbour) (k-core) / min(tau(x), tau(y)) over the triangle's other two edges (k-truss),
+//       H(S)  = the largest h with at least h members of S that are >= h,
+// started from the live keys (live degree / live support, upper bounds).  Every sweep is one plain
+// data-parallel launch -- no frontier queues, no tie-breaks, no atomics except one counter -- and the
+// number of sweeps is 15-45 where the peel needs hundreds of sub-rounds (scripts/sim/*.c measure both on
+// the benchmark graphs).  So the peel engine keeps the bulk levels, where its steps are large and each item
+// is visited once, and hands the remainder over (PeelCtrl::tail_limit):
+//   1. the live units are renumbered 0..n-1, heavy ones (long live slices) first; their live keys become
+//      tau and the slice lengths of the compact index;
+//   2. the live items are collected into the compact index by the peel engine itself, run once over all
+//      live units with a "collect" problem (its light batches / heavy chunks walk the original slices);
+//   3. k_local_step sweeps until a sweep changes nothing; values only ever decrease, updates are in place;
+//   4. the results are scattered back (coreness = tau, trussness = tau + 2).
+// Why the result is exact whatever the interleaving: (a) tau stays >= the true level, because H is monotone
+// and the true levels are a fixed point; (b) a unit is re-evaluated in the next sweep whenever one of its
+// items' values may have dropped below its own value (the notification rule below is conservative under stale
+// reads: a stale value is only ever too high); (c) every evaluation reads each item exactly once, so its count
+// is a consistent sample; when a sweep changes nothing, every unit's last evaluation saw final values and found
+// count(items >= tau) >= tau, which makes {tau >= k} a k-core / (k+2)-truss for every k, i.e. tau <= the true
+// level.  Bit-exact parity with the peel is tested like every other path (tests/test_gpu_parity.py).
+#pragma once
+
+#include "peel_dev.h"
+
+namespace komb {
+
+constexpr int kLocBlock = 512;                 // 8 wave64 per workgroup: three workgroups per CU at <= 80 VGPRs
+constexpr int kLocWaves = kLocBlock / kWave;
+constexpr int kLocHB = 4096;                   // histogram bins of the heavy path
+constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix search
+constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
+
+
+struct LocalGraph {                            // the compacted remainder
+    uint32_t n, nh;          // units; ids [0, nh) are heavy (more than the problem's kItems items)
+    uint32_t *off;           // [n+1] compact slice offsets
+    int32_t *val;            // [n] tau
+    int32_t *mark;           // [n] sweep in which the unit is to be evaluated
+    int32_t *gid;            // [n] unit id of the general engine
+    uint32_t *len;           // [n+1] live key at hand-over = compact slice length (scan input)
+    uint32_t *cur;           // [n] fill cursors of the collect pass
+};
+
+// ---- 1. numbering.  `list` (or all `units` when null) holds the candidates; live = alive marker in `marker`;
+// the live key is key[u].  Heavy units get ids from 0 up, light ones from n_live-1 down (the host knows n_live
+// = PeelCtrl::remaining).  Any order inside a class is fine: the fixed point is unique.
+static __global__ __launch_bounds__(kBlock) void k_local_number(const int32_t *__restrict__ list, uint32_t n_in, uint32_t n_live,
+                                                         const int32_t *__restrict__ marker, const int32_t *__restrict__ key,
+                                                         uint32_t light_max, int32_t *__restrict__ num, LocalGraph g, LocalCtrl *ctrl)
+{
+    const int lane = lane_id();
+    for (uint32_t i0 = blockIdx.x * kBlock; i0 < n_in; i0 += gridDim.x * kBlock) {
+        const uint32_t i = i0 + threadIdx.x;
+        int32_t u = -1, k = 0;
+        if (i < n_in) {
+            u = list ? list[i] : (int32_t)i;
+            if (!marker_alive(marker[u])) u = -1; else k = key[u];
+        }
+        const bool heavy = u >= 0 && (uint32_t)k > light_max, light = u >= 0 && !heavy;
+        const uint64_t mh = __ballot(heavy), ml = __ballot(light);
+        uint32_t base = 0;
+        if (lane == 0 && mh) base = atomicAdd(&ctrl->n_heavy, (uint32_t)__popcll(mh));
+        else if (lane == 1 && ml) base = atomicAdd(&ctrl->n_light, (uint32_t)__popcll(ml));
+        const uint32_t bh = (uint32_t)__shfl((int)base, 0), bl = (uint32_t)__shfl((int)base, 1);
+        if (u < 0) continue;
+        const uint32_t id = heavy ? bh + (uint32_t)__popcll(mh & lanemask_lt())
+                                  : n_live - 1u - (bl + (uint32_t)__popcll(ml & lanemask_lt()));
+        if (id >= n_live) { atomicAdd(&ctrl->bad, 1u); continue; }      // more live units than the control block said
+        num[u] = (int32_t)id;
+        g.gid[id] = u; g.len[id] = (uint32_t)k; g.val[id] = k; g.mark[id] = 1; g.cur[id] = 0u;
+    }
+}
+
+// after the collect pass: every compact slice must be exactly full
+static __global__ __launch_bounds__(kBlock) void k_local_check(LocalGraph g, LocalCtrl *ctrl)
+{
+    uint32_t bad = 0;
+    for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < g.n; id += gridDim.x * kBlock)
+        bad += (g.cur[id] != g.off[id + 1] - g.off[id]) ? 1u : 0u;
+    bad = wave_sum(bad);
+    if (lane_id() == 0 && bad) atomicAdd(&ctrl->bad, bad);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (ctrl->n_heavy != g.nh || ctrl->n_heavy + ctrl->n_light != g.n)) atomicAdd(&ctrl->bad, 1u);
+}
+
+// ---- 3. one sweep.  Problem concept (all __device__):
+//   static constexpr int kU;                     items per lane of a light batch (light unit: <= 64 * kU items)
+//   struct Item;  Item load(pos, val) const;     the item's loads
+//   static int32_t value(const Item &);
+//   static void notify(const Item &, int32_t h, int32_t *mark, int32_t next);   unit dropped to h: mark every
+//                                                neighbour whose (visible, possibly stale = too high) value is > h
+template <class P>
+__global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, LocalGraph g, P p, int32_t k)
+{
+    constexpr int kU = P::kU;
+    constexpr uint32_t kItems = (uint32_t)kWave * kU;
+    __shared__ uint32_t sh_hist[kLocHB];
+    __shared__ uint32_t sh_part[kLocWaves];
+    __shared__ unsigned long long sh_best;
+    __shared__ int32_t sh_i[2];
+    __shared__ uint32_t sh_end[kLocWaves][kWave];
+    __shared__ uint32_t sh_a[kLocWaves][4][kWave];
+    const uint32_t tid = threadIdx.x;
+    const int lane = lane_id(), w = (int)(tid >> 6);
+
+    if (tid == 0) { sh_i[0] = ctrl->done; sh_i[1] = (k > 1) ? (int32_t)ctrl->chg[(k - 1) % 3] : 1; }
+    __syncthreads();
+    if (sh_i[0]) return;
+    if (sh_i[1] == 0) {                                  // the previous sweep changed nothing: fixed point
+        if (blockIdx.x == 0 && tid == 0) { ctrl->done = 1; ctrl->iters = k - 1; }
+        return;
+    }
+    if (blockIdx.x == 0 && tid == 0) ctrl->chg[(k + 1) % 3] = 0u;     // nobody reads or adds to that slot in this launch
+    uint32_t n_changed = 0, n_evals = 0;                 // meaningful in thread 0 (heavy) / lane 0 of each wave (light)
+
+    // ---- heavy units: one workgroup per unit, LDS histogram of the item values, range refined until exact
+    for (uint32_t hu = blockIdx.x; hu < g.nh; hu += gridDim.x) {
+        // one thread reads the unit's mark and value for the workgroup: other workgroups may be re-marking the
+        // unit right now, and the branch below must be uniform
+        __syncthreads();
+        if (tid == 0) { sh_i[0] = g.mark[hu]; sh_i[1] = g.val[hu]; }
+        __syncthreads();
+        if (sh_i[0] != k) continue;
+        const int32_t cap = sh_i[1];
+        if (cap <= 0) continue;
+        const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
+        int32_t lo = 0, hi = cap - 1, H = cap;
+        bool first = true;
+        for (;;) {
+            // histogram of the values in [lo, hi], `above` = values > hi, all from ONE pass over the items
+            const uint32_t width = (uint32_t)(hi - lo) + 1u;
+            int sh = 0;
+            while (((width - 1u) >> sh) >= (uint32_t)kLocHB) ++sh;
+            const uint32_t nb = ((width - 1u) >> sh) + 1u;
+            for (uint32_t i = tid; i < (uint32_t)kLocHB; i += kLocBlock) sh_hist[i] = 0u;
+            if (tid == 0) sh_best = 0ull;
+            __syncthreads();
+            uint32_t ab = 0;
+            for (uint32_t j = tid; j < len; j += kLocBlock) {
+                const typename P::Item it = p.load(beg + j, g.val);
+                const int32_t r = P::value(it);
+                if (r > hi) ++ab;
+                else if (r >= lo) atomicAdd(&sh_hist[(uint32_t)(r - lo) >> sh], 1u);
+            }
+            ab = wave_sum(ab);
+            if (lane == 0) sh_part[w] = ab;
+            __syncthreads();
+            uint32_t above = 0;
+#pragma unroll
+            for (int i = 0; i < kLocWaves; ++i) above += sh_part[i];
+            if (first && above >= (uint32_t)cap) break;                  // still has cap items >= cap: unchanged
+            first = false;
+            // largest bin b with count(values >= lo + (b << sh)) >= lo + (b << sh); thread t owns kLocBins consecutive bins
+            uint32_t h4[kLocBins], mine = 0;
+#pragma unroll
+            for (int i = 0; i < kLocBins; ++i) { h4[i] = sh_hist[kLocBins * tid + i]; mine += h4[i]; }
+            // suffix sum over the threads above this one
+            uint32_t suf = mine;
+            for (int o = 1; o < kWave; o <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)suf, o); if (lane + o < kWave) suf += t; }
+            __syncthreads();                                             // sh_part is reused
+            if (lane == 0) sh_part[w] = suf;                             // wave total
+            __syncthreads();
+            uint32_t run = above + suf - mine;                           // bins above this thread's, inside the wave
+            for (int i = w + 1; i < kLocWaves; ++i) run += sh_part[i];
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int i = kLocBins - 1; i >= 0; --i) {
+                const uint32_t b = kLocBins * tid + (uint32_t)i;
+                const uint32_t s_above = run;                            // count(values >= start of bin b+1)
+                run += h4[i];                                            // count(values >= start of bin b)
+                if (b < nb && best == 0ull && (unsigned long long)run >= (unsigned long long)lo + ((unsigned long long)b << sh))
+                    best = ((unsigned long long)(b + 1u) << 32) | s_above;
+            }
+            if (best) atomicMax(&sh_best, best);
+            __syncthreads();
+            const unsigned long long bb = sh_best;
+            __syncthreads();
+            if (bb == 0ull) {                                            // values dropped under the range while we looked
+                if (lo == 0) { H = 0; break; }
+                hi = lo - 1; lo = 0;
+                continue;
+            }
+            const uint32_t b = (uint32_t)(bb >> 32) - 1u;
+            const int32_t nlo = lo + (int32_t)(b << sh);
+            const int32_t nhi = min(hi, nlo + (int32_t)((1u << sh) - 1u));
+            lo = nlo; hi = nhi;
+            if (sh == 0) { H = lo; break; }
+        }
+        if (tid == 0) ++n_evals;
+        if (H < cap) {
+            if (tid == 0) { g.val[hu] = H; ++n_changed; }
+            for (uint32_t j = tid; j < len; j += kLocBlock) {
+                const typename P::Item it = p.load(beg + j, g.val);
+                P::notify(it, H, g.mark, k + 1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- light units: a wavefront takes 64 consecutive ids, packs the marked ones, and evaluates them in
+    // batches of <= 64 * kU items flattened over the lanes; counts are ballots masked by each unit's lane range
+    uint32_t *s_end = sh_end[w];
+    uint32_t (*s_a)[kWave] = sh_a[w];
+    const uint32_t nlight = g.n - g.nh;
+    const uint32_t nblk = (nlight + kWave - 1) / kWave;
+    const uint32_t gw = blockIdx.x * kLocWaves + (uint32_t)w, nw = gridDim.x * kLocWaves;
+    for (uint32_t blk = gw; blk < nblk; blk += nw) {
+        const uint32_t u = g.nh + blk * kWave + (uint32_t)lane;
+        const bool act = u < g.n && g.mark[u] == k;
+        const uint64_t am = __ballot(act);
+        if (!am) continue;
+        const uint32_t na = (uint32_t)__popcll(am);
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+            const uint32_t q = (uint32_t)__popcll(am & lanemask_lt());
+            const uint32_t b0 = g.off[u];
+            s_a[0][q] = u; s_a[1][q] = b0; s_a[2][q] = g.off[u + 1] - b0; s_a[3][q] = (uint32_t)g.val[u];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t start = 0; start < na;) {
+            const bool has = start + (uint32_t)lane < na;
+            uint32_t mu = 0, mlen = 0;
+            int32_t mcap = 0;
+            if (has) { mu = s_a[0][start + lane]; mlen = s_a[2][start + lane]; mcap = (int32_t)s_a[3][start + lane]; }
+            const uint32_t incl = wave_incl_scan(mlen);
+            uint32_t nb = (uint32_t)__popcll(__ballot(has && incl <= kItems));   // a prefix of the lanes
+            if (nb == 0) {                               // a light unit longer than a batch: cannot happen (numbering rule)
+                if (lane == 0) atomicAdd(&ctrl->bad, 1u);
+                start += 1;
+                continue;
+            }
+            const bool own = (uint32_t)lane < nb;
+            const uint32_t total = (uint32_t)__shfl((int)incl, (int)nb - 1);
+            const int32_t first = (int32_t)(incl - mlen), last = (int32_t)incl;  // my items: flattened positions [first, last)
+            __builtin_amdgcn_wave_barrier();
+            s_end[lane] = own ? incl : 0xFFFFFFFFu;
+            __builtin_amdgcn_wave_barrier();
+            typename P::Item it[kU];
+            int32_t r[kU];
+            int t[kU];
+            bool valid[kU];
+#pragma unroll
+            for (int x = 0; x < kU; ++x) {
+                const uint32_t idx = (uint32_t)(x * kWave + lane);
+                valid[x] = idx < total;
+                int o = 0;                               // owner: smallest t with s_end[t] > idx
+#pragma unroll
+                for (int st = kWave / 2; st > 0; st >>= 1) o += (s_end[o + st - 1] <= idx) ? st : 0;
+                t[x] = valid[x] ? o : 0;
+                r[x] = 0;
+                if (valid[x]) {
+                    const uint32_t f = o ? s_end[o - 1] : 0u;
+                    it[x] = p.load(s_a[1][start + (uint32_t)o] + (idx - f), g.val);
+                    r[x] = P::value(it[x]);
+                }
+            }
+            // per-owner count of its items with value >= thr (thr differs per owner)
+            auto count_ge = [&](int32_t thr) -> uint32_t {
+                uint32_t c = 0;
+#pragma unroll
+                for (int x = 0; x < kU; ++x) {
+                    const int32_t th = __shfl(thr, t[x]);
+                    const uint64_t B = __ballot(valid[x] && r[x] >= th);
+                    int a = first - x * kWave, b = last - x * kWave;
+                    a = a < 0 ? 0 : a; b = b > kWave ? kWave : b;
+                    if (b > a) {
+                        const uint64_t mb = (b == kWave) ? ~0ull : ((1ull << b) - 1ull);
+                        c += (uint32_t)__popcll(B & mb & ~((1ull << a) - 1ull));
+                    }
+                }
+                return c;
+            };
+            const uint32_t c0 = count_ge(mcap);
+            const bool fail = own && mcap > 0 && c0 < (uint32_t)mcap;
+            int32_t lo = fail ? (int32_t)c0 : mcap, hi = fail ? mcap - 1 : mcap;   // H >= c0: the c0 items >= cap are >= c0 too
+            while (__ballot(lo < hi)) {
+                const int32_t mid = (int32_t)(((int64_t)lo + hi + 1) >> 1);
+                const uint32_t c = count_ge(mid);
+                if (lo < hi) { if (c >= (uint32_t)mid) lo = mid; else hi = mid - 1; }
+            }
+            if (fail) g.val[mu] = lo;
+            const int32_t thr_n = fail ? lo : 0x7FFFFFFF;
+#pragma unroll
+            for (int x = 0; x < kU; ++x) {
+                const int32_t th = __shfl(thr_n, t[x]);
+                if (valid[x]) P::notify(it[x], th, g.mark, k + 1);
+            }
+            n_changed += (uint32_t)__popcll(__ballot(fail));
+            n_evals += nb;
+            start += nb;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) {
+        if (n_changed) atomicAdd(&ctrl->chg[k % 3], n_changed);
+        if (n_evals) atomicAdd(&ctrl->evals, n_evals);
+    }
+}
+
+// ---- 4. results back to the general engine's arrays (+ statistics: largest value, which values occur)
+static __global__ __launch_bounds__(kBlock) void k_local_finish(LocalGraph g, int32_t add, int32_t *__restrict__ out,
+                                                         uint32_t *__restrict__ present, LocalCtrl *ctrl)
+{
+    int32_t mx = 0;
+    for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < g.n; id += gridDim.x * kBlock) {
+        const int32_t v = g.val[id];
+        out[g.gid[id]] = v + add;
+        mx = max(mx, v);
+        atomicOr(&present[(uint32_t)v >> 5], 1u << ((uint32_t)v & 31u));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane_id() == 0 && mx) atomicMax(&ctrl->max_val, mx);
+}
+static __global__ __launch_bounds__(kBlock) void k_local_levels(const uint32_t *__restrict__ present, uint32_t words, LocalCtrl *ctrl)
+{
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < words; i += gridDim.x * kBlock) c += (uint32_t)__popc(present[i]);
+    c = wave_sum(c);
+    if (lane_id() == 0 && c) atomicAdd(&ctrl->levels, c);
+}
+
+// Sweep until the control block reports the fixed point.  Like drive_peel: the host keeps a batch of launches
+// queued and looks at a copy of the control block one batch behind.
+template <class P>
+int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, const LocalGraph &g, const P &p, uint64_t total_items, int *launches_out)
+{
+    hipStream_t s = ctx->stream;
+    const int grid = 768;                                 // three 512-thread workgroups per CU
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    LocalCtrl *h = ctx->h_local;
+    // a sweep that changes anything lowers the sum of the values (<= total_items at the start) by at least 1, so this
+    // many launches cannot be reached; the loop ends on `done`
+    const uint64_t max_launches = total_items + (uint64_t)g.n + 64u;
+    int launches = 0, slot = 0, status = KOMB_OK;
+    bool have_prev = false, finished = false;
+    int32_t k = 0;
+    while (!finished && (uint64_t)launches < max_launches && k < 0x3FFFFFF0) {
+        for (int i = 0; i < kLocBatch; ++i) { ++k; k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, g, p, k); ++launches; }
+        if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipEventRecord(ev[slot], s) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
+        if (have_prev) {
+            if (hipEventSynchronize(ev[slot ^ 1]) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
+            if (h[slot ^ 1].done) finished = true;
+        }
+        have_prev = true;
+        slot ^= 1;
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (launches_out) *launches_out = launches;
+    if (status != KOMB_OK || e != hipSuccess)
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local fixed point: HIP failure (%s)", hipGetErrorString(e));
+    return KOMB_OK;
+}
+
+struct LocalStats {
+    uint32_t units = 0, heavy = 0, levels = 0;
+    int32_t max_val = 0;
+    int sweeps = 0, launches = 0;
+    uint64_t items = 0, evals = 0;
+};
+
+// The whole hand-over: number -> scan -> collect (peel engine, `launch_collect`) -> check -> sweep (`run_fix`) ->
+// scatter.  hc = the peel's control block as the host last read it (done == 3, or the initial state of a small
+// input); marker / key = the peel's alive markers and live keys; `out` receives value + add for every unit of
+// the remainder.  launch_collect(g, num, items, d_cctrl) issues ONE launch of k_peel_step<Collect>;
+// run_fix(g, items, total, d_lctrl, &launches) = local_fixpoint<Local>; after_number(g) runs once the ids exist
+// (k-core builds its bitmap of live vertices there).
+template <class LaunchCollect, class RunFix, class AfterNumber>
+int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_ctrl, uint32_t units, const int32_t *marker,
+                 const int32_t *key, const int32_t *live_list, uint32_t light_max, size_t item_bytes, int32_t add, int32_t *out,
+                 LaunchCollect &&launch_collect, RunFix &&run_fix, LocalStats *ls, AfterNumber &&after_number)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t n = hc.remaining;
+    if (n == 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "local finish: nothing left to hand over");
+    const int32_t *list = hc.live_mode ? live_list : nullptr;
+    const uint32_t n_in = hc.live_mode ? hc.live_count : units;
+    LocalGraph g{};
+    int32_t *d_num = nullptr;
+    LocalCtrl *d_lctrl = nullptr;
+    PeelCtrl *d_cctrl = nullptr;
+    uint32_t *d_present = nullptr;
+    const size_t present_words = ((size_t)units >> 5) + 2;
+    KOMB_HIP(ctx, bufs.alloc(&d_num, (size_t)units));
+    KOMB_HIP(ctx, bufs.alloc(&g.off, (size_t)n + 1));
+    KOMB_HIP(ctx, bufs.alloc(&g.len, (size_t)n + 1));
+    KOMB_HIP(ctx, bufs.alloc(&g.val, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.mark, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.gid, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.cur, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&d_lctrl, 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_cctrl, 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_present, present_words));
+    KOMB_HIP(ctx, hipMemsetAsync(d_lctrl, 0, sizeof(LocalCtrl), s));
+    KOMB_HIP(ctx, hipMemsetAsync(g.len + n, 0, sizeof(uint32_t), s));
+    KOMB_HIP(ctx, hipMemsetAsync(d_present, 0, present_words * sizeof(uint32_t), s));
+    g.n = n; g.nh = 0;
+    int64_t gb = ((int64_t)n_in + kBlock - 1) / kBlock;
+    k_local_number<<<(int)(gb < 1 ? 1 : (gb > 2048 ? 2048 : gb)), kBlock, 0, s>>>(list, n_in, n, marker, key, light_max, d_num, g, d_lctrl);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, g.len, g.off, (int64_t)n + 1));
+    LocalCtrl hl{};
+    uint32_t total = 0;
+    KOMB_HIP(ctx, hipMemcpyAsync(&hl, d_lctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s));
+    KOMB_HIP(ctx, d2h(ctx, &total, g.off + n, sizeof(uint32_t)));
+    if (hl.bad || hl.n_heavy + hl.n_light != n)
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u live units numbered, the peel counted %u", hl.n_heavy + hl.n_light, n);
+    g.nh = hl.n_heavy;
+    after_number(g);
+    void *d_items = nullptr;
+    KOMB_HIP(ctx, bufs.alloc((unsigned char **)&d_items, (size_t)total * item_bytes));
+
+    // collect: SCAN (every live unit is a hit) + PROCESS of the peel engine on its own control block
+    peel_collect_ctrl(s, d_cctrl, d_ctrl);
+    PeelCtrl hcc{};
+    for (int guard = 0; guard < 16 && hcc.done == 0; ++guard) {
+        for (int i = 0; i < 3; ++i) launch_collect(g, d_num, d_items, d_cctrl);
+        KOMB_HIP(ctx, d2h(ctx, &hcc, d_cctrl, sizeof(PeelCtrl)));
+    }
+    if (hcc.done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: collect pass did not complete (state %d)", hcc.done);
+    int64_t gn = ((int64_t)n + kBlock - 1) / kBlock;
+    const int grid_n = (int)(gn > 1024 ? 1024 : gn);
+    k_local_check<<<grid_n, kBlock, 0, s>>>(g, d_lctrl);
+
+    int launches = 0;
+    KOMB_TRY(run_fix(g, d_items, (uint64_t)total, d_lctrl, &launches));
+    k_local_finish<<<grid_n, kBlock, 0, s>>>(g, add, out, d_present, d_lctrl);
+    k_local_levels<<<(int)(present_words / kBlock + 1 > 256 ? 256 : present_words / kBlock + 1), kBlock, 0, s>>>(d_present, (uint32_t)present_words, d_lctrl);
+    KOMB_HIP(ctx, d2h(ctx, &hl, d_lctrl, sizeof(LocalCtrl)));
+    if (hl.bad) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u consistency failures in the compact index", hl.bad);
+    if (!hl.done) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: launch budget exhausted before the fixed point");
+    if (ls) {
+        ls->units = n; ls->heavy = g.nh; ls->levels = hl.levels; ls->max_val = hl.max_val;
+        ls->sweeps = hl.iters; ls->launches = launches; ls->items = total; ls->evals = hl.evals;
+    }
+    bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
+    bufs.release(g.mark); bufs.release(g.gid); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cctrl); bufs.release(d_present);
+    return KOMB_OK;
+}
+
+} // namespace komb

@@ -1,15 +1,19 @@
-"""Debug: run one k-truss (and k-core) pass with KOMB_PEEL_TRACE and summarise cost per step."""
+"""Debug (needs a build with EXTRA=-DKOMB_DEBUG_SWITCHES): one k-truss and one k-core pass with KOMB_PEEL_TRACE,
+general engine only (KOMB_FINISH=none), one line per step in gpurun_out/peel_trace_<config>.txt."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import komb_amd
-cfg = {"c3": (10_000_000, 24_250_000), "c2": (1_000_000, 2_450_000)}[sys.argv[1] if len(sys.argv) > 1 else "c3"]
-out = "gpurun_out/peel_trace.txt"
+import bench
+name = sys.argv[1] if len(sys.argv) > 1 else "c3"
+nv, ncl, alpha, seed = bench.CONFIGS[name][:4]
+out = f"gpurun_out/peel_trace_{name}.txt"
 os.makedirs("gpurun_out", exist_ok=True)
 if os.path.exists(out): os.remove(out)
-uv = komb_amd.gen_hug_edges(cfg[0], cfg[1], 2.6, 42)
-a = komb_amd.KombAccel(); a.from_edges(cfg[0], uv); del uv
+os.environ["KOMB_FINISH"] = os.environ.get("KOMB_FINISH", "none")
+uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
+a = komb_amd.KombAccel(); a.from_edges(nv, uv); del uv
 a.truss_run()                      # warm the pool
+a.core_run()
 os.environ["KOMB_PEEL_TRACE"] = out
 a.truss_run()
 a.core_run()

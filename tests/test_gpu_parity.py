@@ -26,7 +26,7 @@ def _i64(x):
 
 def test_native_library_is_loaded(K):
     lib = K._lib.load()
-    assert lib.komb_abi_version() == 1
+    assert lib.komb_abi_version() == 2
     with open("/proc/self/maps") as f:
         assert "libkomb_accel.so" in f.read()
 
@@ -376,6 +376,7 @@ def test_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
     whole small graphs, hand-over in mid-peel at several thresholds, refusal (too many vertices; or a clique-like
     remainder, which the tail's cost model leaves to the general engine).  The spill of a frontier beyond the LDS
     queues is exercised by the full-size C3 run (656 LDS queue entries there)."""
+    monkeypatch.setenv("KOMB_FINISH", "lds")
     rng = np.random.default_rng(5)
     cases = []
     for nv, ne in ((60, 900), (400, 14000), (900, 30000), (3000, 90000)):
@@ -411,11 +412,13 @@ def test_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
             clique = len(want) == nv * (nv - 1) // 2
             assert ran > 0 or want.max() <= 2 or clique, nv
     monkeypatch.delenv("KOMB_TAIL", raising=False)
+    monkeypatch.delenv("KOMB_FINISH", raising=False)
 
 
 def test_core_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
     """The single-workgroup LDS tail of the k-core peel (core_tail.h) against the general engine
     (KOMB_CORE_TAIL=0) and the oracle: whole small graphs, hand-over in mid-peel at several thresholds."""
+    monkeypatch.setenv("KOMB_FINISH", "lds")
     rng = np.random.default_rng(11)
     cases = []
     for nv, ne in ((50, 400), (700, 20000), (1024, 60000), (5000, 100000)):
@@ -440,3 +443,75 @@ def test_core_lds_tail_agrees_with_general_engine(K, O, monkeypatch):
                 assert np.array_equal(core, want), (nv, limit)
                 assert a.stats()["max_coreness"] == want.max()
     monkeypatch.delenv("KOMB_CORE_TAIL", raising=False)
+    monkeypatch.delenv("KOMB_FINISH", raising=False)
+
+
+def _local_cases(K):
+    rng = np.random.default_rng(23)
+    cases = []
+    for nv, ne in ((60, 900), (400, 14000), (3000, 90000)):                      # dense random: deep cascades
+        cases.append(("gnm%d" % nv, nv, rng.integers(0, nv, (ne, 2)).astype(np.int64)))
+    cases.append(("hug30k", 30000, K.gen_hug_edges(30000, 90000, 2.3, 9)))      # power-law unitig graphs
+    cases.append(("hug300k", 300000, K.gen_hug_edges(300000, 740000, 2.6, 13)))
+    cases.append(("hug50k_a21", 50000, K.gen_hug_edges(50000, 165000, 2.1, 5)))  # heavy tail: hubs, many levels
+    for n in (40, 300):                                                            # cliques: every unit heavy at n = 300
+        cases.append(("K%d" % n, n, np.stack(np.triu_indices(n, 1), axis=1).astype(np.int64)))
+    n = 4000                                                                       # triangle strip: one unit per sweep
+    path = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
+    cases.append(("strip", n, np.concatenate([path, np.stack([np.arange(n - 2), np.arange(2, n)], axis=1)]).astype(np.int64)))
+    # a hub with 150k leaves (vertex value 150000: the histogram range is refined twice), a ring with chords, a K_40
+    star = np.stack([np.zeros(150000, np.int64), np.arange(1, 150001)], axis=1)
+    ring = np.stack([np.arange(1, 2000), np.arange(2, 2001)], axis=1)
+    cases.append(("hub", 150001, np.concatenate([star, ring, np.stack(np.triu_indices(40, 1), axis=1) + 1]).astype(np.int64)))
+    # books: a spine edge with k pages (k triangles on one edge: light below 256, heavy above, two histogram
+    # passes from 4096 on), plus a clique on some pages to keep several levels alive
+    for k in (255, 256, 257, 700, 5000):
+        pages = np.arange(2, k + 2)
+        uv = np.concatenate([[[0, 1]], np.stack([np.zeros(k, int), pages], 1), np.stack([np.ones(k, int), pages], 1),
+                             np.stack(np.triu_indices(12, 1), axis=1) + 2])
+        cases.append(("book%d" % k, k + 2, uv.astype(np.int64)))
+    return cases
+
+
+def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
+    """The local finish (local_dev.h: h-index fixed point on the remainder the peel hands over) against the general
+    engine alone (KOMB_FINISH=none) and the oracle, for k-core and k-truss: whole graphs (KOMB_LOCAL_LIMIT larger than
+    the graph), the default hand-over, and hand-overs in mid-peel at several thresholds."""
+    for name, nv, uv in _local_cases(K):
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            rowptr, col = a.get_csr()
+            want_core = O.coreness(rowptr, col)
+            want_tr = O.trussness(rowptr, col)
+            monkeypatch.setenv("KOMB_FINISH", "none")
+            monkeypatch.delenv("KOMB_LOCAL_LIMIT", raising=False)
+            assert np.array_equal(a.run_core()[1], want_core), name
+            assert np.array_equal(a.run_truss()[2], want_tr), name
+            st = a.stats()
+            assert st["core_local_units"] == 0 and st["truss_local_units"] == 0
+            monkeypatch.delenv("KOMB_FINISH", raising=False)
+            ran_core = ran_truss = 0
+            for limit in ("4000000000", None, "20000", "1500", "100"):
+                if limit is None:
+                    monkeypatch.delenv("KOMB_LOCAL_LIMIT", raising=False)
+                else:
+                    monkeypatch.setenv("KOMB_LOCAL_LIMIT", limit)
+                core = a.run_core()[1]
+                st = a.stats()
+                assert np.array_equal(core, want_core), (name, limit)
+                assert st["max_coreness"] == want_core.max(), (name, limit)
+                ran_core += st["core_local_units"]
+                if limit == "4000000000":
+                    assert st["core_local_units"] == int((np.diff(rowptr) > 0).sum()), name
+                    assert st["core_levels"] == len(np.unique(want_core)), name
+                tr = a.run_truss()[2]
+                st = a.stats()
+                assert np.array_equal(tr, want_tr), (name, limit)
+                assert st["max_trussness"] == want_tr.max(), (name, limit)
+                ran_truss += st["truss_local_units"]
+                if limit == "4000000000" and len(want_tr):
+                    sup = a.truss_fetch(with_support=True)[3]
+                    assert st["truss_local_units"] == int((sup > 0).sum()), name
+                    assert st["truss_levels"] == len(np.unique(want_tr)), name
+            assert ran_core > 0 and (ran_truss > 0 or want_tr.max() <= 2), name
+    monkeypatch.delenv("KOMB_LOCAL_LIMIT", raising=False)
