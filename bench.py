@@ -107,16 +107,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # the native pieces are built first: nothing has initialised the GPU yet, so the compiler children are
-    # not spawned from a GPU-holding (or, under rocprofv3, profiler-preloaded: use --no-build there) process
-    import __graft_entry__ as entry
-    if rank == 0 and not args.no_build:
-        entry.build()
-
+    # the native pieces are compiled first: nothing has initialised the GPU yet, so the compiler children are
+    # not spawned from a GPU-holding (or, under rocprofv3, profiler-preloaded: use --no-build there) process.
+    # torch is imported (not initialised) before libkomb_accel.so is loaded, so that one HIP runtime serves both.
     import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
+    import __graft_entry__ as entry
+    if rank == 0 and not args.no_build:
+        entry.compile_native()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the komb_accel path has no CPU fallback")

@@ -139,9 +139,9 @@ struct CoreLocal {
         return it;
     }
     static __device__ __forceinline__ int32_t value(const Item &it) { return it.va; }
-    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t *mark, int32_t next)
+    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t a, const int32_t *mark_cur, int32_t *mark_next, int32_t k)
     {
-        if (it.va > h) mark[it.a] = next;
+        if (it.va > h && (it.va <= a || mark_cur[it.a] == k)) mark_next[it.a] = k + 1;
     }
 };
 

@@ -699,10 +699,10 @@ struct TrussLocal {
         return it;
     }
     static __device__ __forceinline__ int32_t value(const Item &it) { return min(it.vx, it.vy); }
-    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t *mark, int32_t next)
+    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t a, const int32_t *mark_cur, int32_t *mark_next, int32_t k)
     {
-        if (it.vx > h) mark[it.x] = next;
-        if (it.vy > h) mark[it.y] = next;
+        if (it.vx > h && (it.vx <= a || mark_cur[it.x] == k)) mark_next[it.x] = k + 1;
+        if (it.vy > h && (it.vy <= a || mark_cur[it.y] == k)) mark_next[it.y] = k + 1;
     }
 };
 

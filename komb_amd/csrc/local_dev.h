@@ -44,7 +44,7 @@ struct LocalGraph {                            // the compacted remainder
     uint32_t n, nh;          // units; ids [0, nh) are heavy (more than the problem's kItems items)
     uint32_t *off;           // [n+1] compact slice offsets
     int32_t *val;            // [n] tau
-    int32_t *mark;           // [n] sweep in which the unit is to be evaluated
+    int32_t *mark[2];        // [n] each: mark[k & 1][u] == k <=> u is evaluated in sweep k (written during sweep k-1 only)
     int32_t *gid;            // [n] unit id of the general engine
     uint32_t *len;           // [n+1] live key at hand-over = compact slice length (scan input)
     uint32_t *cur;           // [n] fill cursors of the collect pass
@@ -76,7 +76,7 @@ static __global__ __launch_bounds__(kBlock) void k_local_number(const int32_t *_
                                   : n_live - 1u - (bl + (uint32_t)__popcll(ml & lanemask_lt()));
         if (id >= n_live) { atomicAdd(&ctrl->bad, 1u); continue; }      // more live units than the control block said
         num[u] = (int32_t)id;
-        g.gid[id] = u; g.len[id] = (uint32_t)k; g.val[id] = k; g.mark[id] = 1; g.cur[id] = 0u;
+        g.gid[id] = u; g.len[id] = (uint32_t)k; g.val[id] = k; g.mark[1][id] = 1; g.mark[0][id] = 0; g.cur[id] = 0u;
     }
 }
 
@@ -95,8 +95,11 @@ static __global__ __launch_bounds__(kBlock) void k_local_check(LocalGraph g, Loc
 //   static constexpr int kU;                     items per lane of a light batch (light unit: <= 64 * kU items)
 //   struct Item;  Item load(pos, val) const;     the item's loads
 //   static int32_t value(const Item &);
-//   static void notify(const Item &, int32_t h, int32_t *mark, int32_t next);   unit dropped to h: mark every
-//                                                neighbour whose (visible, possibly stale = too high) value is > h
+//   static void notify(const Item &, int32_t h, int32_t a, const int32_t *mark_cur, int32_t *mark_next, int32_t k);
+//                                                the unit dropped from a to h in sweep k: mark for sweep k+1 every
+//                                                neighbour w whose count this can lower, i.e. h < val[w] <= a -- or just
+//                                                h < val[w] when w is itself evaluated in this sweep (mark_cur[w] == k):
+//                                                only then can the value we see for it be stale (too high)
 template <class P>
 __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, LocalGraph g, P p, int32_t k)
 {
@@ -105,6 +108,8 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
     __shared__ uint32_t sh_hist[kLocHB];
     __shared__ uint32_t sh_part[kLocWaves];
     __shared__ unsigned long long sh_best;
+    __shared__ uint32_t sh_q[kLocBlock];
+    __shared__ uint32_t sh_qn;
     __shared__ int32_t sh_i[2];
     __shared__ uint32_t sh_end[kLocWaves][kWave];
     __shared__ uint32_t sh_a[kLocWaves][4][kWave];
@@ -121,85 +126,100 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
     if (blockIdx.x == 0 && tid == 0) ctrl->chg[(k + 1) % 3] = 0u;     // nobody reads or adds to that slot in this launch
     uint32_t n_changed = 0, n_evals = 0;                 // meaningful in thread 0 (heavy) / lane 0 of each wave (light)
 
-    // ---- heavy units: one workgroup per unit, LDS histogram of the item values, range refined until exact
-    for (uint32_t hu = blockIdx.x; hu < g.nh; hu += gridDim.x) {
-        // one thread reads the unit's mark and value for the workgroup: other workgroups may be re-marking the
-        // unit right now, and the branch below must be uniform
+    // ---- heavy units: workgroup b owns the heavy ids b, b + G, b + 2G, ...; its threads look at their marks
+    // side by side, the marked ones go through an LDS queue, one unit at a time with the whole workgroup:
+    // first a plain count of the items >= cap (most re-evaluations end there), then an LDS histogram of the
+    // item values whose range is refined until it is exact
+    const int32_t *mark_cur = g.mark[k & 1];
+    int32_t *mark_next = g.mark[(k + 1) & 1];
+    for (uint32_t base = blockIdx.x; base < g.nh; base += gridDim.x * kLocBlock) {
         __syncthreads();
-        if (tid == 0) { sh_i[0] = g.mark[hu]; sh_i[1] = g.val[hu]; }
+        if (tid == 0) sh_qn = 0u;
         __syncthreads();
-        if (sh_i[0] != k) continue;
-        const int32_t cap = sh_i[1];
-        if (cap <= 0) continue;
-        const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
-        int32_t lo = 0, hi = cap - 1, H = cap;
-        bool first = true;
-        for (;;) {
-            // histogram of the values in [lo, hi], `above` = values > hi, all from ONE pass over the items
-            const uint32_t width = (uint32_t)(hi - lo) + 1u;
-            int sh = 0;
-            while (((width - 1u) >> sh) >= (uint32_t)kLocHB) ++sh;
-            const uint32_t nb = ((width - 1u) >> sh) + 1u;
-            for (uint32_t i = tid; i < (uint32_t)kLocHB; i += kLocBlock) sh_hist[i] = 0u;
-            if (tid == 0) sh_best = 0ull;
-            __syncthreads();
-            uint32_t ab = 0;
-            for (uint32_t j = tid; j < len; j += kLocBlock) {
-                const typename P::Item it = p.load(beg + j, g.val);
-                const int32_t r = P::value(it);
-                if (r > hi) ++ab;
-                else if (r >= lo) atomicAdd(&sh_hist[(uint32_t)(r - lo) >> sh], 1u);
-            }
-            ab = wave_sum(ab);
-            if (lane == 0) sh_part[w] = ab;
-            __syncthreads();
-            uint32_t above = 0;
-#pragma unroll
-            for (int i = 0; i < kLocWaves; ++i) above += sh_part[i];
-            if (first && above >= (uint32_t)cap) break;                  // still has cap items >= cap: unchanged
-            first = false;
-            // largest bin b with count(values >= lo + (b << sh)) >= lo + (b << sh); thread t owns kLocBins consecutive bins
-            uint32_t h4[kLocBins], mine = 0;
-#pragma unroll
-            for (int i = 0; i < kLocBins; ++i) { h4[i] = sh_hist[kLocBins * tid + i]; mine += h4[i]; }
-            // suffix sum over the threads above this one
-            uint32_t suf = mine;
-            for (int o = 1; o < kWave; o <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)suf, o); if (lane + o < kWave) suf += t; }
-            __syncthreads();                                             // sh_part is reused
-            if (lane == 0) sh_part[w] = suf;                             // wave total
-            __syncthreads();
-            uint32_t run = above + suf - mine;                           // bins above this thread's, inside the wave
-            for (int i = w + 1; i < kLocWaves; ++i) run += sh_part[i];
-            unsigned long long best = 0ull;
-#pragma unroll
-            for (int i = kLocBins - 1; i >= 0; --i) {
-                const uint32_t b = kLocBins * tid + (uint32_t)i;
-                const uint32_t s_above = run;                            // count(values >= start of bin b+1)
-                run += h4[i];                                            // count(values >= start of bin b)
-                if (b < nb && best == 0ull && (unsigned long long)run >= (unsigned long long)lo + ((unsigned long long)b << sh))
-                    best = ((unsigned long long)(b + 1u) << 32) | s_above;
-            }
-            if (best) atomicMax(&sh_best, best);
-            __syncthreads();
-            const unsigned long long bb = sh_best;
-            __syncthreads();
-            if (bb == 0ull) {                                            // values dropped under the range while we looked
-                if (lo == 0) { H = 0; break; }
-                hi = lo - 1; lo = 0;
-                continue;
-            }
-            const uint32_t b = (uint32_t)(bb >> 32) - 1u;
-            const int32_t nlo = lo + (int32_t)(b << sh);
-            const int32_t nhi = min(hi, nlo + (int32_t)((1u << sh) - 1u));
-            lo = nlo; hi = nhi;
-            if (sh == 0) { H = lo; break; }
+        {
+            const uint64_t hu64 = (uint64_t)base + (uint64_t)tid * gridDim.x;
+            if (hu64 < g.nh && mark_cur[hu64] == k) sh_q[atomicAdd(&sh_qn, 1u)] = (uint32_t)hu64;
         }
-        if (tid == 0) ++n_evals;
-        if (H < cap) {
-            if (tid == 0) { g.val[hu] = H; ++n_changed; }
-            for (uint32_t j = tid; j < len; j += kLocBlock) {
-                const typename P::Item it = p.load(beg + j, g.val);
-                P::notify(it, H, g.mark, k + 1);
+        __syncthreads();
+        const uint32_t nq = sh_qn;
+        for (uint32_t qi = 0; qi < nq; ++qi) {
+            const uint32_t hu = sh_q[qi];
+            const int32_t cap = g.val[hu];                       // written by this workgroup only
+            if (cap <= 0) continue;
+            const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
+            int32_t lo = 0, hi = cap - 1, H = cap;
+            {
+                uint32_t ge = 0;
+                for (uint32_t j = tid; j < len; j += kLocBlock) ge += P::value(p.load(beg + j, g.val)) >= cap ? 1u : 0u;
+                ge = wave_sum(ge);
+                __syncthreads();
+                if (lane == 0) sh_part[w] = ge;
+                __syncthreads();
+                uint32_t c0 = 0;
+#pragma unroll
+                for (int i = 0; i < kLocWaves; ++i) c0 += sh_part[i];
+                if (tid == 0) ++n_evals;
+                if (c0 >= (uint32_t)cap) continue;               // still has cap items >= cap: unchanged
+                lo = (int32_t)c0;                                // the c0 items >= cap are >= c0 as well
+            }
+            for (;;) {
+                // histogram of the values in [lo, hi], `above` = values > hi, all from ONE pass over the items
+                const uint32_t width = (uint32_t)(hi - lo) + 1u;
+                int sh = 0;
+                while (((width - 1u) >> sh) >= (uint32_t)kLocHB) ++sh;
+                const uint32_t nb = ((width - 1u) >> sh) + 1u;
+                __syncthreads();
+                for (uint32_t i = tid; i < nb; i += kLocBlock) sh_hist[i] = 0u;
+                if (tid == 0) sh_best = 0ull;
+                __syncthreads();
+                uint32_t ab = 0;
+                for (uint32_t j = tid; j < len; j += kLocBlock) {
+                    const int32_t r = P::value(p.load(beg + j, g.val));
+                    if (r > hi) ++ab;
+                    else if (r >= lo) atomicAdd(&sh_hist[(uint32_t)(r - lo) >> sh], 1u);
+                }
+                ab = wave_sum(ab);
+                if (lane == 0) sh_part[w] = ab;
+                __syncthreads();
+                uint32_t above = 0;
+#pragma unroll
+                for (int i = 0; i < kLocWaves; ++i) above += sh_part[i];
+                // largest bin b with count(values >= lo + (b << sh)) >= lo + (b << sh); thread t owns kLocBins consecutive bins
+                uint32_t h4[kLocBins], mine = 0;
+#pragma unroll
+                for (int i = 0; i < kLocBins; ++i) { const uint32_t bi = kLocBins * tid + (uint32_t)i; h4[i] = bi < nb ? sh_hist[bi] : 0u; mine += h4[i]; }
+                uint32_t suf = mine;                                         // suffix sum over the lanes above, inclusive
+                for (int o = 1; o < kWave; o <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)suf, o); if (lane + o < kWave) suf += t; }
+                __syncthreads();                                             // sh_part is reused
+                if (lane == 0) sh_part[w] = suf;                             // wave total
+                __syncthreads();
+                uint32_t run = above + suf - mine;                           // values in the bins above this thread's
+                for (int i = w + 1; i < kLocWaves; ++i) run += sh_part[i];
+                unsigned long long best = 0ull;
+#pragma unroll
+                for (int i = kLocBins - 1; i >= 0; --i) {
+                    const uint32_t b = kLocBins * tid + (uint32_t)i;
+                    run += h4[i];                                            // count(values >= start of bin b)
+                    if (b < nb && best == 0ull && (unsigned long long)run >= (unsigned long long)lo + ((unsigned long long)b << sh))
+                        best = (unsigned long long)b + 1ull;
+                }
+                if (best) atomicMax(&sh_best, best);
+                __syncthreads();
+                const unsigned long long bb = sh_best;
+                if (bb == 0ull) {                                            // values dropped under the range while we looked
+                    if (lo == 0) { H = 0; break; }
+                    hi = lo - 1; lo = 0;
+                    continue;
+                }
+                const uint32_t b = (uint32_t)bb - 1u;
+                const int32_t nlo = lo + (int32_t)(b << sh);
+                const int32_t nhi = min(hi, nlo + (int32_t)((1u << sh) - 1u));
+                lo = nlo; hi = nhi;
+                if (sh == 0) { H = lo; break; }
+            }
+            if (H < cap) {
+                if (tid == 0) { g.val[hu] = H; ++n_changed; }
+                for (uint32_t j = tid; j < len; j += kLocBlock) P::notify(p.load(beg + j, g.val), H, cap, mark_cur, mark_next, k);
             }
         }
     }
@@ -214,7 +234,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
     const uint32_t gw = blockIdx.x * kLocWaves + (uint32_t)w, nw = gridDim.x * kLocWaves;
     for (uint32_t blk = gw; blk < nblk; blk += nw) {
         const uint32_t u = g.nh + blk * kWave + (uint32_t)lane;
-        const bool act = u < g.n && g.mark[u] == k;
+        const bool act = u < g.n && mark_cur[u] == k;
         const uint64_t am = __ballot(act);
         if (!am) continue;
         const uint32_t na = (uint32_t)__popcll(am);
@@ -290,8 +310,8 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
             const int32_t thr_n = fail ? lo : 0x7FFFFFFF;
 #pragma unroll
             for (int x = 0; x < kU; ++x) {
-                const int32_t th = __shfl(thr_n, t[x]);
-                if (valid[x]) P::notify(it[x], th, g.mark, k + 1);
+                const int32_t th = __shfl(thr_n, t[x]), old = __shfl(mcap, t[x]);
+                if (valid[x] && th != 0x7FFFFFFF) P::notify(it[x], th, old, mark_cur, mark_next, k);
             }
             n_changed += (uint32_t)__popcll(__ballot(fail));
             n_evals += nb;
@@ -385,6 +405,12 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     hipStream_t s = ctx->stream;
     const uint32_t n = hc.remaining;
     if (n == 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "local finish: nothing left to hand over");
+    // KOMB_LOCAL_DEBUG=1: one stderr line per hand-over with the phase times (HIP events)
+    const bool dbg = getenv("KOMB_LOCAL_DEBUG") != nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (dbg) for (auto &e : ev) (void)hipEventCreate(&e);
+    auto stamp = [&](int i) { if (dbg) (void)hipEventRecord(ev[i], s); };
+    stamp(0);
     const int32_t *list = hc.live_mode ? live_list : nullptr;
     const uint32_t n_in = hc.live_mode ? hc.live_count : units;
     LocalGraph g{};
@@ -397,7 +423,8 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, bufs.alloc(&g.off, (size_t)n + 1));
     KOMB_HIP(ctx, bufs.alloc(&g.len, (size_t)n + 1));
     KOMB_HIP(ctx, bufs.alloc(&g.val, (size_t)n));
-    KOMB_HIP(ctx, bufs.alloc(&g.mark, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.mark[0], (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.mark[1], (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.gid, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.cur, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&d_lctrl, 1));
@@ -417,6 +444,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     if (hl.bad || hl.n_heavy + hl.n_light != n)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u live units numbered, the peel counted %u", hl.n_heavy + hl.n_light, n);
     g.nh = hl.n_heavy;
+    stamp(1);
     after_number(g);
     void *d_items = nullptr;
     KOMB_HIP(ctx, bufs.alloc((unsigned char **)&d_items, (size_t)total * item_bytes));
@@ -432,12 +460,22 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     int64_t gn = ((int64_t)n + kBlock - 1) / kBlock;
     const int grid_n = (int)(gn > 1024 ? 1024 : gn);
     k_local_check<<<grid_n, kBlock, 0, s>>>(g, d_lctrl);
+    stamp(2);
 
     int launches = 0;
     KOMB_TRY(run_fix(g, d_items, (uint64_t)total, d_lctrl, &launches));
+    stamp(3);
     k_local_finish<<<grid_n, kBlock, 0, s>>>(g, add, out, d_present, d_lctrl);
     k_local_levels<<<(int)(present_words / kBlock + 1 > 256 ? 256 : present_words / kBlock + 1), kBlock, 0, s>>>(d_present, (uint32_t)present_words, d_lctrl);
+    stamp(4);
     KOMB_HIP(ctx, d2h(ctx, &hl, d_lctrl, sizeof(LocalCtrl)));
+    if (dbg) {
+        float t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        fprintf(stderr, "komb local finish: %u units (%u heavy), %u items; number+scan %.1f us, collect %.1f us, %d sweeps (%d launches, %u evaluations) %.1f us, scatter %.1f us\n",
+                n, g.nh, total, t[0] * 1e3f, t[1] * 1e3f, hl.iters, launches, hl.evals, t[2] * 1e3f, t[3] * 1e3f);
+    }
     if (hl.bad) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u consistency failures in the compact index", hl.bad);
     if (!hl.done) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: launch budget exhausted before the fixed point");
     if (ls) {
@@ -445,7 +483,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
         ls->sweeps = hl.iters; ls->launches = launches; ls->items = total; ls->evals = hl.evals;
     }
     bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
-    bufs.release(g.mark); bufs.release(g.gid); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cctrl); bufs.release(d_present);
+    bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cctrl); bufs.release(d_present);
     return KOMB_OK;
 }
 
