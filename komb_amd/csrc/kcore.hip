@@ -122,7 +122,7 @@ struct CoreCollect {
     {
         if (!ld.live) return;
         const uint32_t id = (uint32_t)num[ld.me];
-        nbr[off[id] + atomicAdd(&cur[id], 1u)] = (uint32_t)num[ld.u];
+        nbr[off[id] + local_slot(id, cur)] = (uint32_t)num[ld.u];
     }
 };
 

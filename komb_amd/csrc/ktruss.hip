@@ -681,7 +681,7 @@ struct TrussCollect {
     {
         if (!marker_alive(ld.sx) || !marker_alive(ld.sy)) return;
         const uint32_t id = (uint32_t)num[ld.me];
-        cpair[coff[id] + atomicAdd(&cur[id], 1u)] = make_uint2((uint32_t)num[ld.x], (uint32_t)num[ld.y]);
+        cpair[coff[id] + local_slot(id, cur)] = make_uint2((uint32_t)num[ld.x], (uint32_t)num[ld.y]);
     }
 };
 

@@ -33,10 +33,11 @@
 
 namespace komb {
 
-constexpr int kLocBlock = 512;                 // 8 wave64 per workgroup: three workgroups per CU at <= 80 VGPRs
+constexpr int kLocBlock = 512;                 // 8 wave64 per workgroup, two workgroups per CU
 constexpr int kLocWaves = kLocBlock / kWave;
 constexpr int kLocHB = 4096;                   // histogram bins of the heavy path
 constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix search
+constexpr int kHvU = 4;                        // items per thread per trip on the heavy path (independent load chains)
 constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
 
 
@@ -53,12 +54,17 @@ struct LocalGraph {                            // the compacted remainder
 // ---- 1. numbering.  `list` (or all `units` when null) holds the candidates; live = alive marker in `marker`;
 // the live key is key[u].  Heavy units get ids from 0 up, light ones from n_live-1 down (the host knows n_live
 // = PeelCtrl::remaining).  Any order inside a class is fine: the fixed point is unique.
-static __global__ __launch_bounds__(kBlock) void k_local_number(const int32_t *__restrict__ list, uint32_t n_in, uint32_t n_live,
+constexpr int kNumBlock = 1024;
+static __global__ __launch_bounds__(kNumBlock) void k_local_number(const int32_t *__restrict__ list, uint32_t n_in, uint32_t n_live,
                                                          const int32_t *__restrict__ marker, const int32_t *__restrict__ key,
                                                          uint32_t light_max, int32_t *__restrict__ num, LocalGraph g, LocalCtrl *ctrl)
 {
-    const int lane = lane_id();
-    for (uint32_t i0 = blockIdx.x * kBlock; i0 < n_in; i0 += gridDim.x * kBlock) {
+    // one reservation per workgroup and trip (two atomics for 1024 candidates): every live unit taking its id with an
+    // atomic of its own queues 10^5..10^6 of them on two words
+    __shared__ uint32_t sh_cnt[kNumBlock / kWave][2];
+    __shared__ uint32_t sh_base[2];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    for (uint32_t i0 = blockIdx.x * kNumBlock; i0 < n_in; i0 += gridDim.x * kNumBlock) {
         const uint32_t i = i0 + threadIdx.x;
         int32_t u = -1, k = 0;
         if (i < n_in) {
@@ -67,17 +73,49 @@ static __global__ __launch_bounds__(kBlock) void k_local_number(const int32_t *_
         }
         const bool heavy = u >= 0 && (uint32_t)k > light_max, light = u >= 0 && !heavy;
         const uint64_t mh = __ballot(heavy), ml = __ballot(light);
-        uint32_t base = 0;
-        if (lane == 0 && mh) base = atomicAdd(&ctrl->n_heavy, (uint32_t)__popcll(mh));
-        else if (lane == 1 && ml) base = atomicAdd(&ctrl->n_light, (uint32_t)__popcll(ml));
-        const uint32_t bh = (uint32_t)__shfl((int)base, 0), bl = (uint32_t)__shfl((int)base, 1);
+        __syncthreads();
+        if (lane == 0) { sh_cnt[w][0] = (uint32_t)__popcll(mh); sh_cnt[w][1] = (uint32_t)__popcll(ml); }
+        __syncthreads();
+        uint32_t bh = 0, bl = 0, th = 0, tl = 0;
+#pragma unroll
+        for (int x = 0; x < kNumBlock / kWave; ++x) {
+            const uint32_t a = sh_cnt[x][0], b = sh_cnt[x][1];
+            if (x < w) { bh += a; bl += b; }
+            th += a; tl += b;
+        }
+        if (threadIdx.x == 0) {
+            sh_base[0] = th ? atomicAdd(&ctrl->n_heavy, th) : 0u;
+            sh_base[1] = tl ? atomicAdd(&ctrl->n_light, tl) : 0u;
+        }
+        __syncthreads();
         if (u < 0) continue;
-        const uint32_t id = heavy ? bh + (uint32_t)__popcll(mh & lanemask_lt())
-                                  : n_live - 1u - (bl + (uint32_t)__popcll(ml & lanemask_lt()));
+        const uint32_t id = heavy ? sh_base[0] + bh + (uint32_t)__popcll(mh & lanemask_lt())
+                                  : n_live - 1u - (sh_base[1] + bl + (uint32_t)__popcll(ml & lanemask_lt()));
         if (id >= n_live) { atomicAdd(&ctrl->bad, 1u); continue; }      // more live units than the control block said
         num[u] = (int32_t)id;
         g.gid[id] = u; g.len[id] = (uint32_t)k; g.val[id] = k; g.mark[1][id] = 1; g.mark[0][id] = 0; g.cur[id] = 0u;
     }
+}
+
+// Collect pass: position of this lane's entry in the compact slice of unit `id`.  Called by the lanes that have a live
+// item (divergent); lanes of one unit share ONE cursor atomic (every item of a hub taking its slot with an atomic of its
+// own queues them all on one word).
+__device__ __forceinline__ uint32_t local_slot(uint32_t id, uint32_t *cur)
+{
+    const int lane = lane_id();
+    uint64_t todo = __ballot(true);
+    uint32_t pos = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lid = (uint32_t)__shfl((int)id, leader);
+        const uint64_t grp = __ballot(id == lid) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&cur[lid], (uint32_t)__popcll(grp));
+        base = (uint32_t)__shfl((int)base, leader);
+        if ((grp >> lane) & 1ull) pos = base + (uint32_t)__popcll(grp & lanemask_lt());
+        todo &= ~grp;
+    }
+    return pos;
 }
 
 // after the collect pass: every compact slice must be exactly full
@@ -150,7 +188,13 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
             int32_t lo = 0, hi = cap - 1, H = cap;
             {
                 uint32_t ge = 0;
-                for (uint32_t j = tid; j < len; j += kLocBlock) ge += P::value(p.load(beg + j, g.val)) >= cap ? 1u : 0u;
+                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {      // kHvU independent load chains in flight
+                    int32_t r[kHvU];
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? P::value(p.load(beg + j, g.val)) : -1; }
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) ge += r[x] >= cap ? 1u : 0u;
+                }
                 ge = wave_sum(ge);
                 __syncthreads();
                 if (lane == 0) sh_part[w] = ge;
@@ -173,10 +217,15 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
                 if (tid == 0) sh_best = 0ull;
                 __syncthreads();
                 uint32_t ab = 0;
-                for (uint32_t j = tid; j < len; j += kLocBlock) {
-                    const int32_t r = P::value(p.load(beg + j, g.val));
-                    if (r > hi) ++ab;
-                    else if (r >= lo) atomicAdd(&sh_hist[(uint32_t)(r - lo) >> sh], 1u);
+                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
+                    int32_t r[kHvU];
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? P::value(p.load(beg + j, g.val)) : -1; }
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) {
+                        if (r[x] > hi) ++ab;
+                        else if (r[x] >= lo) atomicAdd(&sh_hist[(uint32_t)(r[x] - lo) >> sh], 1u);
+                    }
                 }
                 ab = wave_sum(ab);
                 if (lane == 0) sh_part[w] = ab;
@@ -219,7 +268,13 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
             }
             if (H < cap) {
                 if (tid == 0) { g.val[hu] = H; ++n_changed; }
-                for (uint32_t j = tid; j < len; j += kLocBlock) P::notify(p.load(beg + j, g.val), H, cap, mark_cur, mark_next, k);
+                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
+                    typename P::Item it[kHvU];
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; if (j < len) it[x] = p.load(beg + j, g.val); }
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; if (j < len) P::notify(it[x], H, cap, mark_cur, mark_next, k); }
+                }
             }
         }
     }
@@ -327,14 +382,15 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
 
 // ---- 4. results back to the general engine's arrays (+ statistics: largest value, which values occur)
 static __global__ __launch_bounds__(kBlock) void k_local_finish(LocalGraph g, int32_t add, int32_t *__restrict__ out,
-                                                         uint32_t *__restrict__ present, LocalCtrl *ctrl)
+                                                         uint32_t *present, LocalCtrl *ctrl)
 {
     int32_t mx = 0;
     for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < g.n; id += gridDim.x * kBlock) {
         const int32_t v = g.val[id];
         out[g.gid[id]] = v + add;
         mx = max(mx, v);
-        atomicOr(&present[(uint32_t)v >> 5], 1u << ((uint32_t)v & 31u));
+        // a few distinct values, 10^5..10^6 units: only the first writers of a bit use the atomic
+        if (!((present[(uint32_t)v >> 5] >> ((uint32_t)v & 31u)) & 1u)) atomicOr(&present[(uint32_t)v >> 5], 1u << ((uint32_t)v & 31u));
     }
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
     if (lane_id() == 0 && mx) atomicMax(&ctrl->max_val, mx);
@@ -353,7 +409,7 @@ template <class P>
 int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, const LocalGraph &g, const P &p, uint64_t total_items, int *launches_out)
 {
     hipStream_t s = ctx->stream;
-    const int grid = 768;                                 // three 512-thread workgroups per CU
+    const int grid = 512;                                 // two 512-thread workgroups per CU (<= 96 VGPRs)
     hipEvent_t ev[2] = {nullptr, nullptr};
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
@@ -434,8 +490,8 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, hipMemsetAsync(g.len + n, 0, sizeof(uint32_t), s));
     KOMB_HIP(ctx, hipMemsetAsync(d_present, 0, present_words * sizeof(uint32_t), s));
     g.n = n; g.nh = 0;
-    int64_t gb = ((int64_t)n_in + kBlock - 1) / kBlock;
-    k_local_number<<<(int)(gb < 1 ? 1 : (gb > 2048 ? 2048 : gb)), kBlock, 0, s>>>(list, n_in, n, marker, key, light_max, d_num, g, d_lctrl);
+    int64_t gb = ((int64_t)n_in + kNumBlock - 1) / kNumBlock;
+    k_local_number<<<(int)(gb < 1 ? 1 : (gb > 1024 ? 1024 : gb)), kNumBlock, 0, s>>>(list, n_in, n, marker, key, light_max, d_num, g, d_lctrl);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, g.len, g.off, (int64_t)n + 1));
     LocalCtrl hl{};
     uint32_t total = 0;
