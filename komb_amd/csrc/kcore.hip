@@ -128,7 +128,7 @@ struct CoreCollect {
 
 // Fixed-point problem: item = a live neighbour, value = its current bound.
 struct CoreLocal {
-    static constexpr int kU = 4;         // light unit: <= 256 live neighbours
+    static constexpr int kU = 8;         // light unit: <= 512 live neighbours (one batch = 64 lanes x 8 values)
     const uint32_t *nbr;
     struct Item { uint32_t a; int32_t va; };
     __device__ __forceinline__ Item load(uint32_t pos, const int32_t *val) const

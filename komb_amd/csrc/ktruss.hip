@@ -687,7 +687,7 @@ struct TrussCollect {
 
 // Fixed-point problem: item = a live triangle, value = the smaller bound of its other two edges.
 struct TrussLocal {
-    static constexpr int kU = 4;         // light unit: <= 256 live triangles
+    static constexpr int kU = 8;         // light unit: <= 512 live triangles (one batch = 64 lanes x 8 values)
     const uint2 *cpair;
     struct Item { uint32_t x, y; int32_t vx, vy; };
     __device__ __forceinline__ Item load(uint32_t pos, const int32_t *val) const

@@ -280,16 +280,20 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
     }
     __syncthreads();
 
-    // ---- light units: a wavefront takes 64 consecutive ids, packs the marked ones, and evaluates them in
-    // batches of <= 64 * kU items flattened over the lanes; counts are ballots masked by each unit's lane range
+    // ---- light units: a wavefront takes a group of consecutive ids (64, fewer when there are fewer groups than
+    // wavefronts), packs the marked ones, and evaluates them in batches of <= 64 * kU items flattened over the lanes.
+    // Only the item VALUES stay in registers (and each item's owner, a byte): counts are ballots masked by each unit's
+    // lane range.  The items of the few units that change are loaded again for the notification.
     uint32_t *s_end = sh_end[w];
     uint32_t (*s_a)[kWave] = sh_a[w];
     const uint32_t nlight = g.n - g.nh;
-    const uint32_t nblk = (nlight + kWave - 1) / kWave;
-    const uint32_t gw = blockIdx.x * kLocWaves + (uint32_t)w, nw = gridDim.x * kLocWaves;
-    for (uint32_t blk = gw; blk < nblk; blk += nw) {
-        const uint32_t u = g.nh + blk * kWave + (uint32_t)lane;
-        const bool act = u < g.n && mark_cur[u] == k;
+    const uint32_t nw = gridDim.x * kLocWaves;
+    uint32_t gsz = kWave;
+    while (gsz > 1 && (nlight + gsz - 1) / gsz < nw) gsz >>= 1;
+    const uint32_t ngrp = (nlight + gsz - 1) / gsz;
+    for (uint32_t grp = blockIdx.x * kLocWaves + (uint32_t)w; grp < ngrp; grp += nw) {
+        const uint32_t u = g.nh + grp * gsz + (uint32_t)lane;
+        const bool act = (uint32_t)lane < gsz && u < g.n && mark_cur[u] == k;
         const uint64_t am = __ballot(act);
         if (!am) continue;
         const uint32_t na = (uint32_t)__popcll(am);
@@ -318,32 +322,34 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
             __builtin_amdgcn_wave_barrier();
             s_end[lane] = own ? incl : 0xFFFFFFFFu;
             __builtin_amdgcn_wave_barrier();
-            typename P::Item it[kU];
             int32_t r[kU];
-            int t[kU];
-            bool valid[kU];
+            uint32_t tp[(kU + 3) / 4];                   // owner of item x: byte x of tp
+#pragma unroll
+            for (int x = 0; x < (kU + 3) / 4; ++x) tp[x] = 0u;
+            auto owner_of = [&](int x) -> int { return (int)((tp[x >> 2] >> (8 * (x & 3))) & 0xFFu); };
+            auto item_pos = [&](int x, int o) -> uint32_t {
+                const uint32_t idx = (uint32_t)(x * kWave + lane);
+                return s_a[1][start + (uint32_t)o] + (idx - (o ? s_end[o - 1] : 0u));
+            };
 #pragma unroll
             for (int x = 0; x < kU; ++x) {
                 const uint32_t idx = (uint32_t)(x * kWave + lane);
-                valid[x] = idx < total;
                 int o = 0;                               // owner: smallest t with s_end[t] > idx
 #pragma unroll
                 for (int st = kWave / 2; st > 0; st >>= 1) o += (s_end[o + st - 1] <= idx) ? st : 0;
-                t[x] = valid[x] ? o : 0;
-                r[x] = 0;
-                if (valid[x]) {
-                    const uint32_t f = o ? s_end[o - 1] : 0u;
-                    it[x] = p.load(s_a[1][start + (uint32_t)o] + (idx - f), g.val);
-                    r[x] = P::value(it[x]);
+                r[x] = -1;                               // an empty slot never counts
+                if (idx < total) {
+                    tp[x >> 2] |= (uint32_t)o << (8 * (x & 3));
+                    r[x] = P::value(p.load(item_pos(x, o), g.val));
                 }
             }
-            // per-owner count of its items with value >= thr (thr differs per owner)
+            // per-owner count of its items with value >= thr (thr differs per owner; thr >= 0)
             auto count_ge = [&](int32_t thr) -> uint32_t {
                 uint32_t c = 0;
 #pragma unroll
                 for (int x = 0; x < kU; ++x) {
-                    const int32_t th = __shfl(thr, t[x]);
-                    const uint64_t B = __ballot(valid[x] && r[x] >= th);
+                    const int32_t th = __shfl(thr, owner_of(x));
+                    const uint64_t B = __ballot(r[x] >= th);
                     int a = first - x * kWave, b = last - x * kWave;
                     a = a < 0 ? 0 : a; b = b > kWave ? kWave : b;
                     if (b > a) {
@@ -353,22 +359,26 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
                 }
                 return c;
             };
-            const uint32_t c0 = count_ge(mcap);
+            const uint32_t c0 = count_ge(mcap > 0 ? mcap : 0);
             const bool fail = own && mcap > 0 && c0 < (uint32_t)mcap;
             int32_t lo = fail ? (int32_t)c0 : mcap, hi = fail ? mcap - 1 : mcap;   // H >= c0: the c0 items >= cap are >= c0 too
             while (__ballot(lo < hi)) {
                 const int32_t mid = (int32_t)(((int64_t)lo + hi + 1) >> 1);
-                const uint32_t c = count_ge(mid);
+                const uint32_t c = count_ge(mid > 0 ? mid : 0);
                 if (lo < hi) { if (c >= (uint32_t)mid) lo = mid; else hi = mid - 1; }
             }
-            if (fail) g.val[mu] = lo;
-            const int32_t thr_n = fail ? lo : 0x7FFFFFFF;
+            const uint64_t fm = __ballot(fail);
+            if (fm) {
+                if (fail) g.val[mu] = lo;
+                const int32_t thr_n = fail ? lo : 0x7FFFFFFF;
 #pragma unroll
-            for (int x = 0; x < kU; ++x) {
-                const int32_t th = __shfl(thr_n, t[x]), old = __shfl(mcap, t[x]);
-                if (valid[x] && th != 0x7FFFFFFF) P::notify(it[x], th, old, mark_cur, mark_next, k);
+                for (int x = 0; x < kU; ++x) {
+                    const int o = owner_of(x);
+                    const int32_t th = __shfl(thr_n, o), old = __shfl(mcap, o);
+                    if (r[x] >= 0 && th != 0x7FFFFFFF) P::notify(p.load(item_pos(x, o), g.val), th, old, mark_cur, mark_next, k);
+                }
             }
-            n_changed += (uint32_t)__popcll(__ballot(fail));
+            n_changed += (uint32_t)__popcll(fm);
             n_evals += nb;
             start += nb;
             __builtin_amdgcn_wave_barrier();
@@ -381,17 +391,26 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
 }
 
 // ---- 4. results back to the general engine's arrays (+ statistics: largest value, which values occur)
+constexpr uint32_t kFinWords = 2048;               // values below 65536 go through a bitmap in LDS
 static __global__ __launch_bounds__(kBlock) void k_local_finish(LocalGraph g, int32_t add, int32_t *__restrict__ out,
                                                          uint32_t *present, LocalCtrl *ctrl)
 {
+    // which values occur: 10^5..10^6 units share a few dozen values, so the bits are collected per workgroup in LDS
+    // and every workgroup ORs its non-zero words into the global bitmap once
+    __shared__ uint32_t sh_bits[kFinWords];
+    for (uint32_t i = threadIdx.x; i < kFinWords; i += kBlock) sh_bits[i] = 0u;
+    __syncthreads();
     int32_t mx = 0;
     for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < g.n; id += gridDim.x * kBlock) {
         const int32_t v = g.val[id];
         out[g.gid[id]] = v + add;
         mx = max(mx, v);
-        // a few distinct values, 10^5..10^6 units: only the first writers of a bit use the atomic
-        if (!((present[(uint32_t)v >> 5] >> ((uint32_t)v & 31u)) & 1u)) atomicOr(&present[(uint32_t)v >> 5], 1u << ((uint32_t)v & 31u));
+        const uint32_t wd = (uint32_t)v >> 5, bit = 1u << ((uint32_t)v & 31u);
+        if (wd < kFinWords) { if (!(sh_bits[wd] & bit)) atomicOr(&sh_bits[wd], bit); }
+        else atomicOr(&present[wd], bit);
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kFinWords; i += kBlock) if (sh_bits[i]) atomicOr(&present[i], sh_bits[i]);
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
     if (lane_id() == 0 && mx) atomicMax(&ctrl->max_val, mx);
 }
@@ -420,8 +439,16 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, const LocalGraph &g, const 
     int launches = 0, slot = 0, status = KOMB_OK;
     bool have_prev = false, finished = false;
     int32_t k = 0;
+    // KOMB_LOCAL_DEBUG=2: an event after every launch, the per-sweep times on stderr
+    const char *dbg_env = getenv("KOMB_LOCAL_DEBUG");
+    const bool per_sweep = dbg_env && atoi(dbg_env) >= 2;
+    std::vector<hipEvent_t> sw;
+    if (per_sweep) { sw.resize(1); (void)hipEventCreate(&sw[0]); (void)hipEventRecord(sw[0], s); }
     while (!finished && (uint64_t)launches < max_launches && k < 0x3FFFFFF0) {
-        for (int i = 0; i < kLocBatch; ++i) { ++k; k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, g, p, k); ++launches; }
+        for (int i = 0; i < kLocBatch; ++i) {
+            ++k; k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, g, p, k); ++launches;
+            if (per_sweep && sw.size() < 600) { hipEvent_t e2; (void)hipEventCreate(&e2); (void)hipEventRecord(e2, s); sw.push_back(e2); }
+        }
         if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipEventRecord(ev[slot], s) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
         if (have_prev) {
@@ -434,6 +461,12 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, const LocalGraph &g, const 
     hipError_t e = hipStreamSynchronize(s);
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
+    if (per_sweep) {
+        fprintf(stderr, "komb local sweeps (us):");
+        for (size_t i = 1; i < sw.size(); ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, sw[i - 1], sw[i]); fprintf(stderr, " %.0f", ms * 1e3f); }
+        fprintf(stderr, "\n");
+        for (auto &x : sw) (void)hipEventDestroy(x);
+    }
     if (launches_out) *launches_out = launches;
     if (status != KOMB_OK || e != hipSuccess)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local fixed point: HIP failure (%s)", hipGetErrorString(e));
@@ -474,7 +507,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     LocalCtrl *d_lctrl = nullptr;
     PeelCtrl *d_cctrl = nullptr;
     uint32_t *d_present = nullptr;
-    const size_t present_words = ((size_t)units >> 5) + 2;
+    const size_t present_words = ((size_t)units >> 5) + 2 > kFinWords ? ((size_t)units >> 5) + 2 : (size_t)kFinWords;
     KOMB_HIP(ctx, bufs.alloc(&d_num, (size_t)units));
     KOMB_HIP(ctx, bufs.alloc(&g.off, (size_t)n + 1));
     KOMB_HIP(ctx, bufs.alloc(&g.len, (size_t)n + 1));
