@@ -60,7 +60,7 @@ static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
 struct LocalCtrl {
     int32_t  done;           // 1 once a sweep changed nothing
     int32_t  iters;          // sweeps run (including the one that changed nothing)
-    uint32_t chg[3];         // units whose value dropped in sweep k: chg[k % 3]
+    uint32_t spare[3];       // (the per-sweep change counters live in their own array, spread over several lines)
     uint32_t bad;            // consistency failures (a compact slice whose fill differs from the live key, ...)
     int32_t  max_val;        // largest final value (k_local_finish)
     uint32_t levels;         // distinct final values (k_local_levels)

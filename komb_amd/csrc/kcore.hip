@@ -292,8 +292,8 @@ int core_run(komb_ctx *ctx)
                 CoreCollect C{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, ctx->d_core, d_livebits, num, lg.off, lg.cur, (uint32_t *)items};
                 k_peel_step<CoreCollect><<<grid, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C);
             },
-            [&](const LocalGraph &lg, void *items, uint64_t total, LocalCtrl *d_lctrl, int *launches) -> int {
-                return local_fixpoint(ctx, d_lctrl, lg, CoreLocal{(const uint32_t *)items}, total, launches);
+            [&](const LocalGraph &lg, void *items, uint64_t total, LocalCtrl *d_lctrl, uint32_t *d_cnt, int *launches) -> int {
+                return local_fixpoint(ctx, d_lctrl, d_cnt, lg, CoreLocal{(const uint32_t *)items}, total, launches);
             },
             &ls,
             [&](const LocalGraph &lg) { k_live_bits<<<(int)((lg.n + 255) / 256 > 1024 ? 1024 : (lg.n + 255) / 256), 256, 0, s>>>(lg.gid, lg.n, d_livebits); });

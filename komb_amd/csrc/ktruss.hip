@@ -1100,8 +1100,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 TrussCollect C{(uint32_t)m, d_off, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
                 k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C);
             },
-            [&](const LocalGraph &lg, void *items, uint64_t total_items, LocalCtrl *d_lctrl, int *nl) -> int {
-                return local_fixpoint(ctx, d_lctrl, lg, TrussLocal{(const uint2 *)items}, total_items, nl);
+            [&](const LocalGraph &lg, void *items, uint64_t total_items, LocalCtrl *d_lctrl, uint32_t *d_cnt, int *nl) -> int {
+                return local_fixpoint(ctx, d_lctrl, d_cnt, lg, TrussLocal{(const uint2 *)items}, total_items, nl);
             },
             &ls, [](const LocalGraph &) {});
         (void)hipEventRecord(ev[1], s);

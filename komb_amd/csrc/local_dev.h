@@ -37,6 +37,8 @@ constexpr int kLocBlock = 512;                 // 8 wave64 per workgroup, two wo
 constexpr int kLocWaves = kLocBlock / kWave;
 constexpr int kLocHB = 4096;                   // histogram bins of the heavy path
 constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix search
+constexpr int kCntWays = 8;                    // per-sweep counters are spread over this many 128-byte lines
+constexpr int kCntWords = 4 * kCntWays * 32;   // 3 ring slots of change counters + 1 of evaluation counters
 constexpr int kHvU = 4;                        // items per thread per trip on the heavy path (independent load chains)
 constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
 
@@ -139,8 +141,11 @@ static __global__ __launch_bounds__(kBlock) void k_local_check(LocalGraph g, Loc
 //                                                h < val[w] when w is itself evaluated in this sweep (mark_cur[w] == k):
 //                                                only then can the value we see for it be stale (too high)
 template <class P>
-__global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, LocalGraph g, P p, int32_t k)
+__global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint32_t *cnt, LocalGraph g, P p, int32_t k)
 {
+    // cnt: per-sweep counters spread over kCntWays words on separate 128-byte lines (a single word would queue one
+    // atomic per workgroup, ~88 per microsecond): cnt[(slot * kCntWays + way) * 32 + 0] = units changed in the sweep
+    // using ring slot `slot` = sweep % 3; + 1 = evaluations (statistics)
     constexpr int kU = P::kU;
     constexpr uint32_t kItems = (uint32_t)kWave * kU;
     __shared__ uint32_t sh_hist[kLocHB];
@@ -154,14 +159,17 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id(), w = (int)(tid >> 6);
 
-    if (tid == 0) { sh_i[0] = ctrl->done; sh_i[1] = (k > 1) ? (int32_t)ctrl->chg[(k - 1) % 3] : 1; }
+    if (tid < (uint32_t)kCntWays) sh_part[tid] = (k > 1) ? cnt[(((k - 1) % 3) * kCntWays + tid) * 32] : 1u;
+    if (tid == 0) sh_i[0] = ctrl->done;
+    __syncthreads();
+    if (tid == 0) { uint32_t c = 0; for (int i = 0; i < kCntWays; ++i) c += sh_part[i]; sh_i[1] = c ? 1 : 0; }
     __syncthreads();
     if (sh_i[0]) return;
     if (sh_i[1] == 0) {                                  // the previous sweep changed nothing: fixed point
         if (blockIdx.x == 0 && tid == 0) { ctrl->done = 1; ctrl->iters = k - 1; }
         return;
     }
-    if (blockIdx.x == 0 && tid == 0) ctrl->chg[(k + 1) % 3] = 0u;     // nobody reads or adds to that slot in this launch
+    if (blockIdx.x == 0 && tid < (uint32_t)kCntWays) cnt[(((k + 1) % 3) * kCntWays + tid) * 32] = 0u;   // nobody reads or adds to that slot in this launch
     uint32_t n_changed = 0, n_evals = 0;                 // meaningful in thread 0 (heavy) / lane 0 of each wave (light)
 
     // ---- heavy units: workgroup b owns the heavy ids b, b + G, b + 2G, ...; its threads look at their marks
@@ -384,9 +392,16 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, Local
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (lane == 0) {
-        if (n_changed) atomicAdd(&ctrl->chg[k % 3], n_changed);
-        if (n_evals) atomicAdd(&ctrl->evals, n_evals);
+    // one add per workgroup, spread over kCntWays words
+    __syncthreads();
+    if (lane == 0) { sh_end[w][0] = n_changed; sh_end[w][1] = n_evals; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0, e = 0;
+        for (int i = 0; i < kLocWaves; ++i) { c += sh_end[i][0]; e += sh_end[i][1]; }
+        uint32_t *mine = cnt + ((k % 3) * kCntWays + (blockIdx.x % kCntWays)) * 32;
+        if (c) atomicAdd(mine, c);
+        if (e) atomicAdd(cnt + (3 * kCntWays + (blockIdx.x % kCntWays)) * 32, e);
     }
 }
 
@@ -409,13 +424,18 @@ static __global__ __launch_bounds__(kBlock) void k_local_finish(LocalGraph g, in
         if (wd < kFinWords) { if (!(sh_bits[wd] & bit)) atomicOr(&sh_bits[wd], bit); }
         else atomicOr(&present[wd], bit);
     }
+    __shared__ int32_t sh_mx;
+    if (threadIdx.x == 0) sh_mx = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kFinWords; i += kBlock) if (sh_bits[i]) atomicOr(&present[i], sh_bits[i]);
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-    if (lane_id() == 0 && mx) atomicMax(&ctrl->max_val, mx);
+    if (lane_id() == 0 && mx) atomicMax(&sh_mx, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && sh_mx) atomicMax(&ctrl->max_val, sh_mx);           // one per workgroup
 }
-static __global__ __launch_bounds__(kBlock) void k_local_levels(const uint32_t *__restrict__ present, uint32_t words, LocalCtrl *ctrl)
+static __global__ __launch_bounds__(kBlock) void k_local_levels(const uint32_t *__restrict__ present, uint32_t words, const uint32_t *__restrict__ cnt, LocalCtrl *ctrl)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { uint32_t e = 0; for (int i = 0; i < kCntWays; ++i) e += cnt[(3 * kCntWays + i) * 32]; ctrl->evals = e; }
     uint32_t c = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < words; i += gridDim.x * kBlock) c += (uint32_t)__popc(present[i]);
     c = wave_sum(c);
@@ -425,7 +445,7 @@ static __global__ __launch_bounds__(kBlock) void k_local_levels(const uint32_t *
 // Sweep until the control block reports the fixed point.  Like drive_peel: the host keeps a batch of launches
 // queued and looks at a copy of the control block one batch behind.
 template <class P>
-int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, const LocalGraph &g, const P &p, uint64_t total_items, int *launches_out)
+int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const LocalGraph &g, const P &p, uint64_t total_items, int *launches_out)
 {
     hipStream_t s = ctx->stream;
     const int grid = 512;                                 // two 512-thread workgroups per CU (<= 96 VGPRs)
@@ -446,7 +466,7 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, const LocalGraph &g, const 
     if (per_sweep) { sw.resize(1); (void)hipEventCreate(&sw[0]); (void)hipEventRecord(sw[0], s); }
     while (!finished && (uint64_t)launches < max_launches && k < 0x3FFFFFF0) {
         for (int i = 0; i < kLocBatch; ++i) {
-            ++k; k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, g, p, k); ++launches;
+            ++k; k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, d_cnt, g, p, k); ++launches;
             if (per_sweep && sw.size() < 600) { hipEvent_t e2; (void)hipEventCreate(&e2); (void)hipEventRecord(e2, s); sw.push_back(e2); }
         }
         if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -484,7 +504,7 @@ struct LocalStats {
 // scatter.  hc = the peel's control block as the host last read it (done == 3, or the initial state of a small
 // input); marker / key = the peel's alive markers and live keys; `out` receives value + add for every unit of
 // the remainder.  launch_collect(g, num, items, d_cctrl) issues ONE launch of k_peel_step<Collect>;
-// run_fix(g, items, total, d_lctrl, &launches) = local_fixpoint<Local>; after_number(g) runs once the ids exist
+// run_fix(g, items, total, d_lctrl, d_cnt, &launches) = local_fixpoint<Local>; after_number(g) runs once the ids exist
 // (k-core builds its bitmap of live vertices there).
 template <class LaunchCollect, class RunFix, class AfterNumber>
 int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_ctrl, uint32_t units, const int32_t *marker,
@@ -517,6 +537,9 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, bufs.alloc(&g.gid, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.cur, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&d_lctrl, 1));
+    uint32_t *d_cnt = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)kCntWords));
+    KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntWords * sizeof(uint32_t), s));
     KOMB_HIP(ctx, bufs.alloc(&d_cctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&d_present, present_words));
     KOMB_HIP(ctx, hipMemsetAsync(d_lctrl, 0, sizeof(LocalCtrl), s));
@@ -552,10 +575,10 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     stamp(2);
 
     int launches = 0;
-    KOMB_TRY(run_fix(g, d_items, (uint64_t)total, d_lctrl, &launches));
+    KOMB_TRY(run_fix(g, d_items, (uint64_t)total, d_lctrl, d_cnt, &launches));
     stamp(3);
     k_local_finish<<<grid_n, kBlock, 0, s>>>(g, add, out, d_present, d_lctrl);
-    k_local_levels<<<(int)(present_words / kBlock + 1 > 256 ? 256 : present_words / kBlock + 1), kBlock, 0, s>>>(d_present, (uint32_t)present_words, d_lctrl);
+    k_local_levels<<<(int)(present_words / kBlock + 1 > 256 ? 256 : present_words / kBlock + 1), kBlock, 0, s>>>(d_present, (uint32_t)present_words, d_cnt, d_lctrl);
     stamp(4);
     KOMB_HIP(ctx, d2h(ctx, &hl, d_lctrl, sizeof(LocalCtrl)));
     if (dbg) {
@@ -572,7 +595,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
         ls->sweeps = hl.iters; ls->launches = launches; ls->items = total; ls->evals = hl.evals;
     }
     bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
-    bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cctrl); bufs.release(d_present);
+    bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cnt); bufs.release(d_cctrl); bufs.release(d_present);
     return KOMB_OK;
 }
 
