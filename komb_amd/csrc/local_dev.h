@@ -39,6 +39,7 @@ constexpr int kLocHB = 4096;                   // histogram bins of the heavy pa
 constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix search
 constexpr int kCntWays = 8;                    // per-sweep counters are spread over this many 128-byte lines
 constexpr int kCntWords = 4 * kCntWays * 32;   // 3 ring slots of change counters + 1 of evaluation counters
+constexpr int kCntTimerWords = 4 * 8 * 2;      // -DKOMB_LOCAL_TIMERS: 4 sweeps x 8 64-bit stopwatch sums behind the counters
 constexpr int kHvU = 4;                        // items per thread per trip on the heavy path (independent load chains)
 constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
 
@@ -171,6 +172,16 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     }
     if (blockIdx.x == 0 && tid < (uint32_t)kCntWays) cnt[(((k + 1) % 3) * kCntWays + tid) * 32] = 0u;   // nobody reads or adds to that slot in this launch
     uint32_t n_changed = 0, n_evals = 0;                 // meaningful in thread 0 (heavy) / lane 0 of each wave (light)
+#ifdef KOMB_LOCAL_TIMERS
+    // per-wave stopwatch (100 MHz): [0] heavy section, [1] group setup (marks, offsets), [2] item loads + first count,
+    // [3] search, [4] notification, [5] batches; summed over the waves into cnt[tm_base ..], the slowest wave's total in [6]
+    unsigned long long tmv[6] = {0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+    const unsigned long long tstart = tlast;
+    auto tick = [&](int i) { const unsigned long long now = wall_clock64(); tmv[i] += now - tlast; tlast = now; };
+#define KOMB_LT(i) tick(i)
+#else
+#define KOMB_LT(i) do { } while (0)
+#endif
 
     // ---- heavy units: workgroup b owns the heavy ids b, b + G, b + 2G, ...; its threads look at their marks
     // side by side, the marked ones go through an LDS queue, one unit at a time with the whole workgroup:
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
         }
     }
     __syncthreads();
+    KOMB_LT(0);
 
     // ---- light units: a wavefront takes a group of consecutive ids (64, fewer when there are fewer groups than
     // wavefronts), packs the marked ones, and evaluates them in batches of <= 64 * kU items flattened over the lanes.
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             s_a[0][q] = u; s_a[1][q] = b0; s_a[2][q] = g.off[u + 1] - b0; s_a[3][q] = (uint32_t)g.val[u];
         }
         __builtin_amdgcn_wave_barrier();
+        KOMB_LT(1);
         for (uint32_t start = 0; start < na;) {
             const bool has = start + (uint32_t)lane < na;
             uint32_t mu = 0, mlen = 0;
@@ -368,6 +381,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 return c;
             };
             const uint32_t c0 = count_ge(mcap > 0 ? mcap : 0);
+            KOMB_LT(2);
             const bool fail = own && mcap > 0 && c0 < (uint32_t)mcap;
             int32_t lo = fail ? (int32_t)c0 : mcap, hi = fail ? mcap - 1 : mcap;   // H >= c0: the c0 items >= cap are >= c0 too
             while (__ballot(lo < hi)) {
@@ -376,6 +390,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 if (lo < hi) { if (c >= (uint32_t)mid) lo = mid; else hi = mid - 1; }
             }
             const uint64_t fm = __ballot(fail);
+            KOMB_LT(3);
             if (fm) {
                 if (fail) g.val[mu] = lo;
                 const int32_t thr_n = fail ? lo : 0x7FFFFFFF;
@@ -390,8 +405,20 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             n_evals += nb;
             start += nb;
             __builtin_amdgcn_wave_barrier();
+#ifdef KOMB_LOCAL_TIMERS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tick(4); tmv[5] += 1;
+#endif
         }
     }
+#ifdef KOMB_LOCAL_TIMERS
+    if (lane == 0 && k <= 4) {                           // the first four sweeps
+        unsigned long long *tm = reinterpret_cast<unsigned long long *>(cnt + kCntWords) + (k - 1) * 8;
+        for (int i = 0; i < 6; ++i) atomicAdd(&tm[i], tmv[i]);
+        atomicMax(&tm[6], wall_clock64() - tstart);
+        atomicAdd(&tm[7], 1ull);
+    }
+#endif
     // one add per workgroup, spread over kCntWays words
     __syncthreads();
     if (lane == 0) { sh_end[w][0] = n_changed; sh_end[w][1] = n_evals; }
@@ -538,8 +565,8 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, bufs.alloc(&g.cur, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&d_lctrl, 1));
     uint32_t *d_cnt = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)kCntWords));
-    KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, kCntWords * sizeof(uint32_t), s));
+    KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)kCntWords + kCntTimerWords));
+    KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, (kCntWords + kCntTimerWords) * sizeof(uint32_t), s));
     KOMB_HIP(ctx, bufs.alloc(&d_cctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&d_present, present_words));
     KOMB_HIP(ctx, hipMemsetAsync(d_lctrl, 0, sizeof(LocalCtrl), s));
@@ -588,6 +615,18 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
         fprintf(stderr, "komb local finish: %u units (%u heavy), %u items; number+scan %.1f us, collect %.1f us, %d sweeps (%d launches, %u evaluations) %.1f us, scatter %.1f us\n",
                 n, g.nh, total, t[0] * 1e3f, t[1] * 1e3f, hl.iters, launches, hl.evals, t[2] * 1e3f, t[3] * 1e3f);
     }
+#ifdef KOMB_LOCAL_TIMERS
+    {
+        unsigned long long tm[32];
+        KOMB_HIP(ctx, d2h(ctx, tm, d_cnt + kCntWords, sizeof(tm)));
+        for (int sw = 0; sw < 4; ++sw) {
+            const unsigned long long *t = tm + sw * 8;
+            const double nwv = t[7] ? (double)t[7] : 1.0;
+            fprintf(stderr, "komb local timers, sweep %d (%llu waves), us per wave: heavy %.1f setup %.1f load+count %.1f search %.1f notify %.1f; batches/wave %.2f; slowest wave %.1f us\n",
+                    sw + 1, t[7], t[0] / nwv / 100.0, t[1] / nwv / 100.0, t[2] / nwv / 100.0, t[3] / nwv / 100.0, t[4] / nwv / 100.0, t[5] / nwv, t[6] / 100.0);
+        }
+    }
+#endif
     if (hl.bad) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u consistency failures in the compact index", hl.bad);
     if (!hl.done) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: launch budget exhausted before the fixed point");
     if (ls) {
