@@ -129,20 +129,9 @@ struct CoreCollect {
 // Fixed-point problem: item = a live neighbour, value = its current bound.
 struct CoreLocal {
     static constexpr int kU = 8;         // light unit: <= 512 live neighbours (one batch = 64 lanes x 8 values)
+    static constexpr int kN = 1;
     const uint32_t *nbr;
-    struct Item { uint32_t a; int32_t va; };
-    __device__ __forceinline__ Item load(uint32_t pos, const int32_t *val) const
-    {
-        Item it;
-        it.a = nbr[pos];
-        it.va = val[it.a];
-        return it;
-    }
-    static __device__ __forceinline__ int32_t value(const Item &it) { return it.va; }
-    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t a, const int32_t *mark_cur, int32_t *mark_next, int32_t k)
-    {
-        if (it.va > h && (it.va <= a || mark_cur[it.a] == k)) mark_next[it.a] = k + 1;
-    }
+    __device__ __forceinline__ void ids(uint32_t pos, uint32_t (&id)[1]) const { id[0] = nbr[pos]; }
 };
 
 __global__ void k_live_bits(const int32_t *__restrict__ gid, uint32_t n, unsigned long long *__restrict__ bits)

@@ -688,21 +688,12 @@ struct TrussCollect {
 // Fixed-point problem: item = a live triangle, value = the smaller bound of its other two edges.
 struct TrussLocal {
     static constexpr int kU = 8;         // light unit: <= 512 live triangles (one batch = 64 lanes x 8 values)
+    static constexpr int kN = 2;
     const uint2 *cpair;
-    struct Item { uint32_t x, y; int32_t vx, vy; };
-    __device__ __forceinline__ Item load(uint32_t pos, const int32_t *val) const
+    __device__ __forceinline__ void ids(uint32_t pos, uint32_t (&id)[2]) const
     {
-        Item it;
         const uint2 p = cpair[pos];
-        it.x = p.x; it.y = p.y;
-        it.vx = val[p.x]; it.vy = val[p.y];
-        return it;
-    }
-    static __device__ __forceinline__ int32_t value(const Item &it) { return min(it.vx, it.vy); }
-    static __device__ __forceinline__ void notify(const Item &it, int32_t h, int32_t a, const int32_t *mark_cur, int32_t *mark_next, int32_t k)
-    {
-        if (it.vx > h && (it.vx <= a || mark_cur[it.x] == k)) mark_next[it.x] = k + 1;
-        if (it.vy > h && (it.vy <= a || mark_cur[it.y] == k)) mark_next[it.y] = k + 1;
+        id[0] = p.x; id[1] = p.y;
     }
 };
 

@@ -133,14 +133,46 @@ static __global__ __launch_bounds__(kBlock) void k_local_check(LocalGraph g, Loc
 }
 
 // ---- 3. one sweep.  Problem concept (all __device__):
-//   static constexpr int kU;                     items per lane of a light batch (light unit: <= 64 * kU items)
-//   struct Item;  Item load(pos, val) const;     the item's loads
-//   static int32_t value(const Item &);
-//   static void notify(const Item &, int32_t h, int32_t a, const int32_t *mark_cur, int32_t *mark_next, int32_t k);
-//                                                the unit dropped from a to h in sweep k: mark for sweep k+1 every
-//                                                neighbour w whose count this can lower, i.e. h < val[w] <= a -- or just
-//                                                h < val[w] when w is itself evaluated in this sweep (mark_cur[w] == k):
-//                                                only then can the value we see for it be stale (too high)
+//   static constexpr int kU;                     values per lane of a light batch (light unit: <= 64 * kU items)
+//   static constexpr int kN;                     units an item refers to (k-core: the neighbour; k-truss: the other two edges)
+//   void ids(pos, uint32_t (&id)[kN]) const;     the item's unit ids
+// The value of an item is the smallest current value of its units.  When a unit drops from a to h in sweep k it marks
+// for sweep k+1 every unit w of its items whose count this can lower, i.e. h < val[w] <= a -- or just h < val[w] when w
+// is itself evaluated in this sweep (mark_cur[w] == k): only then can the value we see for it be stale (too high).
+template <class P>
+__device__ __forceinline__ int32_t local_value(const P &p, uint32_t pos, const int32_t *val)
+{
+    uint32_t id[P::kN];
+    p.ids(pos, id);
+    int32_t v = val[id[0]];
+#pragma unroll
+    for (int i = 1; i < P::kN; ++i) v = min(v, val[id[i]]);
+    return v;
+}
+// the marks one item owes, loads first (so that several items' loads are in flight together), stores after
+template <class P>
+struct LocalNotify {
+    uint32_t id[P::kN];
+    bool hit[P::kN];
+    __device__ __forceinline__ void load(const P &p, uint32_t pos, const int32_t *val, const int32_t *mark_cur, int32_t h, int32_t a, int32_t k, bool active)
+    {
+#pragma unroll
+        for (int i = 0; i < P::kN; ++i) hit[i] = false;
+        if (!active) return;
+        p.ids(pos, id);
+        int32_t v[P::kN];
+#pragma unroll
+        for (int i = 0; i < P::kN; ++i) v[i] = val[id[i]];
+#pragma unroll
+        for (int i = 0; i < P::kN; ++i) hit[i] = v[i] > h && (v[i] <= a || mark_cur[id[i]] == k);
+    }
+    __device__ __forceinline__ void store(int32_t *mark_next, int32_t k) const
+    {
+#pragma unroll
+        for (int i = 0; i < P::kN; ++i) if (hit[i]) mark_next[id[i]] = k + 1;
+    }
+};
+
 template <class P>
 __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint32_t *cnt, LocalGraph g, P p, int32_t k)
 {
@@ -210,7 +242,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {      // kHvU independent load chains in flight
                     int32_t r[kHvU];
 #pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? P::value(p.load(beg + j, g.val)) : -1; }
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? local_value(p, beg + j, g.val) : -1; }
 #pragma unroll
                     for (int x = 0; x < kHvU; ++x) ge += r[x] >= cap ? 1u : 0u;
                 }
@@ -239,7 +271,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
                     int32_t r[kHvU];
 #pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? P::value(p.load(beg + j, g.val)) : -1; }
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? local_value(p, beg + j, g.val) : -1; }
 #pragma unroll
                     for (int x = 0; x < kHvU; ++x) {
                         if (r[x] > hi) ++ab;
@@ -288,11 +320,11 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             if (H < cap) {
                 if (tid == 0) { g.val[hu] = H; ++n_changed; }
                 for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
-                    typename P::Item it[kHvU];
+                    LocalNotify<P> nt[kHvU];
 #pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; if (j < len) it[x] = p.load(beg + j, g.val); }
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len); }
 #pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; if (j < len) P::notify(it[x], H, cap, mark_cur, mark_next, k); }
+                    for (int x = 0; x < kHvU; ++x) nt[x].store(mark_next, k);
                 }
             }
         }
@@ -361,7 +393,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 r[x] = -1;                               // an empty slot never counts
                 if (idx < total) {
                     tp[x >> 2] |= (uint32_t)o << (8 * (x & 3));
-                    r[x] = P::value(p.load(item_pos(x, o), g.val));
+                    r[x] = local_value(p, item_pos(x, o), g.val);
                 }
             }
             // per-owner count of its items with value >= thr (thr differs per owner; thr >= 0)
@@ -393,13 +425,18 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             KOMB_LT(3);
             if (fm) {
                 if (fail) g.val[mu] = lo;
+                // the items of the units that dropped are loaded again (their ids were not kept: registers), all loads
+                // first, then the marks
                 const int32_t thr_n = fail ? lo : 0x7FFFFFFF;
+                LocalNotify<P> nt[kU];
 #pragma unroll
                 for (int x = 0; x < kU; ++x) {
                     const int o = owner_of(x);
                     const int32_t th = __shfl(thr_n, o), old = __shfl(mcap, o);
-                    if (r[x] >= 0 && th != 0x7FFFFFFF) P::notify(p.load(item_pos(x, o), g.val), th, old, mark_cur, mark_next, k);
+                    nt[x].load(p, item_pos(x, o), g.val, mark_cur, th, old, k, r[x] >= 0 && th != 0x7FFFFFFF);
                 }
+#pragma unroll
+                for (int x = 0; x < kU; ++x) nt[x].store(mark_next, k);
             }
             n_changed += (uint32_t)__popcll(fm);
             n_evals += nb;
