@@ -40,7 +40,8 @@ constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix 
 constexpr int kCntWays = 8;                    // per-sweep counters are spread over this many 128-byte lines
 constexpr int kCntWords = 4 * kCntWays * 32;   // 3 ring slots of change counters + 1 of evaluation counters
 constexpr int kCntTimerWords = 4 * 8 * 2;      // -DKOMB_LOCAL_TIMERS: 4 sweeps x 8 64-bit stopwatch sums behind the counters
-constexpr int kHvU = 4;                        // items per thread per trip on the heavy path (independent load chains)
+constexpr int kHvU = 8;                        // items per thread per trip on the workgroup path (independent load chains)
+constexpr uint32_t kMedMax = 2048;             // heavy units up to this many items are evaluated by one wavefront (values staged in LDS)
 constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
 
 
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     __shared__ uint32_t sh_hist[kLocHB];
     __shared__ uint32_t sh_part[kLocWaves];
     __shared__ unsigned long long sh_best;
-    __shared__ uint32_t sh_q[kLocBlock];
-    __shared__ uint32_t sh_qn;
+    __shared__ uint32_t sh_q[kLocBlock], sh_m[kLocBlock];
+    __shared__ uint32_t sh_qn, sh_mn;
+    __shared__ uint16_t sh_med[kLocWaves][kMedMax];
     __shared__ int32_t sh_i[2];
     __shared__ uint32_t sh_end[kLocWaves][kWave];
     __shared__ uint32_t sh_a[kLocWaves][4][kWave];
@@ -216,18 +218,63 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
 #endif
 
     // ---- heavy units: workgroup b owns the heavy ids b, b + G, b + 2G, ...; its threads look at their marks
-    // side by side, the marked ones go through an LDS queue, one unit at a time with the whole workgroup:
-    // first a plain count of the items >= cap (most re-evaluations end there), then an LDS histogram of the
-    // item values whose range is refined until it is exact
+    // side by side and queue the marked ones in LDS: "medium" units (<= kMedMax items) are evaluated by one wavefront
+    // each, their item values staged once in the wavefront's LDS buffer (16 bits each: values <= kMedMax); longer
+    // ones by the whole workgroup, one at a time: first a plain count of the items >= cap (most re-evaluations end
+    // there), then an LDS histogram of the item values whose range is refined until it is exact
     const int32_t *mark_cur = g.mark[k & 1];
     int32_t *mark_next = g.mark[(k + 1) & 1];
     for (uint32_t base = blockIdx.x; base < g.nh; base += gridDim.x * kLocBlock) {
         __syncthreads();
-        if (tid == 0) sh_qn = 0u;
+        if (tid == 0) { sh_qn = 0u; sh_mn = 0u; }
         __syncthreads();
         {
             const uint64_t hu64 = (uint64_t)base + (uint64_t)tid * gridDim.x;
-            if (hu64 < g.nh && mark_cur[hu64] == k) sh_q[atomicAdd(&sh_qn, 1u)] = (uint32_t)hu64;
+            if (hu64 < g.nh && mark_cur[hu64] == k) {
+                if (g.off[hu64 + 1] - g.off[hu64] <= kMedMax) sh_m[atomicAdd(&sh_mn, 1u)] = (uint32_t)hu64;
+                else sh_q[atomicAdd(&sh_qn, 1u)] = (uint32_t)hu64;
+            }
+        }
+        __syncthreads();
+        // medium units: wavefront w takes queue entries w, w + 8, ...
+        const uint32_t nm = sh_mn;
+        uint16_t *vb = sh_med[w];
+        for (uint32_t mi = (uint32_t)w; mi < nm; mi += kLocWaves) {
+            const uint32_t hu = sh_m[mi];
+            const int32_t cap = g.val[hu];                       // written by this wavefront only
+            if (lane == 0) ++n_evals;
+            if (cap <= 0) continue;
+            const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j0 = (uint32_t)lane; j0 < len; j0 += kWave * 8) {
+                int32_t r[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; r[x] = j < len ? local_value(p, beg + j, g.val) : 0; }
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; if (j < len) vb[j] = (uint16_t)min(max(r[x], 0), 65535); }
+            }
+            __builtin_amdgcn_wave_barrier();
+            auto count_ge = [&](uint32_t thr) -> uint32_t {
+                uint32_t c = 0;
+                for (uint32_t j = (uint32_t)lane; j < len; j += kWave) c += (uint32_t)vb[j] >= thr ? 1u : 0u;
+                return wave_sum(c);
+            };
+            const uint32_t c0 = count_ge((uint32_t)cap);
+            if (c0 >= (uint32_t)cap) continue;                   // unchanged
+            uint32_t lo = c0, hi = (uint32_t)cap - 1u;           // H >= c0: the c0 items >= cap are >= c0 too
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (count_ge(mid) >= mid) lo = mid; else hi = mid - 1u;
+            }
+            const int32_t H = (int32_t)lo;
+            if (lane == 0) { g.val[hu] = H; ++n_changed; }
+            for (uint32_t j0 = (uint32_t)lane; j0 < len; j0 += kWave * 8) {
+                LocalNotify<P> nt[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len); }
+#pragma unroll
+                for (int x = 0; x < 8; ++x) nt[x].store(mark_next, k);
+            }
         }
         __syncthreads();
         const uint32_t nq = sh_qn;
