@@ -39,7 +39,7 @@ constexpr int kLocHB = 4096;                   // histogram bins of the heavy pa
 constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix search
 constexpr int kCntWays = 8;                    // per-sweep counters are spread over this many 128-byte lines
 constexpr int kCntWords = 4 * kCntWays * 32;   // 3 ring slots of change counters + 1 of evaluation counters
-constexpr int kCntTimerWords = 4 * 8 * 2;      // -DKOMB_LOCAL_TIMERS: 4 sweeps x 8 64-bit stopwatch sums behind the counters
+constexpr int kCntTimerWords = 6 * 12 * 2;     // -DKOMB_LOCAL_TIMERS: 6 sweeps x 12 64-bit stopwatch sums behind the counters
 constexpr int kHvU = 8;                        // items per thread per trip on the workgroup path (independent load chains)
 constexpr uint32_t kMedMax = 2048;             // heavy units up to this many items are evaluated by one wavefront (values staged in LDS)
 constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
@@ -207,9 +207,10 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     if (blockIdx.x == 0 && tid < (uint32_t)kCntWays) cnt[(((k + 1) % 3) * kCntWays + tid) * 32] = 0u;   // nobody reads or adds to that slot in this launch
     uint32_t n_changed = 0, n_evals = 0;                 // meaningful in thread 0 (heavy) / lane 0 of each wave (light)
 #ifdef KOMB_LOCAL_TIMERS
-    // per-wave stopwatch (100 MHz): [0] heavy section, [1] group setup (marks, offsets), [2] item loads + first count,
-    // [3] search, [4] notification, [5] batches; summed over the waves into cnt[tm_base ..], the slowest wave's total in [6]
-    unsigned long long tmv[6] = {0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+    // per-wave stopwatch (100 MHz): [0] heavy-mark scan, [1] medium units, [2] workgroup units, [3] group setup (marks,
+    // offsets), [4] item loads + first count, [5] search, [6] notification, [7] batches, [8] groups with a marked unit;
+    // summed over the waves behind the counters, the slowest wave's total in [9], the number of waves in [10]
+    unsigned long long tmv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
     const unsigned long long tstart = tlast;
     auto tick = [&](int i) { const unsigned long long now = wall_clock64(); tmv[i] += now - tlast; tlast = now; };
 #define KOMB_LT(i) tick(i)
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             }
         }
         __syncthreads();
+        KOMB_LT(0);
         // medium units: wavefront w takes queue entries w, w + 8, ...
         const uint32_t nm = sh_mn;
         uint16_t *vb = sh_med[w];
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             }
         }
         __syncthreads();
+        KOMB_LT(1);
         const uint32_t nq = sh_qn;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             const uint32_t hu = sh_q[qi];
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
         }
     }
     __syncthreads();
-    KOMB_LT(0);
+    KOMB_LT(2);
 
     // ---- light units: a wavefront takes a group of consecutive ids (64, fewer when there are fewer groups than
     // wavefronts), packs the marked ones, and evaluates them in batches of <= 64 * kU items flattened over the lanes.
@@ -403,7 +406,10 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             s_a[0][q] = u; s_a[1][q] = b0; s_a[2][q] = g.off[u + 1] - b0; s_a[3][q] = (uint32_t)g.val[u];
         }
         __builtin_amdgcn_wave_barrier();
-        KOMB_LT(1);
+        KOMB_LT(3);
+#ifdef KOMB_LOCAL_TIMERS
+        tmv[8] += 1;
+#endif
         for (uint32_t start = 0; start < na;) {
             const bool has = start + (uint32_t)lane < na;
             uint32_t mu = 0, mlen = 0;
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 return c;
             };
             const uint32_t c0 = count_ge(mcap > 0 ? mcap : 0);
-            KOMB_LT(2);
+            KOMB_LT(4);
             const bool fail = own && mcap > 0 && c0 < (uint32_t)mcap;
             int32_t lo = fail ? (int32_t)c0 : mcap, hi = fail ? mcap - 1 : mcap;   // H >= c0: the c0 items >= cap are >= c0 too
             while (__ballot(lo < hi)) {
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 if (lo < hi) { if (c >= (uint32_t)mid) lo = mid; else hi = mid - 1; }
             }
             const uint64_t fm = __ballot(fail);
-            KOMB_LT(3);
+            KOMB_LT(5);
             if (fm) {
                 if (fail) g.val[mu] = lo;
                 // the items of the units that dropped are loaded again (their ids were not kept: registers), all loads
@@ -491,16 +497,17 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             __builtin_amdgcn_wave_barrier();
 #ifdef KOMB_LOCAL_TIMERS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tick(4); tmv[5] += 1;
+            tick(6); tmv[7] += 1;
 #endif
         }
     }
 #ifdef KOMB_LOCAL_TIMERS
-    if (lane == 0 && k <= 4) {                           // the first four sweeps
-        unsigned long long *tm = reinterpret_cast<unsigned long long *>(cnt + kCntWords) + (k - 1) * 8;
-        for (int i = 0; i < 6; ++i) atomicAdd(&tm[i], tmv[i]);
-        atomicMax(&tm[6], wall_clock64() - tstart);
-        atomicAdd(&tm[7], 1ull);
+    if (lane == 0 && (k == 1 || k == 4 || k == 8 || k == 12 || k == 16 || k == 20)) {
+        const int slot = k == 1 ? 0 : k / 4;
+        unsigned long long *tm = reinterpret_cast<unsigned long long *>(cnt + kCntWords) + slot * 12;
+        for (int i = 0; i < 9; ++i) atomicAdd(&tm[i], tmv[i]);
+        atomicMax(&tm[9], wall_clock64() - tstart);
+        atomicAdd(&tm[10], 1ull);
     }
 #endif
     // one add per workgroup, spread over kCntWays words
@@ -701,13 +708,15 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     }
 #ifdef KOMB_LOCAL_TIMERS
     {
-        unsigned long long tm[32];
+        unsigned long long tm[72];
         KOMB_HIP(ctx, d2h(ctx, tm, d_cnt + kCntWords, sizeof(tm)));
-        for (int sw = 0; sw < 4; ++sw) {
-            const unsigned long long *t = tm + sw * 8;
-            const double nwv = t[7] ? (double)t[7] : 1.0;
-            fprintf(stderr, "komb local timers, sweep %d (%llu waves), us per wave: heavy %.1f setup %.1f load+count %.1f search %.1f notify %.1f; batches/wave %.2f; slowest wave %.1f us\n",
-                    sw + 1, t[7], t[0] / nwv / 100.0, t[1] / nwv / 100.0, t[2] / nwv / 100.0, t[3] / nwv / 100.0, t[4] / nwv / 100.0, t[5] / nwv, t[6] / 100.0);
+        for (int sw = 0; sw < 6; ++sw) {
+            const unsigned long long *t = tm + sw * 12;
+            const double nwv = t[10] ? (double)t[10] : 1.0;
+            fprintf(stderr, "komb local timers, sweep %d (%llu waves), us per wave: hscan %.1f medium %.1f workgroup %.1f setup %.1f load+count %.1f search %.1f notify %.1f; "
+                            "batches/wave %.2f groups/wave %.2f; slowest wave %.1f us\n",
+                    sw == 0 ? 1 : sw * 4, t[10], t[0] / nwv / 100.0, t[1] / nwv / 100.0, t[2] / nwv / 100.0, t[3] / nwv / 100.0, t[4] / nwv / 100.0, t[5] / nwv / 100.0,
+                    t[6] / nwv / 100.0, t[7] / nwv, t[8] / nwv, t[9] / 100.0);
         }
     }
 #endif
