@@ -219,10 +219,11 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
 #endif
 
     // ---- heavy units: workgroup b owns the heavy ids b, b + G, b + 2G, ...; its threads look at their marks
-    // side by side and queue the marked ones in LDS: "medium" units (<= kMedMax items) are evaluated by one wavefront
-    // each, their item values staged once in the wavefront's LDS buffer (16 bits each: values <= kMedMax); longer
-    // ones by the whole workgroup, one at a time: first a plain count of the items >= cap (most re-evaluations end
-    // there), then an LDS histogram of the item values whose range is refined until it is exact
+    // side by side and queue the marked ones in LDS.  The longest ones (> kMedMax items) are evaluated first, by the whole
+    // workgroup, one at a time: a plain count of the items >= cap (most re-evaluations end there), then an LDS histogram of
+    // the item values whose range is refined until it is exact.  "Medium" units are evaluated by one wavefront each, their
+    // item values staged once in the wavefront's LDS buffer (16 bits each: values <= kMedMax); no workgroup barrier
+    // follows, so a wavefront without medium units goes straight on to the light ones
     const int32_t *mark_cur = g.mark[k & 1];
     int32_t *mark_next = g.mark[(k + 1) & 1];
     for (uint32_t base = blockIdx.x; base < g.nh; base += gridDim.x * kLocBlock) {
@@ -238,48 +239,6 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
         }
         __syncthreads();
         KOMB_LT(0);
-        // medium units: wavefront w takes queue entries w, w + 8, ...
-        const uint32_t nm = sh_mn;
-        uint16_t *vb = sh_med[w];
-        for (uint32_t mi = (uint32_t)w; mi < nm; mi += kLocWaves) {
-            const uint32_t hu = sh_m[mi];
-            const int32_t cap = g.val[hu];                       // written by this wavefront only
-            if (lane == 0) ++n_evals;
-            if (cap <= 0) continue;
-            const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t j0 = (uint32_t)lane; j0 < len; j0 += kWave * 8) {
-                int32_t r[8];
-#pragma unroll
-                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; r[x] = j < len ? local_value(p, beg + j, g.val) : 0; }
-#pragma unroll
-                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; if (j < len) vb[j] = (uint16_t)min(max(r[x], 0), 65535); }
-            }
-            __builtin_amdgcn_wave_barrier();
-            auto count_ge = [&](uint32_t thr) -> uint32_t {
-                uint32_t c = 0;
-                for (uint32_t j = (uint32_t)lane; j < len; j += kWave) c += (uint32_t)vb[j] >= thr ? 1u : 0u;
-                return wave_sum(c);
-            };
-            const uint32_t c0 = count_ge((uint32_t)cap);
-            if (c0 >= (uint32_t)cap) continue;                   // unchanged
-            uint32_t lo = c0, hi = (uint32_t)cap - 1u;           // H >= c0: the c0 items >= cap are >= c0 too
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1u) >> 1;
-                if (count_ge(mid) >= mid) lo = mid; else hi = mid - 1u;
-            }
-            const int32_t H = (int32_t)lo;
-            if (lane == 0) { g.val[hu] = H; ++n_changed; }
-            for (uint32_t j0 = (uint32_t)lane; j0 < len; j0 += kWave * 8) {
-                LocalNotify<P> nt[8];
-#pragma unroll
-                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len); }
-#pragma unroll
-                for (int x = 0; x < 8; ++x) nt[x].store(mark_next, k);
-            }
-        }
-        __syncthreads();
-        KOMB_LT(1);
         const uint32_t nq = sh_qn;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             const uint32_t hu = sh_q[qi];
@@ -378,9 +337,49 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 }
             }
         }
+        KOMB_LT(2);
+        // medium units: wavefront w takes queue entries w, w + 8, ...
+        const uint32_t nm = sh_mn;
+        uint16_t *vb = sh_med[w];
+        for (uint32_t mi = (uint32_t)w; mi < nm; mi += kLocWaves) {
+            const uint32_t hu = sh_m[mi];
+            const int32_t cap = g.val[hu];                       // written by this wavefront only
+            if (lane == 0) ++n_evals;
+            if (cap <= 0) continue;
+            const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j0 = (uint32_t)lane; j0 < len; j0 += kWave * 8) {
+                int32_t r[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; r[x] = j < len ? local_value(p, beg + j, g.val) : 0; }
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; if (j < len) vb[j] = (uint16_t)min(max(r[x], 0), 65535); }
+            }
+            __builtin_amdgcn_wave_barrier();
+            auto count_ge = [&](uint32_t thr) -> uint32_t {
+                uint32_t c = 0;
+                for (uint32_t j = (uint32_t)lane; j < len; j += kWave) c += (uint32_t)vb[j] >= thr ? 1u : 0u;
+                return wave_sum(c);
+            };
+            const uint32_t c0 = count_ge((uint32_t)cap);
+            if (c0 >= (uint32_t)cap) continue;                   // unchanged
+            uint32_t lo = c0, hi = (uint32_t)cap - 1u;           // H >= c0: the c0 items >= cap are >= c0 too
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (count_ge(mid) >= mid) lo = mid; else hi = mid - 1u;
+            }
+            const int32_t H = (int32_t)lo;
+            if (lane == 0) { g.val[hu] = H; ++n_changed; }
+            for (uint32_t j0 = (uint32_t)lane; j0 < len; j0 += kWave * 8) {
+                LocalNotify<P> nt[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len); }
+#pragma unroll
+                for (int x = 0; x < 8; ++x) nt[x].store(mark_next, k);
+            }
+        }
+        KOMB_LT(1);
     }
-    __syncthreads();
-    KOMB_LT(2);
 
     // ---- light units: a wavefront takes a group of consecutive ids (64, fewer when there are fewer groups than
     // wavefronts), packs the marked ones, and evaluates them in batches of <= 64 * kU items flattened over the lanes.
