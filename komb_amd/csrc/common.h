@@ -70,17 +70,19 @@ struct LocalCtrl {
 };
 static_assert(sizeof(LocalCtrl) == 64, "LocalCtrl layout");
 
-// How a peel ends (KOMB_FINISH): "local" (default) hands the remainder to the h-index fixed point of
-// local_dev.h once at most KOMB_LOCAL_LIMIT units (default: a fraction of all units) are left at a level
-// boundary; "lds" uses the single-workgroup LDS tails (truss_tail.h, core_tail.h; thresholds KOMB_TAIL /
-// KOMB_CORE_TAIL); "none" keeps the whole peel in the general engine.  None of them changes a result.
+// How a peel ends (KOMB_FINISH): "local" hands the remainder to the h-index fixed point of local_dev.h once at
+// most KOMB_LOCAL_LIMIT units (default: a fraction of all units) are left at a level boundary; "lds" uses the
+// single-workgroup LDS tails (truss_tail.h, core_tail.h; thresholds KOMB_TAIL / KOMB_CORE_TAIL); "none" keeps the
+// whole peel in the general engine.  None of them changes a result.  Defaults, from the measurements in DESIGN.md:
+// k-core "local" (|V| = 1M: 5.3 -> 3.1 ms, |V| = 10M: 16.8 -> 12.0 ms), k-truss "lds" (the two tie there).
 enum FinishMode : int { FIN_LOCAL = 0, FIN_LDS = 1, FIN_NONE = 2 };
-inline FinishMode finish_mode()
+inline FinishMode finish_mode(FinishMode dflt)
 {
     const char *e = getenv("KOMB_FINISH");
+    if (e && !strcmp(e, "local")) return FIN_LOCAL;
     if (e && !strcmp(e, "lds")) return FIN_LDS;
     if (e && !strcmp(e, "none")) return FIN_NONE;
-    return FIN_LOCAL;
+    return dflt;
 }
 inline uint32_t local_limit(uint64_t units, uint64_t divisor)
 {

@@ -227,7 +227,7 @@ int core_run(komb_ctx *ctx)
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
     // how the peel ends (common.h): local fixed point (default), LDS tail, or the general engine alone
-    const FinishMode fin = finish_mode();
+    const FinishMode fin = finish_mode(FIN_LOCAL);
     uint32_t tail_limit = 0;
     const size_t live_words = ((size_t)nv + 63) / 64;
     unsigned long long *d_livebits = nullptr;
@@ -243,7 +243,7 @@ int core_run(komb_ctx *ctx)
             KOMB_HIP(ctx, bufs.alloc(&T.rows, (size_t)kCoreTailV * kCoreTailWords));
         }
     } else if (fin == FIN_LOCAL) {
-        tail_limit = local_limit((uint64_t)nv, 8);
+        tail_limit = local_limit((uint64_t)nv, 16);
         if (tail_limit) KOMB_HIP(ctx, bufs.alloc(&d_livebits, live_words));
     }
 

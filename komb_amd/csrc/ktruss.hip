@@ -1018,13 +1018,13 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
     // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
-    const FinishMode fin = finish_mode();
+    const FinishMode fin = finish_mode(FIN_LDS);
     uint32_t tail_limit = 0;
     if (fin == FIN_LDS) {
         tail_limit = kTailEdges;
         if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
         if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
-    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 16);
+    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 512);
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));

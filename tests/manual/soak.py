@@ -37,6 +37,8 @@ with komb_amd.KombAccel() as a:
             star = np.stack([np.zeros(nv - 1, np.int64), np.arange(1, nv)], axis=1)
             uv = np.concatenate([core[keep], star, rng.integers(0, nv, (nv, 2))])
         uv = np.ascontiguousarray(uv, dtype=np.int64)
+        os.environ["KOMB_FINISH"] = str(rng.choice(["local", "lds", "none"]))
+        os.environ["KOMB_LOCAL_LIMIT"] = str(rng.choice([0, 40, 900, 20000, 4000000000]))
         os.environ["KOMB_TAIL"] = str(rng.choice([0, 50, 700, 5000, 32768, 65534]))
         os.environ["KOMB_CORE_TAIL"] = str(rng.choice([0, 9, 200, 1024]))
         for k, on in (("KOMB_TWO_PASS", rng.random() < 0.3), ("KOMB_OFF64", rng.random() < 0.3)):
@@ -51,7 +53,8 @@ with komb_amd.KombAccel() as a:
         if not ok:
             bad += 1
             np.save(f"gpurun_out/soak_fail_{g}.npy", uv)
-            print(f"MISMATCH graph {g} kind {kind} nv {nv} env TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
+            print(f"MISMATCH graph {g} kind {kind} nv {nv} env FINISH={os.environ['KOMB_FINISH']} LOCAL_LIMIT={os.environ['KOMB_LOCAL_LIMIT']} "
+                  f"TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
                   f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')}", flush=True)
         if g % 100 == 99:
             print(f"{g + 1} graphs, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)

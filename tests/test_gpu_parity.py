@@ -489,7 +489,7 @@ def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
             assert np.array_equal(a.run_truss()[2], want_tr), name
             st = a.stats()
             assert st["core_local_units"] == 0 and st["truss_local_units"] == 0
-            monkeypatch.delenv("KOMB_FINISH", raising=False)
+            monkeypatch.setenv("KOMB_FINISH", "local")
             ran_core = ran_truss = 0
             for limit in ("4000000000", None, "20000", "1500", "100"):
                 if limit is None:
@@ -515,3 +515,4 @@ def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
                     assert st["truss_levels"] == len(np.unique(want_tr)), name
             assert ran_core > 0 and (ran_truss > 0 or want_tr.max() <= 2), name
     monkeypatch.delenv("KOMB_LOCAL_LIMIT", raising=False)
+    monkeypatch.delenv("KOMB_FINISH", raising=False)
