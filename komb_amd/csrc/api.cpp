@@ -52,6 +52,15 @@ komb_ctx *komb_create(const komb_opts *opts)
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctrl, 2 * sizeof(PeelCtrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_local, 2 * sizeof(LocalCtrl), hipHostMallocDefault);
     if (e == hipSuccess && !ctx->timer.init()) e = hipErrorUnknown;
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                 // lo = least priority
+        e = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, lo);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_aux0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_aux1);
     if (e != hipSuccess) {
         ctx->err = std::string("device initialisation failed: ") + hipGetErrorString(e);
         return ctx;
@@ -69,6 +78,8 @@ void komb_destroy(komb_ctx *ctx)
         graph_free(ctx);
         ctx->pool.clear();
         ctx->timer.destroy();
+        if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+        for (hipEvent_t ev : {ctx->ev_fork, ctx->ev_join, ctx->ev_aux0, ctx->ev_aux1}) if (ev) (void)hipEventDestroy(ev);
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
         if (ctx->h_local) (void)hipHostFree(ctx->h_local);
     }

@@ -51,13 +51,8 @@ struct CoreProblem {
     int32_t *degw;
     int32_t *core;
 
-    __device__ __forceinline__ bool scan_probe(uint32_t v, int32_t &key, uint32_t &nch) const
-    {
-        const int32_t c = core[v];
-        key = degw[v];
-        nch = marker_chunks(c);
-        return marker_alive(c);
-    }
+    __device__ __forceinline__ const int32_t *scan_marker() const { return core; }
+    __device__ __forceinline__ const int32_t *scan_key() const { return degw; }
     __device__ __forceinline__ void mark_scanned(uint32_t v, const CtrlView &cv) const { core[v] = cv.level; }
     __device__ __forceinline__ void slice(uint32_t v, uint32_t &b, uint32_t &len) const
     {
@@ -96,13 +91,8 @@ struct CoreCollect {
     uint32_t *cur;                       // [n] fill cursors
     uint32_t *nbr;                       // compact rows
 
-    __device__ __forceinline__ bool scan_probe(uint32_t v, int32_t &key, uint32_t &nch) const
-    {
-        const int32_t c = core[v];
-        key = 0;                         // every live vertex enters the one frontier of this pass
-        nch = marker_chunks(c);
-        return marker_alive(c);
-    }
+    __device__ __forceinline__ const int32_t *scan_marker() const { return core; }
+    __device__ __forceinline__ const int32_t *scan_key() const { return nullptr; }   // every live vertex enters the one frontier of this pass
     __device__ __forceinline__ void mark_scanned(uint32_t, const CtrlView &) const {}
     __device__ __forceinline__ void slice(uint32_t v, uint32_t &b, uint32_t &len) const
     {

@@ -257,9 +257,8 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 // Problem concept (all __device__):
 //   static constexpr bool kChain;        triggered light units may be peeled in the same launch
 //   uint32_t units;
-//   bool scan_probe(u, int32_t &key, uint32_t &nch)   liveness, live key and class of unit u (nch = 0: light,
-//                                        else its chunk count), from two independent loads: the alive
-//                                        marker carries the class (common.h)
+//   const int32_t *scan_marker();        [units] alive marker (common.h: it carries the unit's class) or round / level number
+//   const int32_t *scan_key();           [units] live keys, or null when every live unit is a hit (collect passes)
 //   void mark_scanned(u, cv)             unit enters the frontier through SCAN
 //   void slice(u, uint32_t &begin, uint32_t &len)
 //   Loaded item_load(unit, pos, cv)      the item's loads (no side effects)
@@ -323,32 +322,54 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         // ---- pass A: count this wave's light hits, its heavy units' chunks, all hits, survivors.
         // kScanU units per thread per trip: the trips are independent, so their loads overlap
         // (one unit per trip left the sweep bound by 2 x 380 sequential memory latencies).
+        // Dense sweep (no live list yet): a lane takes kScanU CONSECUTIVE units and loads their markers and keys as
+        // one 16-byte vector each, and stores the four classification bytes as one word.
+        const bool vec = !from_list;
+        const int32_t *s_marker = p.scan_marker(), *s_key = p.scan_key();
         uint32_t n_light = 0, n_chunks = 0, n_hits = 0, n_surv = 0;   // n_chunks per lane, others wave-uniform
         int32_t lmin = 0x7FFFFFFF;
         const uint64_t tile = (uint64_t)kPeelBlock * kScanU;
-        for (uint64_t base = (uint64_t)blockIdx.x * tile + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * tile) {
+        auto index_of = [&](uint64_t tb, int k) -> uint64_t {
+            return vec ? tb + ((uint64_t)w * kWave + (uint64_t)lane) * kScanU + (uint64_t)k
+                       : tb + (uint64_t)k * kPeelBlock + (uint64_t)w * kWave + (uint64_t)lane;
+        };
+        for (uint64_t tb = (uint64_t)blockIdx.x * tile; tb < n_in; tb += (uint64_t)nblk * tile) {
             uint8_t code[kScanU];
-#pragma unroll
-            for (int k = 0; k < kScanU; ++k) {
-                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
-                code[k] = SC_NONE;
-                if (idx < n_in) {
-                    const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
-                    // liveness, key and slice length are loaded unconditionally: independent loads (and, in
-                    // the dense sweep, sequential ones) instead of a chain of three dependent round trips
-                    int32_t key;
-                    uint32_t nch;
-                    const bool live = p.scan_probe(u, key, nch);
-                    if (live && key <= L) {
-                        if (nch == 0) code[k] = SC_LIGHT;
-                        else { n_chunks += nch; code[k] = SC_HEAVY; }
-                    } else if (live) { lmin = min(lmin, key); code[k] = SC_SURVIVOR; }
-                }
+            int32_t mk[kScanU], ky[kScanU];
+            const uint64_t i0 = index_of(tb, 0);
+            const bool whole = vec && i0 + kScanU <= n_in;
+            if (whole) {
+                static_assert(kScanU == 4, "the dense sweep loads int4");
+                const int4 m4 = *reinterpret_cast<const int4 *>(s_marker + i0);
+                mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
+                if (s_key) { const int4 k4 = *reinterpret_cast<const int4 *>(s_key + i0); ky[0] = k4.x; ky[1] = k4.y; ky[2] = k4.z; ky[3] = k4.w; }
+                else { ky[0] = ky[1] = ky[2] = ky[3] = 0; }
             }
 #pragma unroll
             for (int k = 0; k < kScanU; ++k) {
-                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
-                if (idx < n_in) Q.code[idx] = code[k];      // pass B reads this byte instead of the unit's state
+                const uint64_t idx = index_of(tb, k);
+                code[k] = SC_NONE;
+                if (idx < n_in) {
+                    // liveness, key and slice length are loaded unconditionally: independent loads (and, in
+                    // the dense sweep, sequential ones) instead of a chain of three dependent round trips
+                    if (!whole) {
+                        const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
+                        mk[k] = s_marker[u];
+                        ky[k] = s_key ? s_key[u] : 0;
+                    }
+                    const bool live = marker_alive(mk[k]);
+                    const uint32_t nch = marker_chunks(mk[k]);
+                    if (live && ky[k] <= L) {
+                        if (nch == 0) code[k] = SC_LIGHT;
+                        else { n_chunks += nch; code[k] = SC_HEAVY; }
+                    } else if (live) { lmin = min(lmin, ky[k]); code[k] = SC_SURVIVOR; }
+                }
+            }
+            if (whole) *reinterpret_cast<uchar4 *>(Q.code + i0) = make_uchar4(code[0], code[1], code[2], code[3]);
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const uint64_t idx = index_of(tb, k);
+                if (!whole && idx < n_in) Q.code[idx] = code[k];      // pass B reads this byte instead of the unit's state
                 const bool hit = code[k] == SC_LIGHT || code[k] == SC_HEAVY;
                 n_light += (uint32_t)__popcll(__ballot(code[k] == SC_LIGHT));
                 n_hits += (uint32_t)__popcll(__ballot(hit));
@@ -378,17 +399,23 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         // ---- pass B: replay the classification bytes, write the entries
         const uint32_t base_l = sh_base[0] + sh_w[w][0], base_h = sh_base[1] + sh_w[w][1], base_s = sh_base[2] + sh_w[w][3];
         uint32_t run_l = 0, run_h = 0, run_s = 0;
-        for (uint64_t base = (uint64_t)blockIdx.x * tile + (uint64_t)w * kWave; base < n_in; base += (uint64_t)nblk * tile) {
+        for (uint64_t tb = (uint64_t)blockIdx.x * tile; tb < n_in; tb += (uint64_t)nblk * tile) {
             uint8_t code[kScanU];
             uint32_t u[kScanU];
-#pragma unroll
-            for (int k = 0; k < kScanU; ++k) {
-                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
-                code[k] = idx < n_in ? Q.code[idx] : (uint8_t)SC_NONE;
+            const uint64_t i0 = index_of(tb, 0);
+            const bool whole = vec && i0 + kScanU <= n_in;
+            if (whole) {
+                const uchar4 c4 = *reinterpret_cast<const uchar4 *>(Q.code + i0);
+                code[0] = c4.x; code[1] = c4.y; code[2] = c4.z; code[3] = c4.w;
             }
 #pragma unroll
             for (int k = 0; k < kScanU; ++k) {
-                const uint64_t idx = base + (uint64_t)k * kPeelBlock + (uint64_t)lane;
+                const uint64_t idx = index_of(tb, k);
+                if (!whole) code[k] = idx < n_in ? Q.code[idx] : (uint8_t)SC_NONE;
+            }
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const uint64_t idx = index_of(tb, k);
                 u[k] = 0;
                 if (code[k] != SC_NONE) u[k] = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
             }
