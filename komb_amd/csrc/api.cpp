@@ -55,7 +55,16 @@ komb_ctx *komb_create(const komb_opts *opts)
     if (e == hipSuccess) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                 // lo = least priority
-        e = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, lo);
+        // KOMB_AUX_CUS=<n>: confine the side stream to n CUs (the mask's bits are dealt round-robin over the XCDs), so
+        // that whole CUs stay free for the peel's 1024-thread workgroups
+        const char *cus = getenv("KOMB_AUX_CUS");
+        const int ncu = cus ? atoi(cus) : 0;
+        if (ncu > 0 && ncu < 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+            if (hipExtStreamCreateWithCUMask(&ctx->aux, 8, mask) != hipSuccess) { (void)hipGetLastError(); ctx->aux = nullptr; }
+        }
+        if (!ctx->aux) e = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, lo);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);

@@ -999,8 +999,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;
     bufs.release(d_cnt); bufs.release(d_own);
 
-    // ---- canonical edge list, supports and the map to internal ids: on the side stream, beside the peel
-    // (KOMB_AUX=0: on the main stream, for A/B measurements)
+    // ---- canonical edge list, supports and the map to internal ids: nothing here needs the peel.  KOMB_AUX=1 runs it on
+    // the side stream beside the peel (measured: no gain yet -- the peel's 1024-thread workgroups need whole CUs, and the
+    // map's workgroups keep every CU partly busy; KOMB_AUX_CUS confines the side stream to some CUs)
     uint32_t *d_ucnt = nullptr, *d_ebase = nullptr, *d_pi = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
@@ -1012,7 +1013,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
     k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
-    const bool use_aux = !(getenv("KOMB_AUX") && atoi(getenv("KOMB_AUX")) == 0);
+    const bool use_aux = getenv("KOMB_AUX") && atoi(getenv("KOMB_AUX")) != 0;
     hipStream_t ms = use_aux ? ctx->aux : s;
     struct AuxGuard {                                  // no buffer of this run goes back to the pool while the side stream uses it
         komb_ctx *c; bool pending;
