@@ -124,9 +124,10 @@ int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
 /* One process per GPU, every rank holding the same graph: the triangle-support
  * phase is sharded by source-vertex range [rank/world) and the partial support
  * vectors (|E|+1 words) are summed across ranks by `allreduce` -- an in-place SUM
- * all-reduce over uint32[count] in device memory, ordered after all work already queued
- * on the device's default stream (the host implements it with RCCL; return 0 on
- * success).  Incidence index, peel and gather then run on every rank; all
+ * all-reduce over uint32[count] in device memory (the host implements it with RCCL; the
+ * library has drained its stream when it calls, the reduction must be complete when the
+ * callback returns; 32-bit two's-complement sums, so an int32 view of the words is fine;
+ * return 0 on success).  Incidence index, peel and gather then run on every rank; all
  * ranks end with identical results.  world == 1 is komb_truss_run. */
 typedef int (*komb_allreduce_fn)(void *user, void *device_u32, int64_t count);
 int komb_truss_run_sharded(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world,

@@ -51,6 +51,9 @@ komb_ctx *komb_create(const komb_opts *opts)
     e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctrl, 2 * sizeof(PeelCtrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_local, 2 * sizeof(LocalCtrl), hipHostMallocDefault);
+    // the library's own stream (non-blocking: no implicit ordering with the legacy default stream, so the side stream
+    // below really runs beside it); every entry point leaves it drained
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess && !ctx->timer.init()) e = hipErrorUnknown;
     if (e == hipSuccess) {
         int lo = 0, hi = 0;
@@ -60,6 +63,8 @@ komb_ctx *komb_create(const komb_opts *opts)
         const char *cus = getenv("KOMB_AUX_CUS");
         const int ncu = cus ? atoi(cus) : 0;
         if (ncu > 0 && ncu < 256) {
+            // NOTE: a stream made this way is a blocking one (it orders itself with the legacy default stream, which the
+            // library does not use)
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
             if (hipExtStreamCreateWithCUMask(&ctx->aux, 8, mask) != hipSuccess) { (void)hipGetLastError(); ctx->aux = nullptr; }
@@ -74,7 +79,6 @@ komb_ctx *komb_create(const komb_opts *opts)
         ctx->err = std::string("device initialisation failed: ") + hipGetErrorString(e);
         return ctx;
     }
-    ctx->stream = nullptr;           // the device's default stream
     ctx->device_ok = true;
     return ctx;
 }
@@ -88,6 +92,7 @@ void komb_destroy(komb_ctx *ctx)
         ctx->pool.clear();
         ctx->timer.destroy();
         if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+        if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
         for (hipEvent_t ev : {ctx->ev_fork, ctx->ev_join, ctx->ev_aux0, ctx->ev_aux1}) if (ev) (void)hipEventDestroy(ev);
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
         if (ctx->h_local) (void)hipHostFree(ctx->h_local);

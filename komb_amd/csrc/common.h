@@ -286,7 +286,7 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
         if (f) fprintf(f, "# peel units=%lld\n", (long long)units);
         for (int64_t i = 0; i < 4 * units + 4096; ++i) {
             PeelCtrl before;
-            if (hipMemcpy(&before, d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost) != hipSuccess) break;
+            if (d2h(ctx, &before, d_ctrl, sizeof(PeelCtrl)) != hipSuccess) break;
             if (before.done) break;
             (void)hipEventRecord(a, ctx->stream);
             launch(); ++launches;
@@ -300,7 +300,7 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
         if (f) fclose(f);
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
         if (launches_out) *launches_out = launches;
-        KOMB_HIP(ctx, hipMemcpy(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost));
+        KOMB_HIP(ctx, d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)));
         return KOMB_OK;
     }
 #endif
@@ -327,7 +327,7 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
     if (launches_out) *launches_out = launches;
     if (status != KOMB_OK || e != hipSuccess)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: HIP failure (%s)", hipGetErrorString(e));
-    if (hipMemcpy(&ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost) != hipSuccess)
+    if (d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) != hipSuccess)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: control block readback failed");
     if (!ctx->h_ctrl[0].done)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: launch budget exhausted before completion (level %d, remaining %u)",

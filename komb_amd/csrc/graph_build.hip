@@ -157,7 +157,7 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
         // the drop key, if present, is the last unique key
         if (nu > 0) {
             uint64_t last = 0;
-            e = hipMemcpy(&last, other + (nu - 1), sizeof(uint64_t), hipMemcpyDeviceToHost);
+            e = d2h(ctx, &last, other + (nu - 1), sizeof(uint64_t));
             if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
             if (last == kDropKey) --nu;
         }
@@ -199,10 +199,10 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
     hipStream_t s = ctx->stream;
     ctx->timer.start(s);
     int64_t *d_rp64 = nullptr; int *d_bad = nullptr;
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_rowptr, (size_t)(nv + 1) * sizeof(uint32_t)));
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_col, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t)));
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_src, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t)));
-    hipError_t e = hipMalloc(&d_rp64, (size_t)(nv + 1) * sizeof(int64_t));
+    hipError_t e = hipMalloc(&ctx->d_rowptr, (size_t)(nv + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_col, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_src, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_rp64, (size_t)(nv + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rp64, rowptr, (size_t)(nv + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);

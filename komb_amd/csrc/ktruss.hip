@@ -951,6 +951,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (!single && world > 1) {
         // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
         ctx->timer.start(s);
+        KOMB_HIP(ctx, hipStreamSynchronize(s));          // the buffer is complete when the callback runs
         if (fn(user, d_cnt, (int64_t)m + 1) != 0)
             KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
         st.ms_allreduce = ctx->timer.stop(s);
@@ -1013,7 +1014,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
     k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
-    const bool use_aux = getenv("KOMB_AUX") && atoi(getenv("KOMB_AUX")) != 0;
+    const bool use_aux = !(getenv("KOMB_AUX") && atoi(getenv("KOMB_AUX")) == 0);
     hipStream_t ms = use_aux ? ctx->aux : s;
     struct AuxGuard {                                  // no buffer of this run goes back to the pool while the side stream uses it
         komb_ctx *c; bool pending;
