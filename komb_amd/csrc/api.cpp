@@ -51,30 +51,12 @@ komb_ctx *komb_create(const komb_opts *opts)
     e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctrl, 2 * sizeof(PeelCtrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_local, 2 * sizeof(LocalCtrl), hipHostMallocDefault);
-    // the library's own stream (non-blocking: no implicit ordering with the legacy default stream, so the side stream
-    // below really runs beside it); every entry point leaves it drained
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    // The library works on the device's default (legacy) stream.  A stream of its own (hipStreamNonBlocking) was tried in
+    // order to run independent work beside the peel: there was nothing to gain (both sides are bound by HBM), and
+    // with two processes sharing one GPU the peel's launch-to-launch hand-over of its control block became unreliable on it
+    // (stale control blocks; tests/test_distributed.py caught it), so everything stays on the default stream.
+    ctx->stream = nullptr;
     if (e == hipSuccess && !ctx->timer.init()) e = hipErrorUnknown;
-    if (e == hipSuccess) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                 // lo = least priority
-        // KOMB_AUX_CUS=<n>: confine the side stream to n CUs (the mask's bits are dealt round-robin over the XCDs), so
-        // that whole CUs stay free for the peel's 1024-thread workgroups
-        const char *cus = getenv("KOMB_AUX_CUS");
-        const int ncu = cus ? atoi(cus) : 0;
-        if (ncu > 0 && ncu < 256) {
-            // NOTE: a stream made this way is a blocking one (it orders itself with the legacy default stream, which the
-            // library does not use)
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
-            if (hipExtStreamCreateWithCUMask(&ctx->aux, 8, mask) != hipSuccess) { (void)hipGetLastError(); ctx->aux = nullptr; }
-        }
-        if (!ctx->aux) e = hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, lo);
-    }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_aux0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_aux1);
     if (e != hipSuccess) {
         ctx->err = std::string("device initialisation failed: ") + hipGetErrorString(e);
         return ctx;
@@ -91,9 +73,6 @@ void komb_destroy(komb_ctx *ctx)
         graph_free(ctx);
         ctx->pool.clear();
         ctx->timer.destroy();
-        if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
-        if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-        for (hipEvent_t ev : {ctx->ev_fork, ctx->ev_join, ctx->ev_aux0, ctx->ev_aux1}) if (ev) (void)hipEventDestroy(ev);
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
         if (ctx->h_local) (void)hipHostFree(ctx->h_local);
     }

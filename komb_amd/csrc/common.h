@@ -159,8 +159,6 @@ struct komb_ctx {
     bool device_ok = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux = nullptr;               // low-priority side stream: work that needs no peel result runs beside the peel
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_aux0 = nullptr, ev_aux1 = nullptr;
     komb::Timer timer;
 
     // ---- resident simple graph (symmetric CSR, rows ascending)

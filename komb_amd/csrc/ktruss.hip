@@ -694,10 +694,9 @@ struct TrussLocal {
 // The oriented slot of {u,v} -- where trussness and support live -- is the slot's own rank in the
 // orientation compaction, or found by a binary search of the tiny oriented row of the other endpoint.
 // Nothing of this depends on the peel: the edge list, the supports and the map pi (canonical position ->
-// internal id) are produced on the side stream while the peel runs; afterwards trussness is one gather through pi.
+// internal id) are produced before it; afterwards trussness is one gather through pi.
 // Canonical edge list and the map canonical position -> internal edge id.  One workgroup per kMapSlots slots
-// of the working CSR and no grid-stride loop: the kernel runs on the low-priority side stream beside the peel, and
-// short workgroups give the CUs back to the peel's launches within microseconds.
+// of the working CSR.
 constexpr int kMapPerThread = 8;
 constexpr int kMapSlots = kBlock * kMapPerThread;
 __global__ __launch_bounds__(kBlock) void k_canonical_map(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
@@ -1000,9 +999,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;
     bufs.release(d_cnt); bufs.release(d_own);
 
-    // ---- canonical edge list, supports and the map to internal ids: nothing here needs the peel.  KOMB_AUX=1 runs it on
-    // the side stream beside the peel (measured: no gain yet -- the peel's 1024-thread workgroups need whole CUs, and the
-    // map's workgroups keep every CU partly busy; KOMB_AUX_CUS confines the side stream to some CUs)
+    // ---- canonical edge list, supports and the map to internal ids.  Nothing here needs the peel; running it on a side
+    // stream beside the peel was measured and gained nothing (both are bound by HBM), so it simply runs first.
     uint32_t *d_ucnt = nullptr, *d_ebase = nullptr, *d_pi = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
@@ -1011,32 +1009,18 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+    ctx->timer.start(s);
     KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
     k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
-    const bool use_aux = !(getenv("KOMB_AUX") && atoi(getenv("KOMB_AUX")) == 0);
-    hipStream_t ms = use_aux ? ctx->aux : s;
-    struct AuxGuard {                                  // no buffer of this run goes back to the pool while the side stream uses it
-        komb_ctx *c; bool pending;
-        ~AuxGuard() { if (pending) (void)hipStreamSynchronize(c->aux); }
-    } aux_guard{ctx, false};
-    bool fork_ok = false;
-    if (use_aux) {
-        KOMB_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
-        KOMB_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-        aux_guard.pending = true;
-        fork_ok = true;
-    }
-    (void)hipEventRecord(ctx->ev_aux0, ms);
-    k_canonical_map<<<(unsigned)((w_ns + kMapSlots - 1) / kMapSlots), kBlock, 0, ms>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol,
-                                                                                        d_off, ctx->d_t_eu, ctx->d_t_ev, d_pi, ctx->d_t_sup);
-    (void)hipEventRecord(ctx->ev_aux1, ms);
-    if (use_aux) KOMB_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    k_canonical_map<<<(unsigned)((w_ns + kMapSlots - 1) / kMapSlots), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol,
+                                                                                       d_off, ctx->d_t_eu, ctx->d_t_ev, d_pi, ctx->d_t_sup);
+    st.ms_canon_map = ctx->timer.stop(s);
 
     // ---- peel
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
     PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
-    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, getenv("KOMB_SCAN_SCALAR") ? 1 : 0};
     const size_t heavy_cap = (size_t)total / 32 + 64;             // see kcore.hip
     KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
@@ -1192,16 +1176,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
 
     // ---- canonical-order trussness: one gather through the map the side stream has built meanwhile
     ctx->timer.start(s);
-    if (fork_ok) {
-        KOMB_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-        aux_guard.pending = false;
-    }
     k_gather_truss<<<grid_for(m), kBlock, 0, s>>>(d_pi, d_truss, m, ctx->d_t_truss);
     st.ms_gather = ctx->timer.stop(s);
-    {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev_aux0, ctx->ev_aux1) == hipSuccess) st.ms_canon_map = (double)ms;
-    }
     ctx->t_ne = m;
     ctx->truss_done = true;
     return KOMB_OK;

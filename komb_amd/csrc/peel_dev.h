@@ -98,6 +98,7 @@ struct PeelQueues {
     int32_t *light[2];       // unit ids
     int2 *heavy[2];          // (unit id, chunk index)
     int32_t *live[2];        // compacted ids of the units still live (SCAN's input once it pays off)
+    int scalar_scan;         // debug: dense sweeps without the 16-byte loads
 };
 
 // ---------------------------------------------------------------- appenders
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         // (one unit per trip left the sweep bound by 2 x 380 sequential memory latencies).
         // Dense sweep (no live list yet): a lane takes kScanU CONSECUTIVE units and loads their markers and keys as
         // one 16-byte vector each, and stores the four classification bytes as one word.
-        const bool vec = !from_list;
+        const bool vec = !from_list && !Q.scalar_scan;
         const int32_t *s_marker = p.scan_marker(), *s_key = p.scan_key();
         uint32_t n_light = 0, n_chunks = 0, n_hits = 0, n_surv = 0;   // n_chunks per lane, others wave-uniform
         int32_t lmin = 0x7FFFFFFF;
