@@ -695,10 +695,7 @@ struct TrussLocal {
 // orientation compaction, or found by a binary search of the tiny oriented row of the other endpoint.
 // Nothing of this depends on the peel: the edge list, the supports and the map pi (canonical position ->
 // internal id) are produced before it; afterwards trussness is one gather through pi.
-// Canonical edge list and the map canonical position -> internal edge id.  One workgroup per kMapSlots slots
-// of the working CSR.
-constexpr int kMapPerThread = 8;
-constexpr int kMapSlots = kBlock * kMapPerThread;
+// Canonical edge list and the map canonical position -> internal edge id.
 __global__ __launch_bounds__(kBlock) void k_canonical_map(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
                                                           const int32_t *__restrict__ col, int64_t ns,
                                                           const unsigned long long *__restrict__ obits,
@@ -709,11 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_canonical_map(const uint32_t *__rest
                                                           int32_t *__restrict__ eu, int32_t *__restrict__ ev,
                                                           uint32_t *__restrict__ pi, int32_t *__restrict__ sup_out)
 {
-    const int64_t j0 = (int64_t)blockIdx.x * kMapSlots + threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < kMapPerThread; ++r) {
-        const int64_t j = j0 + (int64_t)r * kBlock;
-        if (j >= ns) break;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
         const int32_t u = src[j], v = col[j];
         if (v <= u) continue;
         const uint32_t eb = ebase[u];
@@ -1013,7 +1006,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
     k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
-    k_canonical_map<<<(unsigned)((w_ns + kMapSlots - 1) / kMapSlots), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol,
+    k_canonical_map<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol,
                                                                                        d_off, ctx->d_t_eu, ctx->d_t_ev, d_pi, ctx->d_t_sup);
     st.ms_canon_map = ctx->timer.stop(s);
 
