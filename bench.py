@@ -64,7 +64,7 @@ def cpu_baseline():
     import komb_amd
     from oracle import oracle as O
     nv, ncl, alpha, seed = CPU_SAMPLE
-    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
+    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed + (rank if args.batch else 0))
     rowptr, col = O.simplify(nv, uv)
     ne = len(col) // 2
     t0 = time.perf_counter()
@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", action="store_true",
+                    help="N > 1: every rank decomposes a graph of its own (seed + rank) -- KOMB's one-graph-per-sample shape "
+                         "(KOMB.py --file-list); no exchange on the data path, weak scaling.  Default: the SAME graph on every "
+                         "rank, support counting sharded by vertex range + one all-reduce (BASELINE configs[3])")
     ap.add_argument("--no-build", action="store_true",
                     help="load the prebuilt libkomb_accel.so, spawn no compiler (use under rocprofv3)")
     ap.add_argument("--faithful", action="store_true",
@@ -159,7 +163,7 @@ def main():
 
     nv, ncl, alpha, seed, desc = CONFIGS[args.config]
     t0 = time.perf_counter()
-    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
+    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed + (rank if args.batch else 0))
     t_gen = time.perf_counter() - t0
     acc = komb_amd.KombAccel(device=local_rank)
     t0 = time.perf_counter()
@@ -178,7 +182,7 @@ def main():
         from komb_amd import distributed as kd
 
     def step():
-        if world > 1:
+        if world > 1 and not args.batch:
             kd.truss_run_sharded(acc, group=data_group)   # support phase sharded by vertex range + all-reduce
         else:
             acc.truss_run()
@@ -196,10 +200,15 @@ def main():
             phase[k] += s[k]
     barrier_sync()
     dt = time.perf_counter() - t0
+    ne_total = ne
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if args.batch:                                    # the job's units: the edges of all the ranks' graphs
+            t = torch.tensor([ne], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ne_total = int(t.item())
     st = acc.stats()
     for k in phase:
         phase[k] /= args.steps
@@ -264,10 +273,10 @@ def main():
             "whole_step_frac": sum(v[2] for v in kernels.values()) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }
         out = {
-            "metric": "peeled edges/sec (k-truss)", "value": ne * args.steps / dt,
+            "metric": "peeled edges/sec (k-truss)", "value": ne_total * args.steps / dt,
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "scaling": "weak" if (args.batch and world > 1) else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": desc, "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
                        "max_degree": st["max_degree"], "max_trussness": st["max_trussness"],
                        "max_coreness": core_stats["max_coreness"],
@@ -276,7 +285,9 @@ def main():
                        "truss_local": {"edges": st["truss_local_units"], "index_entries": st["truss_local_items"],
                                        "sweeps": st["truss_local_sweeps"]},
                        "parallelism": "single" if world == 1 else
-                       f"same graph on {world} ranks: support phase sharded by source-vertex range + one all-reduce ({exchange}), index/peel replicated"},
+                       (f"batch: {world} independent graphs (seed + rank), one per GPU, no exchange on the data path" if args.batch else
+                        f"same graph on {world} ranks: triangle-support counting sharded by source-vertex range + one all-reduce of the "
+                        f"per-edge support vector ({exchange}); incidence fill, peel and gather replicated on every rank")},
             "phases_ms": phase,
             "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
                       "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],

@@ -35,7 +35,9 @@ def n_support_tasks(nv, verts_per_task=16):
 
 
 class _RawDeviceI32:
-    """Zero-copy view of a raw device pointer for torch.as_tensor."""
+    """Zero-copy view of a raw device pointer for torch.as_tensor.  The ABI's buffer is uint32[count]; it is viewed as
+    int32 because torch reduces int32 on every backend, and a 32-bit two's-complement SUM is the same bits either way
+    (the header says so: include/komb_accel.h, komb_allreduce_fn)."""
 
     def __init__(self, address, count):
         self.__cuda_array_interface__ = {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output into the small summaries kept under profiles/.
 
-    python scripts/prof_summary.py <tag> <kernel_trace_dir> [<pmc_fetch_dir> <pmc_write_dir>]
+    python scripts/prof_summary.py <tag> <kernel_trace_dir> [<pmc_fetch_dir> <pmc_write_dir> [<pmc_sq_dir>]]
 
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --stats), profiles/<tag>_kernels.json
 (per-kernel launches / total / average from the kernel trace) and, when the two PMC directories
@@ -25,7 +25,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     n = name.replace("komb::(anonymous namespace)::", "").replace("komb::", "").replace("void ", "")
     if n.startswith("k_peel_step<"):
-        return "k_peel_step<Truss>" if "TrussProblem" in n else "k_peel_step<Core>"
+        for key, nice in (("TrussProblem", "Truss"), ("CoreProblem", "Core"), ("TrussCollect", "TrussCollect"), ("CoreCollect", "CoreCollect")):
+            if key in n:
+                return f"k_peel_step<{nice}>"
+    if n.startswith("k_local_step<"):
+        return "k_local_step<Truss>" if "TrussLocal" in n else "k_local_step<Core>"
     for key, nice in (("k_triangles<0", "k_triangles<count>"), ("k_triangles<1", "k_triangles<fill>"),
                       ("k_triangles<2", "k_triangles<single>"), ("k_compact_inc<", "k_compact_inc")):
         if n.startswith(key):
@@ -52,6 +56,23 @@ def main():
                for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))}
     json.dump(kernels, open(os.path.join(out, f"{tag}_kernels.json"), "w"), indent=1)
     print(json.dumps(kernels, indent=1)[:1500])
+    if len(sys.argv) >= 6:
+        # SQ counters (one --pmc pass): per kernel sums, and the share of wave cycles spent waiting / issuing
+        f = glob.glob(os.path.join(sys.argv[5], "**", "*_counter_collection.csv"), recursive=True)[0]
+        sq = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            sq[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        res = {}
+        for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0.0)):
+            wc = v.get("SQ_WAVE_CYCLES", 0.0)
+            if wc <= 0:
+                continue
+            res[k] = dict(v)
+            res[k]["wait_any_frac"] = v.get("SQ_WAIT_ANY", 0.0) / wc
+            res[k]["wait_inst_frac"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
+            res[k]["active_inst_frac"] = v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+        json.dump(res, open(os.path.join(out, f"{tag}_sq.json"), "w"), indent=1)
+        print({k: {"wait": round(v["wait_any_frac"], 3), "issue": round(v["active_inst_frac"], 3)} for k, v in list(res.items())[:8]})
     if len(sys.argv) >= 5:
         traffic = collections.defaultdict(lambda: {"launches": 0})
         for ctr_dir in sys.argv[3:5]:

@@ -52,8 +52,33 @@ def partial_support(orow, rows, v_lo, v_hi):
     return own + other                                   # what the library sums before the exchange
 
 
+def rccl_main():
+    """One rank, backend "nccl" (= RCCL): the in-place device branch of the all-reduce callback, called the way the
+    library calls it (raw device pointer + count).  With one rank the sum is the identity."""
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl"
+    cb = kd.make_allreduce_callback(0)
+    x = torch.arange(1, 100001, dtype=torch.int32, device="cuda:0")
+    want = x.clone()
+    torch.cuda.synchronize()
+    rc = cb(None, x.data_ptr(), x.numel())
+    assert rc == 0 and torch.equal(x, want)
+    # and through the library: world 1 of 1 takes the single-GPU path, results equal the oracle's
+    nv = 20000
+    uv = komb_amd.gen_hug_edges(nv, int(2.6 * nv), 2.6, 11)
+    rowptr, col = O.simplify(nv, uv)
+    with komb_amd.KombAccel(device=0) as a:
+        a.from_edges(nv, uv)
+        kd.truss_run_sharded(a)
+        assert np.array_equal(a.truss_fetch()[2], O.trussness(rowptr, col))
+    print("DIST_OK rccl 1")
+    dist.destroy_process_group()
+
+
 def main():
     mode = sys.argv[1]
+    if mode == "rccl":
+        return rccl_main()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     nv = 3000 if mode == "cpu" else 60000

@@ -37,3 +37,10 @@ def test_world2_gloo_cpu(built):
 def test_world2_sharded_on_gpu(built):
     r = _launch("gpu", 2, 29612)
     assert r.returncode == 0 and "DIST_OK gpu 2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_rccl_inplace_branch_single_rank(built):
+    """backend "nccl" on the GPU box: the in-place RCCL branch of komb_amd.distributed's callback runs (one rank)."""
+    r = _launch("rccl", 1, 29613)
+    assert r.returncode == 0 and "DIST_OK rccl 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
