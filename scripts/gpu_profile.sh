@@ -3,7 +3,8 @@
 # (separate passes; nothing but the program itself after "--").  usage: gpu_profile.sh <tag> <config>
 tag=$1; cfg=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
+mkdir -p gpurun_out/profiles
+export KOMB_PROF_OUT=gpurun_out/profiles
 cmd="python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-build"
 timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt -- $cmd > gpurun_out/${tag}_kt.log 2>&1 || exit 1
 timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $cmd > gpurun_out/${tag}_fetch.log 2>&1 || exit 1

@@ -43,7 +43,7 @@ def short(name):
 
 def main():
     tag, trace_dir = sys.argv[1], sys.argv[2]
-    out = os.path.join(ROOT, "profiles")
+    out = os.environ.get("KOMB_PROF_OUT", os.path.join(ROOT, "profiles"))    # on the GPU box: a directory under gpurun_out/
     os.makedirs(out, exist_ok=True)
     stats = glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
