@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -24,9 +25,16 @@ constexpr int32_t kAlive = 0x7FFFFFFF;
 constexpr int32_t kAliveMin = 0x40000000;   // every alive marker is >= this; every round / level number is below it
 
 // Device-side control block of a peel loop.  One 128-byte record; the fields a
-// launch reads at entry are written only by the previous launch's last block.
+// launch reads at entry are written only by the workgroup that finalises a step.
+// `seq` is the index of the launch the state is meant for: every launch carries its
+// own index, a workgroup acts only when the two agree before AND after it has read
+// the state, and a finaliser moves `seq` on before it touches anything else -- so a
+// workgroup that is dispatched late (another process shares the GPU, say), after the
+// state has already been rewritten for the next launch, leaves instead of taking part
+// in a step that is not its launch's.
 struct PeelCtrl {
-    // ---- stable during a launch (written by the finalising workgroup only)
+    // ---- first 64-byte line: the state a launch reads at entry (one coalesced load = one snapshot) and its sequence word.
+    // Written by the finalising workgroup only; the counters in it are statistics.
     int32_t  mode;          // 0 = SCAN, 1 = PROCESS
     int32_t  level;         // current peel level (degree k / support L)
     int32_t  round;         // sub-round id stamped on the current frontier
@@ -42,17 +50,18 @@ struct PeelCtrl {
     uint32_t live_count;    // entries of the compacted live list (live_mode 1)
     int32_t  live_sel;      // which live-list buffer is current
     int32_t  live_mode;     // 0: SCAN sweeps all units; 1: SCAN sweeps the live list
-    uint32_t live_tail;     // (atomic) survivors appended by the running SCAN
-    // ---- modified with atomics during a launch
+    int32_t  seq;           // index of the launch this state is for (see above)
+    // ---- second line: modified with atomics during a launch
     uint32_t tail_l[2];     // append cursors of the light queues
     uint32_t tail_h[2];     // append cursors of the heavy queues
     int32_t  next_min;      // min live key above the scanned level
-    uint32_t blocks_done;   // second-level arrival ticket
-    uint32_t acc;           // units that entered a frontier in this launch
-    // ---- hand-over to a specialised tail kernel (k-truss, truss_tail.h)
+    uint32_t live_tail;     // survivors appended by the running SCAN
+    uint32_t acc;           // (unused)
+    // ---- hand-over to a finish (local_dev.h, truss_tail.h, core_tail.h); constant while launches are queued
     uint32_t tail_limit;    // a level that starts with at most this many units left sets done = 3 (0: never)
     uint32_t pad1[8];
 };
+static_assert(offsetof(PeelCtrl, seq) == 60 && offsetof(PeelCtrl, tail_l) == 64, "PeelCtrl: the entry state is one 64-byte line");
 static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
 
 // Device-side control block of the local finish (local_dev.h): an h-index fixed point on the remainder
@@ -269,7 +278,11 @@ int peel_grid(int64_t units);
 template <typename F>
 int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *launches_out)
 {
+    // launch(i) issues the launch with index i; the state says which index it expects (PeelCtrl::seq)
     constexpr int kBatch = 24;
+    PeelCtrl first;
+    KOMB_HIP(ctx, d2h(ctx, &first, d_ctrl, sizeof(PeelCtrl)));
+    int32_t next = first.seq;
 #ifdef KOMB_DEBUG_SWITCHES
     if (const char *tr = getenv("KOMB_PEEL_TRACE")) {
         // debug: one launch at a time; append "mode level round light heavy live_mode live_count remaining us" per step
@@ -287,7 +300,7 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
             if (d2h(ctx, &before, d_ctrl, sizeof(PeelCtrl)) != hipSuccess) break;
             if (before.done) break;
             (void)hipEventRecord(a, ctx->stream);
-            launch(); ++launches;
+            launch(before.seq); ++launches;
             (void)hipEventRecord(b, ctx->stream);
             (void)hipEventSynchronize(b);
             float ms = 0.f;
@@ -307,14 +320,18 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     const int64_t max_batches = (4 * units + 4096) / kBatch + 16;   // > 2 launches per unit: cannot be reached
     int launches = 0, slot = 0, status = KOMB_OK;
-    bool have_prev = false, finished = false;
+    bool have_prev = false, finished = false, stuck = false;
+    int32_t seen_seq = first.seq - 1;
     for (int64_t batch = 0; batch < max_batches && !finished; ++batch) {
-        for (int i = 0; i < kBatch; ++i) { launch(); ++launches; }
+        for (int i = 0; i < kBatch; ++i) { launch(next); ++next; ++launches; }
         if (hipMemcpyAsync(&ctx->h_ctrl[slot], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipEventRecord(ev[slot], ctx->stream) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
         if (have_prev) {
             if (hipEventSynchronize(ev[slot ^ 1]) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
-            if (ctx->h_ctrl[slot ^ 1].done) finished = true;
+            const PeelCtrl &h = ctx->h_ctrl[slot ^ 1];
+            if (h.done) finished = true;
+            else if (h.seq == seen_seq) { stuck = true; finished = true; }   // a whole batch of launches moved nothing
+            seen_seq = h.seq;
         }
         have_prev = true;
         slot ^= 1;
@@ -328,8 +345,9 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
     if (d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) != hipSuccess)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: control block readback failed");
     if (!ctx->h_ctrl[0].done)
-        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: launch budget exhausted before completion (level %d, remaining %u)",
-                  ctx->h_ctrl[0].level, ctx->h_ctrl[0].remaining);
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: %s (level %d, remaining %u, launch %d of state %d)",
+                  stuck ? "the launches make no progress" : "launch budget exhausted before completion",
+                  ctx->h_ctrl[0].level, ctx->h_ctrl[0].remaining, (int)next, (int)ctx->h_ctrl[0].seq);
     return KOMB_OK;
 }
 } // namespace komb

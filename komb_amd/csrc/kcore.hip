@@ -137,7 +137,7 @@ __global__ void k_collect_ctrl(PeelCtrl *c2, const PeelCtrl *from)
 {
     if (threadIdx.x == 0) {
         PeelCtrl c{};
-        c.mode = MODE_SCAN; c.round = 1; c.level = 0x3FFFFFFF;
+        c.mode = MODE_SCAN; c.round = 1; c.level = 0x3FFFFFFF; c.seq = 1;
         c.remaining = from->remaining;
         c.live_mode = from->live_mode; c.live_sel = from->live_sel; c.live_count = from->live_count;
         c.next_min = 0x7FFFFFFF;
@@ -157,7 +157,7 @@ __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t u
         const uint32_t peeled = grp_done[kInitOff];
         const int32_t first = (int32_t)grp_done[kInitOff + 1];
         PeelCtrl c{};
-        c.mode = MODE_SCAN; c.round = 1;
+        c.mode = MODE_SCAN; c.round = 1; c.seq = 1;
         c.remaining = units - peeled;
         c.done = (c.remaining == 0) ? 1 : 0;
         c.level = c.remaining ? first : 0;           // start at the first populated level
@@ -267,9 +267,9 @@ int core_run(komb_ctx *ctx)
         LocalStats ls;
         const int rc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)nv, ctx->d_core, d_degw, Q.live[hc.live_sel],
             (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), 0, ctx->d_core,
-            [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl) {
+            [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 CoreCollect C{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, ctx->d_core, d_livebits, num, lg.off, lg.cur, (uint32_t *)items};
-                k_peel_step<CoreCollect><<<grid, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C);
+                k_peel_step<CoreCollect><<<grid, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);
             },
             [&](const LocalGraph &lg, void *items, uint64_t total, LocalCtrl *d_lctrl, uint32_t *d_cnt, int *launches) -> int {
                 return local_fixpoint(ctx, d_lctrl, d_cnt, lg, CoreLocal{(const uint32_t *)items}, total, launches);
@@ -307,8 +307,8 @@ int core_run(komb_ctx *ctx)
             continue;
         }
         int batch = 0;
-        st = drive_peel(ctx, d_ctrl, nv, [&]() {
-            k_peel_step<CoreProblem><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
+        st = drive_peel(ctx, d_ctrl, nv, [&](int32_t launch) {
+            k_peel_step<CoreProblem><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P, launch);
         }, &batch);
         launches += batch;
     }

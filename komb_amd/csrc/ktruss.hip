@@ -1097,9 +1097,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         LocalStats ls;
         const int lrc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)m, d_stamp, d_sup, Q.live[hc.live_sel],
             (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), 2, d_truss,
-            [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl) {
+            [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 TrussCollect C{(uint32_t)m, d_off, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
-                k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C);
+                k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);
             },
             [&](const LocalGraph &lg, void *items, uint64_t total_items, LocalCtrl *d_lctrl, uint32_t *d_cnt, int *nl) -> int {
                 return local_fixpoint(ctx, d_lctrl, d_cnt, lg, TrussLocal{(const uint2 *)items}, total_items, nl);
@@ -1142,8 +1142,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             continue;
         }
         int batch = 0;
-        rc = drive_peel(ctx, d_ctrl, m, [&]() {
-            k_peel_step<TrussProblem><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P);
+        rc = drive_peel(ctx, d_ctrl, m, [&](int32_t launch) {
+            k_peel_step<TrussProblem><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, P, launch);
         }, &batch);
         launches += batch;
     }

@@ -620,7 +620,7 @@ struct LocalStats {
 // The whole hand-over: number -> scan -> collect (peel engine, `launch_collect`) -> check -> sweep (`run_fix`) ->
 // scatter.  hc = the peel's control block as the host last read it (done == 3, or the initial state of a small
 // input); marker / key = the peel's alive markers and live keys; `out` receives value + add for every unit of
-// the remainder.  launch_collect(g, num, items, d_cctrl) issues ONE launch of k_peel_step<Collect>;
+// the remainder.  launch_collect(g, num, items, d_cctrl, index) issues ONE launch of k_peel_step<Collect>;
 // run_fix(g, items, total, d_lctrl, d_cnt, &launches) = local_fixpoint<Local>; after_number(g) runs once the ids exist
 // (k-core builds its bitmap of live vertices there).
 template <class LaunchCollect, class RunFix, class AfterNumber>
@@ -681,9 +681,11 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     // collect: SCAN (every live unit is a hit) + PROCESS of the peel engine on its own control block
     peel_collect_ctrl(s, d_cctrl, d_ctrl);
     PeelCtrl hcc{};
+    int32_t cl = 1;                                        // launch indices of the collect pass (its state starts at seq 1)
     for (int guard = 0; guard < 16 && hcc.done == 0; ++guard) {
-        for (int i = 0; i < 3; ++i) launch_collect(g, d_num, d_items, d_cctrl);
+        for (int i = 0; i < 3; ++i) launch_collect(g, d_num, d_items, d_cctrl, cl++);
         KOMB_HIP(ctx, d2h(ctx, &hcc, d_cctrl, sizeof(PeelCtrl)));
+        cl = hcc.seq;                                      // launches that found nothing to do do not move the state on
     }
     if (hcc.done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: collect pass did not complete (state %d)", hcc.done);
     int64_t gn = ((int64_t)n + kBlock - 1) / kBlock;

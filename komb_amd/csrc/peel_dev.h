@@ -204,9 +204,12 @@ __device__ __forceinline__ uint32_t plan_step(const CtrlView &cv, uint32_t grid,
 // participating workgroup has arrived; the independent atomics are issued from different lanes
 // so they cost one round trip, not seven.  The new state is also left in *out (LDS) so that a
 // single workgroup can go on to the next step without re-reading global memory.
-__device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out, uint32_t acc)
+__device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out, uint32_t acc, int32_t launch)
 {
     const int lane = lane_id();
+    // from here on the state belongs to the NEXT launch: late workgroups of this one must not act on it
+    if (lane == 0) { (void)atomicExch(&ctrl->seq, launch + 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_wave_barrier();
     const bool scan = cv.mode == MODE_SCAN;
     const int sel = cv.cur_sel;
     const bool emitted = scan && (cv.live_mode != 0 || cv.remaining <= units / 2);
@@ -267,7 +270,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 //                                        decrements; ids of triggered units or -1, and their classes
 // (load and apply are split so that the loads of several items are in flight together)
 template <class P>
-__global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p)
+__global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p, int32_t launch)
 {
     __shared__ CtrlView sh_cv;
     __shared__ uint32_t sh_w[kPeelWaves][4];           // per-wave counts / bases
@@ -286,12 +289,20 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
 #else
 #define KOMB_TK(i) do { } while (0)
 #endif
+    // Entry: the state and its sequence word are one 64-byte line, loaded by 16 lanes of ONE instruction -- one snapshot.
+    // A workgroup acts only on the state written for THIS launch (PeelCtrl::seq, common.h): one that is dispatched after a
+    // finaliser has moved on is late and leaves.
+    __shared__ int32_t sh_raw[16];
+    if (threadIdx.x < 16) sh_raw[threadIdx.x] = reinterpret_cast<const int32_t *>(ctrl)[threadIdx.x];
+    __syncthreads();
     if (threadIdx.x == 0) {
-        sh_cv.mode = ctrl->mode; sh_cv.level = ctrl->level; sh_cv.round = ctrl->round; sh_cv.done = ctrl->done;
-        sh_cv.cur_sel = ctrl->cur_sel; sh_cv.cur_light = ctrl->cur_light; sh_cv.cur_heavy = ctrl->cur_heavy;
-        sh_cv.remaining = ctrl->remaining; sh_cv.live_count = ctrl->live_count;
-        sh_cv.live_sel = ctrl->live_sel; sh_cv.live_mode = ctrl->live_mode;
+        const PeelCtrl *c = reinterpret_cast<const PeelCtrl *>(sh_raw);        // the first line only
+        sh_cv.mode = c->mode; sh_cv.level = c->level; sh_cv.round = c->round; sh_cv.done = c->done;
+        sh_cv.cur_sel = c->cur_sel; sh_cv.cur_light = c->cur_light; sh_cv.cur_heavy = c->cur_heavy;
+        sh_cv.remaining = c->remaining; sh_cv.live_count = c->live_count;
+        sh_cv.live_sel = c->live_sel; sh_cv.live_mode = c->live_mode;
         sh_cv.tail_limit = ctrl->tail_limit;
+        if (c->seq != launch) sh_cv.done = 1;
     }
     __syncthreads();
     CtrlView cv = sh_cv;
@@ -616,11 +627,11 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
 #endif
         last = __shfl(last, 0);
         total = (uint32_t)__shfl((int)total, 0);
-        if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total);
+        if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total, launch);
         return;
     }
     // one workgroup did the whole step: finalise locally, chain the next step if it is small too
-    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc);
+    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc, launch);
     __syncthreads();
     cv = sh_cv;
     if (cv.done || chained >= kMaxInKernelSteps) return;
