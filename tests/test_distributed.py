@@ -44,3 +44,12 @@ def test_rccl_inplace_branch_single_rank(built):
     """backend "nccl" on the GPU box: the in-place RCCL branch of komb_amd.distributed's callback runs (one rank)."""
     r = _launch("rccl", 1, 29613)
     assert r.returncode == 0 and "DIST_OK rccl 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_processes_sharing_one_gpu(built):
+    """Two processes decomposing at the same time on GPU 0 (scripts/share_stress.py): workgroups of a launch get
+    dispatched late when the CUs are busy with somebody else's kernels -- the peel's launch-to-launch hand-over must not
+    depend on when they start (this caught stale-state steps before every launch carried its index)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "share_stress.py"), "2", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rc [0, 0]" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
