@@ -192,7 +192,7 @@ def main():
     barrier_sync()
     t0 = time.perf_counter()
     phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_compact", "ms_peel", "ms_tail",
-                              "ms_truss_local", "ms_gather", "ms_canon_map")}
+                              "ms_truss_local", "ms_gather")}
     for _ in range(args.steps):
         step()
         s = acc.stats()

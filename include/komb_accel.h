@@ -75,7 +75,6 @@ typedef struct komb_stats {
     int32_t truss_local_units, truss_local_sweeps; /* edges handed over; sweeps                */
     double  ms_core_local;          /* part of ms_core: numbering + collect + sweeps + scatter */
     double  ms_truss_local;         /* part of ms_peel                                         */
-    double  ms_canon_map;           /* truss: canonical edge list, supports, edge -> internal id map (before the peel) */
 } komb_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -38,7 +38,7 @@ class KombStats(ctypes.Structure):
         ("core_local_items", ctypes.c_int64), ("truss_local_items", ctypes.c_int64),
         ("core_local_units", ctypes.c_int32), ("core_local_sweeps", ctypes.c_int32),
         ("truss_local_units", ctypes.c_int32), ("truss_local_sweeps", ctypes.c_int32),
-        ("ms_core_local", ctypes.c_double), ("ms_truss_local", ctypes.c_double), ("ms_canon_map", ctypes.c_double),
+        ("ms_core_local", ctypes.c_double), ("ms_truss_local", ctypes.c_double),
     ]
 
 

@@ -691,20 +691,24 @@ struct TrussLocal {
 // One thread per slot of the working CSR.  Upper slots (u < v) are the canonical
 // copies of the edges; they are the suffix of their (ascending) row, so the
 // canonical id is ebase[u] + (j - first upper slot of u) with no compaction.
-// The oriented slot of {u,v} -- where trussness and support live -- is the slot's own rank in the
-// orientation compaction, or found by a binary search of the tiny oriented row of the other endpoint.
-// Nothing of this depends on the peel: the edge list, the supports and the map pi (canonical position ->
-// internal id) are produced before it; afterwards trussness is one gather through pi.
-// Canonical edge list and the map canonical position -> internal edge id.
-__global__ __launch_bounds__(kBlock) void k_canonical_map(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
-                                                          const int32_t *__restrict__ col, int64_t ns,
-                                                          const unsigned long long *__restrict__ obits,
-                                                          const uint32_t *__restrict__ wrank,
-                                                          const uint32_t *__restrict__ ebase,
-                                                          const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
-                                                          const uint32_t *__restrict__ off,
-                                                          int32_t *__restrict__ eu, int32_t *__restrict__ ev,
-                                                          uint32_t *__restrict__ pi, int32_t *__restrict__ sup_out)
+// The oriented slot of {u,v} -- where trussness and support live -- is found by
+// a binary search of the tiny oriented row of the lower-(degree,id) endpoint.
+__global__ __launch_bounds__(kBlock) void k_pack_results(const int32_t *__restrict__ truss, const uint32_t *__restrict__ off,
+                                                         int64_t m, int2 *__restrict__ res)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock)
+        res[e] = make_int2(truss[e], (int)(off[e + 1] - off[e]));
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
+                                                             const int32_t *__restrict__ col, int64_t ns,
+                                                             const unsigned long long *__restrict__ obits,
+                                                             const uint32_t *__restrict__ wrank,
+                                                             const uint32_t *__restrict__ ebase,
+                                                             const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
+                                                             const int2 *__restrict__ res,
+                                                             int32_t *__restrict__ eu, int32_t *__restrict__ ev,
+                                                             int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
         const int32_t u = src[j], v = col[j];
@@ -726,16 +730,11 @@ __global__ __launch_bounds__(kBlock) void k_canonical_map(const uint32_t *__rest
                 if (ocol[mid] < u) lo = mid + 1; else hi = mid;
             }
         }
+        const int2 r = res[lo];
         eu[o] = u; ev[o] = v;
-        pi[o] = lo;
-        sup_out[o] = (int32_t)(off[lo + 1] - off[lo]);
+        tr_out[o] = r.x;
+        sup_out[o] = r.y;
     }
-}
-
-__global__ __launch_bounds__(kBlock) void k_gather_truss(const uint32_t *__restrict__ pi, const int32_t *__restrict__ truss, int64_t m,
-                                                         int32_t *__restrict__ tr_out)
-{
-    for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < m; o += (int64_t)gridDim.x * kBlock) tr_out[o] = truss[pi[o]];
 }
 
 // sum_v d(v)^2 and sum_e min(d(u),d(v)) for the roofline's algorithmic bytes
@@ -992,24 +991,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;
     bufs.release(d_cnt); bufs.release(d_own);
 
-    // ---- canonical edge list, supports and the map to internal ids.  Nothing here needs the peel; running it on a side
-    // stream beside the peel was measured and gained nothing (both are bound by HBM), so it simply runs first.
-    uint32_t *d_ucnt = nullptr, *d_ebase = nullptr, *d_pi = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_pi, (size_t)m));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-    ctx->timer.start(s);
-    KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
-    k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
-    k_canonical_map<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol,
-                                                                                       d_off, ctx->d_t_eu, ctx->d_t_ev, d_pi, ctx->d_t_sup);
-    st.ms_canon_map = ctx->timer.stop(s);
-
     // ---- peel
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
     PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
@@ -1167,9 +1148,23 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     bufs.release(Q.code);
     bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc);
 
-    // ---- canonical-order trussness: one gather through the map the side stream has built meanwhile
+    // ---- canonical-order results with original vertex ids
+    uint32_t *d_ucnt = nullptr, *d_ebase = nullptr;
     ctx->timer.start(s);
-    k_gather_truss<<<grid_for(m), kBlock, 0, s>>>(d_pi, d_truss, m, ctx->d_t_truss);
+    KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
+    KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
+    k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+    int2 *d_res = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
+    k_pack_results<<<grid_for(m), kBlock, 0, s>>>(d_truss, d_off, m, d_res);
+    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol, d_res,
+                                                        ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
     ctx->t_ne = m;
     ctx->truss_done = true;
