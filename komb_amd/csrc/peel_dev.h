@@ -345,6 +345,17 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             return vec ? tb + ((uint64_t)w * kWave + (uint64_t)lane) * kScanU + (uint64_t)k
                        : tb + (uint64_t)k * kPeelBlock + (uint64_t)w * kWave + (uint64_t)lane;
         };
+        // dense sweep: the vectors of the NEXT trip are requested before this trip is classified, so a workgroup's ~100 trips
+        // are not a chain of ~100 exposed memory latencies
+        int4 nm4 = make_int4(0, 0, 0, 0), nk4 = make_int4(0, 0, 0, 0);
+        auto fetch = [&](uint64_t tb) {
+            const uint64_t i0 = index_of(tb, 0);
+            if (vec && tb < n_in && i0 + kScanU <= n_in) {
+                nm4 = *reinterpret_cast<const int4 *>(s_marker + i0);
+                if (s_key) nk4 = *reinterpret_cast<const int4 *>(s_key + i0);
+            }
+        };
+        fetch((uint64_t)blockIdx.x * tile);
         for (uint64_t tb = (uint64_t)blockIdx.x * tile; tb < n_in; tb += (uint64_t)nblk * tile) {
             uint8_t code[kScanU];
             int32_t mk[kScanU], ky[kScanU];
@@ -352,11 +363,10 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             const bool whole = vec && i0 + kScanU <= n_in;
             if (whole) {
                 static_assert(kScanU == 4, "the dense sweep loads int4");
-                const int4 m4 = *reinterpret_cast<const int4 *>(s_marker + i0);
-                mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
-                if (s_key) { const int4 k4 = *reinterpret_cast<const int4 *>(s_key + i0); ky[0] = k4.x; ky[1] = k4.y; ky[2] = k4.z; ky[3] = k4.w; }
-                else { ky[0] = ky[1] = ky[2] = ky[3] = 0; }
+                mk[0] = nm4.x; mk[1] = nm4.y; mk[2] = nm4.z; mk[3] = nm4.w;
+                ky[0] = nk4.x; ky[1] = nk4.y; ky[2] = nk4.z; ky[3] = nk4.w;
             }
+            fetch(tb + (uint64_t)nblk * tile);
 #pragma unroll
             for (int k = 0; k < kScanU; ++k) {
                 const uint64_t idx = index_of(tb, k);
