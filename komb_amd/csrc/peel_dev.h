@@ -421,23 +421,22 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         // ---- pass B: replay the classification bytes, write the entries
         const uint32_t base_l = sh_base[0] + sh_w[w][0], base_h = sh_base[1] + sh_w[w][1], base_s = sh_base[2] + sh_w[w][3];
         uint32_t run_l = 0, run_h = 0, run_s = 0;
+        // (dense sweep: the wavefront replays the SAME 256 units it classified, now 64 consecutive ones per instruction, so
+        // that its stores -- queue entries, markers, results -- are whole lines and the live list stays in ascending order)
+        auto index_b = [&](uint64_t tb, int k) -> uint64_t {
+            return vec ? tb + (uint64_t)w * (kWave * kScanU) + (uint64_t)k * kWave + (uint64_t)lane : index_of(tb, k);
+        };
         for (uint64_t tb = (uint64_t)blockIdx.x * tile; tb < n_in; tb += (uint64_t)nblk * tile) {
             uint8_t code[kScanU];
             uint32_t u[kScanU];
-            const uint64_t i0 = index_of(tb, 0);
-            const bool whole = vec && i0 + kScanU <= n_in;
-            if (whole) {
-                const uchar4 c4 = *reinterpret_cast<const uchar4 *>(Q.code + i0);
-                code[0] = c4.x; code[1] = c4.y; code[2] = c4.z; code[3] = c4.w;
+#pragma unroll
+            for (int k = 0; k < kScanU; ++k) {
+                const uint64_t idx = index_b(tb, k);
+                code[k] = idx < n_in ? Q.code[idx] : (uint8_t)SC_NONE;
             }
 #pragma unroll
             for (int k = 0; k < kScanU; ++k) {
-                const uint64_t idx = index_of(tb, k);
-                if (!whole) code[k] = idx < n_in ? Q.code[idx] : (uint8_t)SC_NONE;
-            }
-#pragma unroll
-            for (int k = 0; k < kScanU; ++k) {
-                const uint64_t idx = index_of(tb, k);
+                const uint64_t idx = index_b(tb, k);
                 u[k] = 0;
                 if (code[k] != SC_NONE) u[k] = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
             }
