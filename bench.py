@@ -30,6 +30,7 @@ CONFIGS = {
     "tiny": (100_000, 245_000, 2.6, 42, "tiny: |V|=100k |E|~1M (debug)"),
 }
 CPU_SAMPLE = (700_000, 1_715_000, 2.6, 42)    # ~7M edges: 10-30 s of single-thread CPU work
+CPU_SAMPLE_ALL = (3_000_000, 7_350_000)       # ~30M edges for the all-cores variant
 
 
 def algorithmic_bytes(st):
@@ -59,20 +60,54 @@ def measured_traffic(config, kernel):
 
 
 def cpu_baseline():
-    """The oracle's igraph-equivalent trussness (single thread) on a bounded sample."""
+    """The CPU restatement of igraph's trussness (oracle/, test infrastructure) timed on this box's host cores, next to
+    the GPU figure: single thread pinned to one core (igraph is single-threaded and the reference calls it from one
+    thread, src/graph.cpp:508) on a bounded sample of the same generator, and the OpenMP all-cores variant on a larger
+    one.  The library is compiled on this machine for its own instruction set (oracle/Makefile target native)."""
     import numpy as np  # noqa: F401
     import komb_amd
     from oracle import oracle as O
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    native = O.native_lib() is not None
+    run1 = (lambda rp, c: O.trussness_native(rp, c, 1)) if native else O.trussness
     nv, ncl, alpha, seed = CPU_SAMPLE
-    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed + (rank if args.batch else 0))
+    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
     rowptr, col = O.simplify(nv, uv)
     ne = len(col) // 2
-    t0 = time.perf_counter()
-    O.trussness(rowptr, col)
-    dt = time.perf_counter() - t0
-    return {"value": ne / dt, "unit": "edges/s", "cores": 1, "kind": "port",
-            "sample": f"oracle orc_trussness (support + bucket peel, 1 thread) on |V|={nv} |E|={ne} of the same generator: {dt:.1f} s",
-            "host_cpus": os.cpu_count()}
+    cpus = sorted(os.sched_getaffinity(0))
+    os.sched_setaffinity(0, {cpus[0]})                    # taskset: one core for the single-thread figure
+    try:
+        t0 = time.perf_counter()
+        run1(rowptr, col)
+        dt = time.perf_counter() - t0
+    finally:
+        os.sched_setaffinity(0, set(cpus))
+    out = {"value": ne / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+           "sample": f"oracle orc_trussness (support + bucket peel, 1 thread pinned to cpu {cpus[0]}, "
+                     f"{'-march=native' if native else 'portable build'}) on |V|={nv} |E|={ne} of the same generator: {dt:.1f} s",
+           "cpu_model": model, "host_cpus": len(cpus),
+           "full_graph_recorded": "the full C3 graph (|E|=100.1M) took 335 s = 3.0e5 edges/s on one thread of a GPU box "
+                                  "(profiles/r01_c3_full_parity.log)"}
+    if native:
+        nv2, ncl2 = CPU_SAMPLE_ALL[:2]
+        uv = komb_amd.gen_hug_edges(nv2, ncl2, alpha, seed)
+        rowptr, col = O.simplify(nv2, uv)
+        ne2 = len(col) // 2
+        t0 = time.perf_counter()
+        O.trussness_native(rowptr, col, len(cpus))
+        dt2 = time.perf_counter() - t0
+        out["all_cores"] = {"value": ne2 / dt2, "unit": "edges/s", "cores": len(cpus), "kind": "port",
+                            "sample": f"oracle orc_trussness_omp (parallel supports + level-synchronous parallel peel, OpenMP, "
+                                      f"{len(cpus)} threads) on |V|={nv2} |E|={ne2}: {dt2:.1f} s"}
+    return out
 
 
 def main():

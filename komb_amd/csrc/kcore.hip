@@ -35,12 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_core_init(const uint32_t *__restrict
         if (d == 0) { core[v] = 0; ++zeros; }
         else { core[v] = alive_marker((uint32_t)d); lmin = min(lmin, d); }
     }
-    zeros = wave_sum(zeros);
-    lmin = wave_min(lmin);
-    if (lane_id() == 0) {
-        if (zeros) atomicAdd(&init[0], zeros);
-        if (lmin != 0x7FFFFFFF) atomicMin((int32_t *)&init[1], lmin);
-    }
+    block_add_min(zeros, lmin, &init[0], (int32_t *)&init[1]);
 }
 
 struct CoreProblem {

@@ -472,8 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_total_u32(const uint32_t *__restrict
 {
     unsigned long long t = 0;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) t += v[e];
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane_id() == 0 && t) atomicAdd(total, t);
+    block_add_u64(t, total);
 }
 
 __global__ __launch_bounds__(kBlock) void k_back_cursors(const uint32_t *__restrict__ off, int64_t m, uint32_t *__restrict__ cursor)
@@ -495,8 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restric
         sum[e] = c;
         t += c;
     }
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane_id() == 0 && t) atomicAdd(total, t);               // 64-bit: the 32-bit slice offsets must not wrap
+    block_add_u64(t, total);                                    // 64-bit: the 32-bit slice offsets must not wrap
 }
 // capacity of edge (a->b)'s slice in the single-pass layout: |N(a) & N(b)| <= d(a) - 1, a being the
 // lower-(degree,id) endpoint.  total accumulates the 64-bit sum (the 32-bit offsets must not wrap).
@@ -509,8 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_caps(const int32_t *__restrict
         cap[e] = c;
         t += c;
     }
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane_id() == 0 && t) atomicAdd(total, t);
+    block_add_u64(t, total);
 }
 
 // Dense index from the bounded slices: 64 consecutive edges per wavefront, their entries flattened
@@ -575,12 +572,7 @@ __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t 
         if (s0 == 0) { stamp[e] = 0; truss[e] = 2; ++zeros; }       // round 0: gone before the first sub-round
         else { stamp[e] = alive_marker((uint32_t)s0); lmin = min(lmin, s0); }
     }
-    zeros = wave_sum(zeros);
-    lmin = wave_min(lmin);
-    if (lane_id() == 0) {
-        if (zeros) atomicAdd(&init[0], zeros);
-        if (lmin != 0x7FFFFFFF) atomicMin((int32_t *)&init[1], lmin);
-    }
+    block_add_min(zeros, lmin, &init[0], (int32_t *)&init[1]);
 }
 
 // ------------------------------------------------------------------ the peel

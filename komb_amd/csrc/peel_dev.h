@@ -91,6 +91,36 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
+// One atomic per WORKGROUP on a word every workgroup adds to (a word takes ~88 atomics per microsecond: a wavefront-level
+// add from a 4096-workgroup grid queues 16 000 of them).  All threads of the workgroup must call these.
+__device__ __forceinline__ void block_add_u64(unsigned long long v, unsigned long long *dst)
+{
+    __shared__ unsigned long long sh_blk64[16];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63) >> 6);
+    __syncthreads();
+    if (lane_id() == 0) sh_blk64[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < nw; ++i) t += sh_blk64[i]; if (t) atomicAdd(dst, t); }
+}
+__device__ __forceinline__ void block_add_min(uint32_t add, int32_t mn, uint32_t *dst_add, int32_t *dst_min)
+{
+    __shared__ uint32_t sh_blk_a[16];
+    __shared__ int32_t sh_blk_m[16];
+    add = wave_sum(add);
+    mn = wave_min(mn);
+    const int w = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63) >> 6);
+    __syncthreads();
+    if (lane_id() == 0) { sh_blk_a[w] = add; sh_blk_m[w] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0; int32_t m = 0x7FFFFFFF;
+        for (int i = 0; i < nw; ++i) { a += sh_blk_a[i]; m = min(m, sh_blk_m[i]); }
+        if (a) atomicAdd(dst_add, a);
+        if (m != 0x7FFFFFFF) atomicMin(dst_min, m);
+    }
+}
+
 enum : uint8_t { SC_NONE = 0, SC_LIGHT = 1, SC_HEAVY = 2, SC_SURVIVOR = 4 };   // SCAN pass A -> pass B
 
 struct PeelQueues {

@@ -350,6 +350,85 @@ int32_t orc_trussness(int64_t nv, const int64_t *rowptr, const int32_t *col,
     return mx;
 }
 
+/* ------------------------------------------------- a6, all-cores variant
+ * The same trussness with every host core: supports by a parallel loop over the
+ * edges, then a level-synchronous parallel peel in the manner of Kabir & Madduri's
+ * PKT (2017): level l's edges form the current set; every thread takes edges of
+ * the set, and a triangle whose other two edges are both unprocessed loses one
+ * support on each edge that is above the level -- on one edge only, by the smaller
+ * edge id, when the other one is in the current set too; an edge that lands on the
+ * level joins the next set.  Trussness is unique, so the values equal
+ * orc_trussness's (tests/test_oracle.py).  This is NOT how the reference runs
+ * (igraph is single-threaded, src/graph.cpp:508 is called from one thread): it
+ * is the "fairer CPU ceiling" of SURVEY section 8(d), reported next to the
+ * single-thread figure.  Built only with OpenMP (oracle/Makefile target native). */
+#ifdef _OPENMP
+#include <omp.h>
+struct pkt_ctx { int32_t *S; const uint8_t *processed; const uint8_t *in_curr; int32_t *next; int64_t *next_n; uint8_t *in_next; int32_t e, l; };
+static inline void pkt_dec(struct pkt_ctx *p, int32_t x)
+{
+    int32_t old = __atomic_fetch_sub(&p->S[x], 1, __ATOMIC_RELAXED);
+    if (old == p->l + 1) { int64_t i = __atomic_fetch_add(p->next_n, 1, __ATOMIC_RELAXED); p->next[i] = x; p->in_next[x] = 1; }
+    else if (old <= p->l) __atomic_fetch_add(&p->S[x], 1, __ATOMIC_RELAXED);       /* it was on the level already */
+}
+static void pkt_cb(void *c, int32_t e1, int32_t e2)
+{
+    struct pkt_ctx *p = (struct pkt_ctx *)c;
+    if (p->processed[e1] || p->processed[e2]) return;
+    const int32_t s1 = __atomic_load_n(&p->S[e1], __ATOMIC_RELAXED), s2 = __atomic_load_n(&p->S[e2], __ATOMIC_RELAXED);
+    if (s1 > p->l && s2 > p->l) { pkt_dec(p, e1); pkt_dec(p, e2); }
+    else if (s1 > p->l) { if (!p->in_curr[e2] || p->e < e2) pkt_dec(p, e1); }
+    else if (s2 > p->l) { if (!p->in_curr[e1] || p->e < e1) pkt_dec(p, e2); }
+}
+int32_t orc_trussness_omp(int64_t nv, const int64_t *rowptr, const int32_t *col, int32_t *truss, int nthreads)
+{
+    int64_t ne = rowptr[nv] / 2;
+    if (ne == 0) return 0;
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    int64_t *ustart = (int64_t *)malloc((size_t)(nv + 1) * sizeof(int64_t));
+    int64_t *ebase = (int64_t *)malloc((size_t)(nv + 1) * sizeof(int64_t));
+    upper_index(nv, rowptr, col, ustart, ebase);
+    int32_t *eid = slot_edge_ids(nv, rowptr, col, ustart, ebase);
+    int32_t *eu = (int32_t *)malloc((size_t)ne * sizeof(int32_t));
+    int32_t *ev = (int32_t *)malloc((size_t)ne * sizeof(int32_t));
+    orc_edge_list(nv, rowptr, col, eu, ev);
+    int32_t *S = (int32_t *)malloc((size_t)ne * sizeof(int32_t));
+    uint8_t *processed = (uint8_t *)calloc((size_t)ne, 1), *in_curr = (uint8_t *)calloc((size_t)ne, 1), *in_next = (uint8_t *)calloc((size_t)ne, 1);
+    int32_t *curr = (int32_t *)malloc((size_t)ne * sizeof(int32_t)), *next = (int32_t *)malloc((size_t)ne * sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t e = 0; e < ne; ++e) {
+        struct cnt_ctx c = {0};
+        for_common(rowptr, col, eid, eu[e], ev[e], cnt_cb, &c);
+        S[e] = (int32_t)c.n;
+    }
+    int64_t todo = ne;
+    int32_t mx = 0;
+    for (int32_t l = 0; todo > 0; ++l) {
+        int64_t curr_n = 0;
+#pragma omp parallel for schedule(static)
+        for (int64_t e = 0; e < ne; ++e)
+            if (!processed[e] && S[e] == l) { int64_t i = __atomic_fetch_add(&curr_n, 1, __ATOMIC_RELAXED); curr[i] = (int32_t)e; in_curr[e] = 1; }
+        while (curr_n > 0) {
+            todo -= curr_n;
+            mx = l + 2;
+            int64_t next_n = 0;
+#pragma omp parallel for schedule(dynamic, 64)
+            for (int64_t i = 0; i < curr_n; ++i) {
+                struct pkt_ctx p = { S, processed, in_curr, next, &next_n, in_next, curr[i], l };
+                if (l > 0) for_common(rowptr, col, eid, eu[p.e], ev[p.e], pkt_cb, &p);
+            }
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < curr_n; ++i) { const int32_t e = curr[i]; processed[e] = 1; in_curr[e] = 0; truss[e] = l + 2; }
+            int32_t *t = curr; curr = next; next = t;
+            uint8_t *tf = in_curr; in_curr = in_next; in_next = tf;
+            curr_n = next_n;
+        }
+    }
+    free(ustart); free(ebase); free(eid); free(eu); free(ev); free(S); free(processed); free(in_curr); free(in_next); free(curr); free(next);
+    return mx;
+}
+#endif
+
 /* ------------------------------------------------------ a10 fractionalRank
  * Reference: CoreA::fractionalRank, src/CoreA.h:142-187.  Scores truncated to
  * int (:149), sorted descending (:152), uniqued (:154); then for every unique

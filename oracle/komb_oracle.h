@@ -90,6 +90,11 @@ void orc_corea_scores(const int32_t *degree, const int32_t *coreness, int64_t n,
 /* a12  HashIndexedMinHeap -- src/HashIndexedMinHeap.h:10-238 is exercised only
  * by the dead CombineCoreA::runMerge; no oracle entry point. */
 
+/* a6 with every host core (OpenMP builds only: oracle/Makefile target `native`): a level-synchronous parallel peel;
+ * the same values as orc_trussness.  nthreads <= 0: OpenMP's default. */
+int32_t orc_trussness_omp(int64_t nv, const int64_t *rowptr, const int32_t *col,
+                          int32_t *truss, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,42 @@ def lib():
     return _LIB
 
 
+_NATIVE = None
+
+
+def native_lib():
+    """liboracle built for THIS machine (-march=native, OpenMP): bench.py's CPU baseline.  None if it cannot be built."""
+    global _NATIVE
+    if _NATIVE is None:
+        path = os.path.join(_HERE, "_native", "liboracle_native.so")
+        try:
+            subprocess.run(["make", "-s", "-C", _HERE, "native"], check=True, stdout=subprocess.DEVNULL)
+            L = ctypes.CDLL(path)
+            for name in ("orc_trussness", "orc_trussness_omp"):
+                getattr(L, name).restype = ctypes.c_int32
+            L.orc_trussness.argtypes = [_i64, _i64p, _i32p, _i32p]
+            L.orc_trussness_omp.argtypes = [_i64, _i64p, _i32p, _i32p, ctypes.c_int]
+            _NATIVE = L
+        except (OSError, subprocess.CalledProcessError):
+            _NATIVE = False
+    return _NATIVE or None
+
+
+def trussness_native(rowptr, col, threads=1):
+    """orc_trussness (threads == 1) or orc_trussness_omp from the native build."""
+    L = native_lib()
+    if L is None:
+        raise RuntimeError("native oracle build unavailable")
+    nv = len(rowptr) - 1
+    ne = int(rowptr[nv]) // 2
+    t = np.zeros(max(ne, 1), dtype=np.int32)
+    if threads == 1:
+        L.orc_trussness(nv, rowptr, _colbuf(col), t)
+    else:
+        L.orc_trussness_omp(nv, rowptr, _colbuf(col), t, int(threads))
+    return t[:ne]
+
+
 def ref_corea_path():
     p = os.path.join(_HERE, "_ref", "corea_ref")
     return p if os.path.exists(p) else None

@@ -152,3 +152,27 @@ def test_truss_core_bound(O, built):
     assert np.all(tr >= 2) and np.all(tr <= sup + 2)
     assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
     assert sup.sum() == 3 * tri
+
+
+def test_all_cores_variant_matches(built):
+    """orc_trussness_omp (level-synchronous parallel peel, the all-cores CPU baseline of bench.py) gives the values of
+    the sequential restatement: goldens, random dense graphs, a power-law sample; 1, 3 and 8 threads."""
+    import json
+    import os
+    import numpy as np
+    import komb_amd
+    from oracle import oracle as O
+    if O.native_lib() is None:
+        pytest.skip("native oracle build unavailable")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "graphs.json")) as f:
+        golden = json.load(f)
+    cases = [(np.asarray(g["rowptr"], dtype=np.int64), np.asarray(g["col"], dtype=np.int32)) for g in golden if g["nv"]]
+    rng = np.random.default_rng(3)
+    for nv, ne in ((50, 700), (400, 9000)):
+        cases.append(O.simplify(nv, rng.integers(0, nv, (ne, 2)).astype(np.int64)))
+    cases.append(O.simplify(20000, komb_amd.gen_hug_edges(20000, 60000, 2.3, 4)))
+    for rowptr, col in cases:
+        want = O.trussness(rowptr, col)
+        for threads in (1, 3, 8):
+            assert np.array_equal(O.trussness_native(rowptr, col, threads), want)
