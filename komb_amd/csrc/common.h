@@ -13,7 +13,18 @@
 
 #include "komb_accel.h"
 
+#include <roctracer/roctx.h>
+
 namespace komb {
+
+// roctx range around a phase of the path (rocprofv3 --marker-trace shows them)
+struct Range {
+    explicit Range(const char *name) { (void)roctxRangePushA(name); }
+    ~Range() { (void)roctxRangePop(); }
+    void next(const char *name) { (void)roctxRangePop(); (void)roctxRangePushA(name); }   // one phase ends, the next begins
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
 
 constexpr int kBlock = 256;                 // 4 wave64 per workgroup
 constexpr int kWave = 64;

@@ -72,22 +72,16 @@ int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t 
         if (core[i] > maxc) maxc = core[i];
     }
     hipStream_t s = ctx->stream;
+    DevBufs bufs(ctx);                                   // scratch from the context's pool, returned on every exit
     int32_t *d_deg = nullptr, *d_core = nullptr; int64_t *d_k[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_i[4] = {nullptr, nullptr, nullptr, nullptr}; double *d_r[2] = {nullptr, nullptr};
-    auto cleanup = [&]() {
-        if (d_deg) (void)hipFree(d_deg); if (d_core) (void)hipFree(d_core);
-        for (auto p : d_k) if (p) (void)hipFree(p);
-        for (auto p : d_i) if (p) (void)hipFree(p);
-        for (auto p : d_r) if (p) (void)hipFree(p);
-    };
-    hipError_t e = hipMalloc(&d_deg, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_core, (size_t)n * 4);
-    for (int t = 0; t < 4 && e == hipSuccess; ++t) e = hipMalloc(&d_k[t], (size_t)n * 8);
-    for (int t = 0; t < 4 && e == hipSuccess; ++t) e = hipMalloc(&d_i[t], (size_t)n * 4);
-    for (int t = 0; t < 2 && e == hipSuccess; ++t) e = hipMalloc(&d_r[t], (size_t)n * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_deg, deg, (size_t)n * 4, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_core, core, (size_t)n * 4, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
+    KOMB_HIP(ctx, bufs.alloc(&d_deg, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&d_core, (size_t)n));
+    for (int t = 0; t < 4; ++t) KOMB_HIP(ctx, bufs.alloc(&d_k[t], (size_t)n));
+    for (int t = 0; t < 4; ++t) KOMB_HIP(ctx, bufs.alloc(&d_i[t], (size_t)n));
+    for (int t = 0; t < 2; ++t) KOMB_HIP(ctx, bufs.alloc(&d_r[t], (size_t)n));
+    KOMB_HIP(ctx, hipMemcpyAsync(d_deg, deg, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    KOMB_HIP(ctx, hipMemcpyAsync(d_core, core, (size_t)n * 4, hipMemcpyHostToDevice, s));
     int64_t g64 = (n + kBlock - 1) / kBlock;
     const int grid = (int)(g64 > 4096 ? 4096 : g64);
     ctx->timer.start(s);
@@ -100,12 +94,10 @@ int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t 
     }
     if (st == KOMB_OK) k_run_ranks<<<grid, kBlock, 0, s>>>(sk, si, n, d_r[1]);
     ctx->stats.ms_corea = ctx->timer.stop(s);
-    if (st != KOMB_OK) { cleanup(); return st; }
-    e = hipMemcpyAsync(rank_deg, d_r[0], (size_t)n * 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(rank_key, d_r[1], (size_t)n * 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    cleanup();
-    KOMB_HIP(ctx, e);
+    KOMB_TRY(st);
+    KOMB_HIP(ctx, hipMemcpyAsync(rank_deg, d_r[0], (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    KOMB_HIP(ctx, hipMemcpyAsync(rank_key, d_r[1], (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    KOMB_HIP(ctx, hipStreamSynchronize(s));
     return KOMB_OK;
 }
 

@@ -125,6 +125,7 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
     if (2 * n_raw > INT32_MAX)
         KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph_from_edges: %lld raw pairs exceed the 2^30 design limit", (long long)n_raw);
     hipStream_t s = ctx->stream;
+    Range r_all("komb_graph_from_edges");
     ctx->timer.start(s);
 
     KOMB_HIP(ctx, hipMalloc(&ctx->d_rowptr, (size_t)(nv + 1) * sizeof(uint32_t)));

@@ -197,6 +197,7 @@ int core_run(komb_ctx *ctx)
     stt.core_local_units = 0; stt.core_local_sweeps = 0; stt.core_local_items = 0; stt.ms_core_local = 0.0;
     if (nv == 0) { ctx->core_done = true; return KOMB_OK; }
 
+    Range r_all("komb_core_run");
     DevBufs bufs(ctx);
     const size_t heavy_cap = (size_t)(2 * ctx->ne) / 32 + 64;    // sum over units with > kLight items of ceil(items / kChunk) <= 3/128 of all items
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
@@ -255,6 +256,7 @@ int core_run(komb_ctx *ctx)
     // local finish: compact the live subgraph, sweep the h-index operator to its fixed point (local_dev.h)
     auto run_local = [&]() -> int {
         const PeelCtrl hc = ctx->h_ctrl[0];
+        Range r_local("core: local finish");
         hipEvent_t ev[2] = {nullptr, nullptr};
         for (auto &e : ev) KOMB_HIP(ctx, hipEventCreate(&e));
         (void)hipEventRecord(ev[0], s);

@@ -823,6 +823,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         ctx->t_ne = 0; ctx->truss_done = true;
         return KOMB_OK;
     }
+    Range r_all("komb_truss_run");
     DevBufs bufs(ctx);
     const int gv = grid_for(nv);
 
@@ -849,6 +850,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
 
     // ---- orientation: oriented CSR, internal edge id = oriented slot
+    Range phase("truss: orientation");
     int32_t *d_deg = nullptr; uint32_t *d_orow = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_deg, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_orow, (size_t)nv + 1));
@@ -862,6 +864,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
     KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank));
     st.ms_orient = ctx->timer.stop(s);
+    phase.next("truss: triangles + incidence index");
 
     // ---- triangle support + incidence index
     const int ge = grid_for(m);
@@ -984,6 +987,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     bufs.release(d_cnt); bufs.release(d_own);
 
     // ---- peel
+    phase.next("truss: peel");
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
     PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
     PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, getenv("KOMB_SCAN_SCALAR") ? 1 : 0};
@@ -1141,6 +1145,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc);
 
     // ---- canonical-order results with original vertex ids
+    phase.next("truss: canonical gather");
     uint32_t *d_ucnt = nullptr, *d_ebase = nullptr;
     ctx->timer.start(s);
     KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));

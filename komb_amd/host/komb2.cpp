@@ -50,11 +50,24 @@ namespace {
 using clk = std::chrono::steady_clock;
 double since(clk::time_point t0) { return std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count() / 1000000.0; }
 
+// The HIP context is created on a second thread beside the SAM parse.  A fatal exit on the main thread first waits for
+// that thread (and drops the context): exit() runs the static destructors, and the HIP runtime must not be torn down
+// under a thread that is still initialising it.
+std::future<komb_ctx *> *g_ctx_early = nullptr;
+[[noreturn]] void leave(int code)
+{
+    if (g_ctx_early && g_ctx_early->valid()) {
+        komb_ctx *c = g_ctx_early->get();
+        if (c) komb_destroy(c);
+    }
+    exit(code);
+}
+
 [[noreturn]] void file_not_found(const std::string &path)
 {
     // src/graph.cpp:58-61
     fprintf(stderr, "File %s could not be opened. Exiting...\n", path.c_str());
-    exit(EXIT_FAILURE);
+    leave(EXIT_FAILURE);
 }
 
 [[noreturn]] void parse_error(const char *prog, const std::string &what)
@@ -155,7 +168,7 @@ struct Mapped {
             size_t got = 0;
             while (got < size) {
                 ssize_t r = ::read(fd, &fallback[got], size - got);
-                if (r <= 0) { fprintf(stderr, "Encountered error while reading %s\n", path.c_str()); exit(EXIT_FAILURE); }   // src/graph.cpp:188-192
+                if (r <= 0) { fprintf(stderr, "Encountered error while reading %s\n", path.c_str()); leave(EXIT_FAILURE); }   // src/graph.cpp:188-192
                 got += (size_t)r;
             }
             data = fallback.data();
@@ -481,7 +494,7 @@ void write_rows(FILE *fp, int64_t n, int threads, RowFn &&row)
 [[noreturn]] void die_accel(komb_ctx *ctx, const char *what, int rc)
 {
     fprintf(stderr, "komb2: %s failed (%d): %s\n", what, rc, ctx ? komb_last_error(ctx) : "no context");
-    exit(EXIT_FAILURE);
+    leave(EXIT_FAILURE);
 }
 
 bool env_on(const char *name)
@@ -630,6 +643,7 @@ int main(int argc, const char **argv)
     komb_opts opts{};
     opts.device = getenv("KOMB_DEVICE") ? atoi(getenv("KOMB_DEVICE")) : 0;
     std::future<komb_ctx *> ctx_early;
+    g_ctx_early = &ctx_early;
     for (const std::string *path : {&args.input, &args.input2})          // fail on a missing input before a second thread exists
         if (access(path->c_str(), R_OK) != 0) file_not_found(*path);
     if (!env_on("KOMB_STOP_AFTER_EDGES")) ctx_early = std::async(std::launch::async, [&opts]() { return komb_create(&opts); });

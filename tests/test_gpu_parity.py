@@ -369,6 +369,45 @@ def test_full_size_c3_known_answer(K, O):
         assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
         assert hashlib.sha256(core.tobytes()).hexdigest()[:16] == "120d47bf172d8b8f"
         assert hashlib.sha256(tr.tobytes()).hexdigest()[:16] == "5970a467914854ea"
+        # Independent of the recorded hash: (1) every truss class from 7 up, exactly.  The edges with trussness >= t ARE the
+        # t-truss, and every higher truss lies inside it, so the oracle run on that subgraph alone (340k edges, all the levels
+        # the peel's finish computes) must reproduce the GPU's values edge for edge.
+        sel = tr >= 7
+        vs = np.unique(np.concatenate([eu[sel], ev[sel]]))
+        remap = -np.ones(nv, np.int64); remap[vs] = np.arange(len(vs))
+        s_rowptr, s_col = O.simplify(len(vs), np.stack([remap[eu[sel]], remap[ev[sel]]], axis=1))
+        s_eu, s_ev = O.edge_list(s_rowptr, s_col)
+        assert np.array_equal(vs[s_eu], eu[sel]) and np.array_equal(vs[s_ev], ev[sel])      # same canonical order
+        assert np.array_equal(O.trussness(s_rowptr, s_col), tr[sel])
+        assert len(np.unique(tr[sel])) >= 20
+        # (2) 2-hop neighbourhoods of 20 random vertices (capped at 30k vertices): in the induced subgraph the edges at the
+        # centre keep ALL their triangles, so their supports equal the global ones; every other support and every trussness
+        # can only be smaller (monotone under taking subgraphs).
+        rowptr, col = a.get_csr()
+        rng = np.random.default_rng(77)
+        key = eu.astype(np.int64) * nv + ev
+        checked = 0
+        for c in rng.integers(0, nv, 60):
+            n1 = col[rowptr[c]:rowptr[c + 1]]
+            if len(n1) == 0 or len(n1) > 300:
+                continue
+            n2 = np.unique(np.concatenate([col[rowptr[u]:rowptr[u + 1]] for u in n1] + [n1, [c]]))
+            if len(n2) > 30000:
+                continue
+            mask = np.zeros(nv, np.uint8); mask[n2] = 1
+            srp, scol, inv = O.induced_subgraph(rowptr, col, mask)
+            ssup, _ = O.support(srp, scol)
+            str_ = O.trussness(srp, scol)
+            su, sv = O.edge_list(srp, scol)
+            pos = np.searchsorted(key, inv[su].astype(np.int64) * nv + inv[sv])
+            assert np.array_equal(key[pos], inv[su].astype(np.int64) * nv + inv[sv])
+            assert np.all(ssup <= sup[pos]) and np.all(str_ <= tr[pos])
+            centre = (inv[su] == c) | (inv[sv] == c)
+            assert centre.sum() == len(n1) and np.array_equal(ssup[centre], sup[pos][centre])
+            checked += 1
+            if checked == 20:
+                break
+        assert checked >= 10
 
 
 def test_lds_tail_agrees_with_general_engine(K, O, monkeypatch):

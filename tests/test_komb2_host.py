@@ -9,7 +9,7 @@ import pytest
 import samgraph
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KOMB2 = os.path.join(ROOT, "komb_amd", "bin", "komb2")
+KOMB2 = os.environ.get("KOMB2_BIN", os.path.join(ROOT, "komb_amd", "bin", "komb2"))   # `make -C komb_amd/csrc asan` points this at the sanitizer build
 
 
 @pytest.fixture(scope="module")
