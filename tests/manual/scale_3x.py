@@ -1,13 +1,17 @@
-"""Scale smoke test beyond the bench configuration: |V| = 30M, |E| ~ 300M (3x C3).  Checks the size-independent
-properties the suite checks at C2 (support >= trussness - 2 inside every k-truss, coreness bound) and prints times."""
+"""Scale / stress run beyond the bench configuration.  Default: |V| = 30M, |E| ~ 300M (3x C3); arguments
+`nv n_cliques alpha` select another shape (SURVEY 8(d)'s stress variant: 10000000 27500000 2.2).  Checks the
+size-independent properties the suite checks at C2 (support >= trussness - 2 inside every k-truss, coreness bound)
+and prints times."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import komb_amd
 
-nv, nc = 30_000_000, 72_750_000
+nv, nc, alpha = 30_000_000, 72_750_000, 2.6
+if len(sys.argv) > 3:
+    nv, nc, alpha = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 t0 = time.time()
-uv = komb_amd.gen_hug_edges(nv, nc, 2.6, 42)
+uv = komb_amd.gen_hug_edges(nv, nc, alpha, 42)
 print(f"generated {len(uv) // 2} raw pairs in {time.time() - t0:.1f} s", flush=True)
 with komb_amd.KombAccel() as a:
     t0 = time.time(); a.from_edges(nv, uv); del uv
@@ -19,7 +23,7 @@ with komb_amd.KombAccel() as a:
     for i in range(2):
         a.truss_run()
         st = a.stats()
-        print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items() if k.startswith('ms_') or k.startswith('truss') or k in ('triangles', 'max_trussness')}, flush=True)
+        print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items() if k.startswith('ms_') or k.startswith('truss') or k in ('triangles', 'max_trussness', 'max_degree')}, flush=True)
     eu, ev, tr, sup = a.run_truss(with_support=True)
     assert sup.sum() == 3 * st["triangles"]
     assert np.all(tr >= 2) and np.all(tr <= sup + 2)
