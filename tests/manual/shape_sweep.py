@@ -19,17 +19,22 @@ cases.append(("K_250 inside 1M sparse", 1_000_000, np.concatenate([np.stack(iu, 
 kk = 180
 iu = np.triu_indices(kk, 1)
 cases.append(("40 x K_180 disjoint", 40 * kk, np.concatenate([np.stack(iu, axis=1) + i * kk for i in range(40)]), True))
+modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["default"]     # KOMB_FINISH values to compare
 with komb_amd.KombAccel() as a:
     for name, nv, uv, check in cases:
-        uv = np.ascontiguousarray(uv, dtype=np.int64)
-        a.from_edges(nv, uv)
+      uv = np.ascontiguousarray(uv, dtype=np.int64)
+      a.from_edges(nv, uv)
+      for mode in modes:
+        if mode == "default": os.environ.pop("KOMB_FINISH", None)
+        else: os.environ["KOMB_FINISH"] = mode
         a.truss_run(); a.core_run()                     # warm the pool
         a.truss_run(); st = a.stats()
         a.core_run(); sc = a.stats()
         tot = st["ms_orient"] + st["ms_support"] + st["ms_peel"] + st["ms_gather"]
-        line = (f"{name:34s} |E| {st['ne']:9d} T {st['triangles']:10d} tmax {st['max_trussness']:4d}  truss {tot:7.2f} ms "
-                f"(tri {st['ms_tri_fill'] + st['ms_tri_count']:.2f} peel {st['ms_peel']:.2f} tail {st['ms_tail']:.2f} x{st['truss_tail_runs']})"
-                f"  core {sc['ms_core']:.2f} ms kmax {sc['max_coreness']}")
+        line = (f"{name:34s} [{mode:7s}] |E| {st['ne']:9d} T {st['triangles']:10d} tmax {st['max_trussness']:4d}  truss {tot:7.2f} ms "
+                f"(tri {st['ms_tri_fill'] + st['ms_tri_count']:.2f} peel {st['ms_peel']:.2f} tail {st['ms_tail']:.2f} x{st['truss_tail_runs']} "
+                f"local {st['ms_truss_local']:.2f}/{st['truss_local_sweeps']})"
+                f"  core {sc['ms_core']:.2f} ms (local {sc['ms_core_local']:.2f}/{sc['core_local_sweeps']}) kmax {sc['max_coreness']}")
         if check:
             rowptr, col = a.get_csr()
             _, _, tr = a.truss_fetch()
