@@ -219,8 +219,14 @@ def main():
     if world > 1:
         from komb_amd import distributed as kd
 
+    # Same graph on N ranks: what can be sharded profitably is the support-counting enumeration (the
+    # exchange is one all-reduce of the |E|+1 support words, ~3 ms at C3; the sharded count saves 12.3 ms x (1 - 1/N) but
+    # the exact two-pass index it needs costs ~0.2 ms more than the single pass) -- a gain from N = 8 on, a loss below.
+    # So: N >= 8 shards the counting, 1 < N < 8 runs replicas (every rank the whole single-GPU path, no exchange).
+    shard = world >= int(os.environ.get("KOMB_SHARD_FROM", "8")) and not args.batch
+
     def step():
-        if world > 1 and not args.batch:
+        if shard:
             kd.truss_run_sharded(acc, group=data_group)   # support phase sharded by vertex range + all-reduce
         else:
             acc.truss_run()
@@ -324,8 +330,10 @@ def main():
                                        "sweeps": st["truss_local_sweeps"]},
                        "parallelism": "single" if world == 1 else
                        (f"batch: {world} independent graphs (seed + rank), one per GPU, no exchange on the data path" if args.batch else
-                        f"same graph on {world} ranks: triangle-support counting sharded by source-vertex range + one all-reduce of the "
-                        f"per-edge support vector ({exchange}); incidence fill, peel and gather replicated on every rank")},
+                        (f"same graph on {world} ranks: triangle-support counting sharded by source-vertex range + one all-reduce of the "
+                         f"per-edge support vector ({exchange}); incidence fill, peel and gather replicated on every rank") if shard else
+                        f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange (sharding the "
+                        f"support counting pays from 8 ranks on)")},
             "phases_ms": phase,
             "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
                       "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],
