@@ -86,7 +86,8 @@ struct LocalCtrl {
     uint32_t levels;         // distinct final values (k_local_levels)
     uint32_t evals;          // unit evaluations, all sweeps
     uint32_t n_light, n_heavy;   // numbering counters (k_local_number)
-    uint32_t pad[5];
+    uint32_t n_giant;        // heavy units with more than kMedMax items
+    uint32_t pad[4];
 };
 static_assert(sizeof(LocalCtrl) == 64, "LocalCtrl layout");
 

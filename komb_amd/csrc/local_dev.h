@@ -38,9 +38,10 @@ constexpr int kLocWaves = kLocBlock / kWave;
 constexpr int kLocHB = 4096;                   // histogram bins of the heavy path
 constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix search
 constexpr int kCntWays = 8;                    // per-sweep counters are spread over this many 128-byte lines
-constexpr int kCntWords = 4 * kCntWays * 32;   // 3 ring slots of change counters + 1 of evaluation counters
+constexpr int kCntWords = (4 * kCntWays + 3) * 32;   // 3 ring slots of change counters + 1 of evaluation counters, 3 queue heads
 constexpr int kCntTimerWords = 6 * 12 * 2;     // -DKOMB_LOCAL_TIMERS: 6 sweeps x 12 64-bit stopwatch sums behind the counters
 constexpr int kHvU = 8;                        // items per thread per trip on the workgroup path (independent load chains)
+constexpr uint32_t kKeyBins = 4096;            // histogram of the live keys at hand-over (bound on the largest level)
 constexpr uint32_t kMedMax = 2048;             // heavy units up to this many items are evaluated by one wavefront (values staged in LDS)
 constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
 
@@ -53,6 +54,9 @@ struct LocalGraph {                            // the compacted remainder
     int32_t *gid;            // [n] unit id of the general engine
     uint32_t *len;           // [n+1] live key at hand-over = compact slice length (scan input)
     uint32_t *cur;           // [n] fill cursors of the collect pass
+    uint32_t *giant;         // [ng] ids of the heavy units with more than kMedMax items (taken from a shared queue, whole workgroup each)
+    uint32_t ng;
+    uint32_t *khist;         // [kKeyBins] how many units have live key k (the last bin: k >= kKeyBins - 1)
 };
 
 // ---- 1. numbering.  `list` (or all `units` when null) holds the candidates; live = alive marker in `marker`;
@@ -67,6 +71,8 @@ static __global__ __launch_bounds__(kNumBlock) void k_local_number(const int32_t
     // atomic of its own queues 10^5..10^6 of them on two words
     __shared__ uint32_t sh_cnt[kNumBlock / kWave][2];
     __shared__ uint32_t sh_base[2];
+    __shared__ uint32_t sh_kh[kKeyBins];
+    for (uint32_t i = threadIdx.x; i < kKeyBins; i += kNumBlock) sh_kh[i] = 0u;
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     for (uint32_t i0 = blockIdx.x * kNumBlock; i0 < n_in; i0 += gridDim.x * kNumBlock) {
         const uint32_t i = i0 + threadIdx.x;
@@ -98,7 +104,19 @@ static __global__ __launch_bounds__(kNumBlock) void k_local_number(const int32_t
         if (id >= n_live) { atomicAdd(&ctrl->bad, 1u); continue; }      // more live units than the control block said
         num[u] = (int32_t)id;
         g.gid[id] = u; g.len[id] = (uint32_t)k; g.val[id] = k; g.mark[1][id] = 1; g.mark[0][id] = 0; g.cur[id] = 0u;
+        atomicAdd(&sh_kh[min((uint32_t)k, kKeyBins - 1u)], 1u);
+        if ((uint32_t)k > kMedMax) g.giant[atomicAdd(&ctrl->n_giant, 1u)] = id;          // a few hundred at most
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kKeyBins; i += kNumBlock) if (sh_kh[i]) atomicAdd(&g.khist[i], sh_kh[i]);
+}
+
+// Every level of the remainder is <= K, the h-index of its live keys (a level-t core / truss holds more than t units of key
+// >= t): the values start at min(key, K), so a hub's first evaluations do not have to refine a range of 10^5.
+static __global__ __launch_bounds__(kBlock) void k_local_clamp(LocalGraph g, int32_t K)
+{
+    for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < g.n; id += gridDim.x * kBlock)
+        if (g.val[id] > K) g.val[id] = K;
 }
 
 // Collect pass: position of this lane's entry in the compact slice of unit `id`.  Called by the lanes that have a live
@@ -185,8 +203,8 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     __shared__ uint32_t sh_hist[kLocHB];
     __shared__ uint32_t sh_part[kLocWaves];
     __shared__ unsigned long long sh_best;
-    __shared__ uint32_t sh_q[kLocBlock], sh_m[kLocBlock];
-    __shared__ uint32_t sh_qn, sh_mn;
+    __shared__ uint32_t sh_m[kLocBlock];
+    __shared__ uint32_t sh_mn;
     __shared__ uint16_t sh_med[kLocWaves][kMedMax];
     __shared__ int32_t sh_i[2];
     __shared__ uint32_t sh_end[kLocWaves][kWave];
@@ -205,6 +223,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
         return;
     }
     if (blockIdx.x == 0 && tid < (uint32_t)kCntWays) cnt[(((k + 1) % 3) * kCntWays + tid) * 32] = 0u;   // nobody reads or adds to that slot in this launch
+    if (blockIdx.x == 0 && tid == 0) cnt[(4 * kCntWays + ((k + 1) % 3)) * 32] = 0u;                    // next sweep's queue of the longest units
     uint32_t n_changed = 0, n_evals = 0;                 // meaningful in thread 0 (heavy) / lane 0 of each wave (light)
 #ifdef KOMB_LOCAL_TIMERS
     // per-wave stopwatch (100 MHz): [0] heavy-mark scan, [1] medium units, [2] workgroup units, [3] group setup (marks,
@@ -218,126 +237,22 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
 #define KOMB_LT(i) do { } while (0)
 #endif
 
-    // ---- heavy units: workgroup b owns the heavy ids b, b + G, b + 2G, ...; its threads look at their marks
-    // side by side and queue the marked ones in LDS.  The longest ones (> kMedMax items) are evaluated first, by the whole
-    // workgroup, one at a time: a plain count of the items >= cap (most re-evaluations end there), then an LDS histogram of
-    // the item values whose range is refined until it is exact.  "Medium" units are evaluated by one wavefront each, their
-    // item values staged once in the wavefront's LDS buffer (16 bits each: values <= kMedMax); no workgroup barrier
-    // follows, so a wavefront without medium units goes straight on to the light ones
+    // ---- heavy units of medium length (<= kMedMax items): workgroup b owns the heavy ids b, b + G, b + 2G, ...; its threads
+    // look at their marks side by side and queue the marked medium ones in LDS; one wavefront evaluates each, the item
+    // values staged once in the wavefront's LDS buffer (16 bits each: values <= kMedMax).  No workgroup barrier follows, so
+    // a wavefront without medium units goes straight on to the light ones.  (The longest units come last, below.)
     const int32_t *mark_cur = g.mark[k & 1];
     int32_t *mark_next = g.mark[(k + 1) & 1];
     for (uint32_t base = blockIdx.x; base < g.nh; base += gridDim.x * kLocBlock) {
         __syncthreads();
-        if (tid == 0) { sh_qn = 0u; sh_mn = 0u; }
+        if (tid == 0) sh_mn = 0u;
         __syncthreads();
         {
             const uint64_t hu64 = (uint64_t)base + (uint64_t)tid * gridDim.x;
-            if (hu64 < g.nh && mark_cur[hu64] == k) {
-                if (g.off[hu64 + 1] - g.off[hu64] <= kMedMax) sh_m[atomicAdd(&sh_mn, 1u)] = (uint32_t)hu64;
-                else sh_q[atomicAdd(&sh_qn, 1u)] = (uint32_t)hu64;
-            }
+            if (hu64 < g.nh && mark_cur[hu64] == k && g.off[hu64 + 1] - g.off[hu64] <= kMedMax) sh_m[atomicAdd(&sh_mn, 1u)] = (uint32_t)hu64;
         }
         __syncthreads();
         KOMB_LT(0);
-        const uint32_t nq = sh_qn;
-        for (uint32_t qi = 0; qi < nq; ++qi) {
-            const uint32_t hu = sh_q[qi];
-            const int32_t cap = g.val[hu];                       // written by this workgroup only
-            if (cap <= 0) continue;
-            const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
-            int32_t lo = 0, hi = cap - 1, H = cap;
-            {
-                uint32_t ge = 0;
-                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {      // kHvU independent load chains in flight
-                    int32_t r[kHvU];
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? local_value(p, beg + j, g.val) : -1; }
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) ge += r[x] >= cap ? 1u : 0u;
-                }
-                ge = wave_sum(ge);
-                __syncthreads();
-                if (lane == 0) sh_part[w] = ge;
-                __syncthreads();
-                uint32_t c0 = 0;
-#pragma unroll
-                for (int i = 0; i < kLocWaves; ++i) c0 += sh_part[i];
-                if (tid == 0) ++n_evals;
-                if (c0 >= (uint32_t)cap) continue;               // still has cap items >= cap: unchanged
-                lo = (int32_t)c0;                                // the c0 items >= cap are >= c0 as well
-            }
-            for (;;) {
-                // histogram of the values in [lo, hi], `above` = values > hi, all from ONE pass over the items
-                const uint32_t width = (uint32_t)(hi - lo) + 1u;
-                int sh = 0;
-                while (((width - 1u) >> sh) >= (uint32_t)kLocHB) ++sh;
-                const uint32_t nb = ((width - 1u) >> sh) + 1u;
-                __syncthreads();
-                for (uint32_t i = tid; i < nb; i += kLocBlock) sh_hist[i] = 0u;
-                if (tid == 0) sh_best = 0ull;
-                __syncthreads();
-                uint32_t ab = 0;
-                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
-                    int32_t r[kHvU];
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? local_value(p, beg + j, g.val) : -1; }
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) {
-                        if (r[x] > hi) ++ab;
-                        else if (r[x] >= lo) atomicAdd(&sh_hist[(uint32_t)(r[x] - lo) >> sh], 1u);
-                    }
-                }
-                ab = wave_sum(ab);
-                if (lane == 0) sh_part[w] = ab;
-                __syncthreads();
-                uint32_t above = 0;
-#pragma unroll
-                for (int i = 0; i < kLocWaves; ++i) above += sh_part[i];
-                // largest bin b with count(values >= lo + (b << sh)) >= lo + (b << sh); thread t owns kLocBins consecutive bins
-                uint32_t h4[kLocBins], mine = 0;
-#pragma unroll
-                for (int i = 0; i < kLocBins; ++i) { const uint32_t bi = kLocBins * tid + (uint32_t)i; h4[i] = bi < nb ? sh_hist[bi] : 0u; mine += h4[i]; }
-                uint32_t suf = mine;                                         // suffix sum over the lanes above, inclusive
-                for (int o = 1; o < kWave; o <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)suf, o); if (lane + o < kWave) suf += t; }
-                __syncthreads();                                             // sh_part is reused
-                if (lane == 0) sh_part[w] = suf;                             // wave total
-                __syncthreads();
-                uint32_t run = above + suf - mine;                           // values in the bins above this thread's
-                for (int i = w + 1; i < kLocWaves; ++i) run += sh_part[i];
-                unsigned long long best = 0ull;
-#pragma unroll
-                for (int i = kLocBins - 1; i >= 0; --i) {
-                    const uint32_t b = kLocBins * tid + (uint32_t)i;
-                    run += h4[i];                                            // count(values >= start of bin b)
-                    if (b < nb && best == 0ull && (unsigned long long)run >= (unsigned long long)lo + ((unsigned long long)b << sh))
-                        best = (unsigned long long)b + 1ull;
-                }
-                if (best) atomicMax(&sh_best, best);
-                __syncthreads();
-                const unsigned long long bb = sh_best;
-                if (bb == 0ull) {                                            // values dropped under the range while we looked
-                    if (lo == 0) { H = 0; break; }
-                    hi = lo - 1; lo = 0;
-                    continue;
-                }
-                const uint32_t b = (uint32_t)bb - 1u;
-                const int32_t nlo = lo + (int32_t)(b << sh);
-                const int32_t nhi = min(hi, nlo + (int32_t)((1u << sh) - 1u));
-                lo = nlo; hi = nhi;
-                if (sh == 0) { H = lo; break; }
-            }
-            if (H < cap) {
-                if (tid == 0) { g.val[hu] = H; ++n_changed; }
-                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
-                    LocalNotify<P> nt[kHvU];
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len); }
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) nt[x].store(mark_next, k);
-                }
-            }
-        }
-        KOMB_LT(2);
         // medium units: wavefront w takes queue entries w, w + 8, ...
         const uint32_t nm = sh_mn;
         uint16_t *vb = sh_med[w];
@@ -500,6 +415,121 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
 #endif
         }
     }
+    // ---- the longest units (> kMedMax items; g.giant lists them): whole workgroup each, taken from a queue all workgroups
+    // share, so whoever is done with its light and medium units takes the next one.  A plain count of the items >= cap
+    // first (most re-evaluations end there), then an LDS histogram of the item values whose range is refined until exact.
+    if (g.ng) {
+        uint32_t *gq = cnt + (4 * kCntWays + (k % 3)) * 32;
+        for (;;) {
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t i = atomicAdd(gq, 1u);
+                int32_t pick = -1;                                   // queue exhausted
+                if (i < g.ng) { const uint32_t id = g.giant[i]; pick = mark_cur[id] == k ? (int32_t)id : -2; }
+                sh_i[0] = pick;
+            }
+            __syncthreads();
+            const int32_t pick = sh_i[0];
+            if (pick == -1) break;
+            if (pick == -2) continue;
+            const uint32_t hu = (uint32_t)pick;
+            const int32_t cap = g.val[hu];                       // written by this workgroup only
+            if (cap <= 0) continue;
+            const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
+            int32_t lo = 0, hi = cap - 1, H = cap;
+            {
+                uint32_t ge = 0;
+                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {      // kHvU independent load chains in flight
+                    int32_t r[kHvU];
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? local_value(p, beg + j, g.val) : -1; }
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) ge += r[x] >= cap ? 1u : 0u;
+                }
+                ge = wave_sum(ge);
+                __syncthreads();
+                if (lane == 0) sh_part[w] = ge;
+                __syncthreads();
+                uint32_t c0 = 0;
+#pragma unroll
+                for (int i = 0; i < kLocWaves; ++i) c0 += sh_part[i];
+                if (tid == 0) ++n_evals;
+                if (c0 >= (uint32_t)cap) continue;               // still has cap items >= cap: unchanged
+                lo = (int32_t)c0;                                // the c0 items >= cap are >= c0 as well
+            }
+            for (;;) {
+                // histogram of the values in [lo, hi], `above` = values > hi, all from ONE pass over the items
+                const uint32_t width = (uint32_t)(hi - lo) + 1u;
+                int sh = 0;
+                while (((width - 1u) >> sh) >= (uint32_t)kLocHB) ++sh;
+                const uint32_t nb = ((width - 1u) >> sh) + 1u;
+                __syncthreads();
+                for (uint32_t i = tid; i < nb; i += kLocBlock) sh_hist[i] = 0u;
+                if (tid == 0) sh_best = 0ull;
+                __syncthreads();
+                uint32_t ab = 0;
+                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
+                    int32_t r[kHvU];
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < len ? local_value(p, beg + j, g.val) : -1; }
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) {
+                        if (r[x] > hi) ++ab;
+                        else if (r[x] >= lo) atomicAdd(&sh_hist[(uint32_t)(r[x] - lo) >> sh], 1u);
+                    }
+                }
+                ab = wave_sum(ab);
+                if (lane == 0) sh_part[w] = ab;
+                __syncthreads();
+                uint32_t above = 0;
+#pragma unroll
+                for (int i = 0; i < kLocWaves; ++i) above += sh_part[i];
+                // largest bin b with count(values >= lo + (b << sh)) >= lo + (b << sh); thread t owns kLocBins consecutive bins
+                uint32_t h4[kLocBins], mine = 0;
+#pragma unroll
+                for (int i = 0; i < kLocBins; ++i) { const uint32_t bi = kLocBins * tid + (uint32_t)i; h4[i] = bi < nb ? sh_hist[bi] : 0u; mine += h4[i]; }
+                uint32_t suf = mine;                                         // suffix sum over the lanes above, inclusive
+                for (int o = 1; o < kWave; o <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)suf, o); if (lane + o < kWave) suf += t; }
+                __syncthreads();                                             // sh_part is reused
+                if (lane == 0) sh_part[w] = suf;                             // wave total
+                __syncthreads();
+                uint32_t run = above + suf - mine;                           // values in the bins above this thread's
+                for (int i = w + 1; i < kLocWaves; ++i) run += sh_part[i];
+                unsigned long long best = 0ull;
+#pragma unroll
+                for (int i = kLocBins - 1; i >= 0; --i) {
+                    const uint32_t b = kLocBins * tid + (uint32_t)i;
+                    run += h4[i];                                            // count(values >= start of bin b)
+                    if (b < nb && best == 0ull && (unsigned long long)run >= (unsigned long long)lo + ((unsigned long long)b << sh))
+                        best = (unsigned long long)b + 1ull;
+                }
+                if (best) atomicMax(&sh_best, best);
+                __syncthreads();
+                const unsigned long long bb = sh_best;
+                if (bb == 0ull) {                                            // values dropped under the range while we looked
+                    if (lo == 0) { H = 0; break; }
+                    hi = lo - 1; lo = 0;
+                    continue;
+                }
+                const uint32_t b = (uint32_t)bb - 1u;
+                const int32_t nlo = lo + (int32_t)(b << sh);
+                const int32_t nhi = min(hi, nlo + (int32_t)((1u << sh) - 1u));
+                lo = nlo; hi = nhi;
+                if (sh == 0) { H = lo; break; }
+            }
+            if (H < cap) {
+                if (tid == 0) { g.val[hu] = H; ++n_changed; }
+                for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
+                    LocalNotify<P> nt[kHvU];
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len); }
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) nt[x].store(mark_next, k);
+                }
+            }
+        }
+    }
+    KOMB_LT(2);
 #ifdef KOMB_LOCAL_TIMERS
     if (lane == 0 && (k == 1 || k == 4 || k == 8 || k == 12 || k == 16 || k == 20)) {
         const int slot = k == 1 ? 0 : k / 4;
@@ -653,6 +683,9 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, bufs.alloc(&g.mark[1], (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.gid, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.cur, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.giant, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.khist, (size_t)kKeyBins));
+    KOMB_HIP(ctx, hipMemsetAsync(g.khist, 0, kKeyBins * sizeof(uint32_t), s));
     KOMB_HIP(ctx, bufs.alloc(&d_lctrl, 1));
     uint32_t *d_cnt = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)kCntWords + kCntTimerWords));
@@ -662,7 +695,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, hipMemsetAsync(d_lctrl, 0, sizeof(LocalCtrl), s));
     KOMB_HIP(ctx, hipMemsetAsync(g.len + n, 0, sizeof(uint32_t), s));
     KOMB_HIP(ctx, hipMemsetAsync(d_present, 0, present_words * sizeof(uint32_t), s));
-    g.n = n; g.nh = 0;
+    g.n = n; g.nh = 0; g.ng = 0;
     int64_t gb = ((int64_t)n_in + kNumBlock - 1) / kNumBlock;
     k_local_number<<<(int)(gb < 1 ? 1 : (gb > 1024 ? 1024 : gb)), kNumBlock, 0, s>>>(list, n_in, n, marker, key, light_max, d_num, g, d_lctrl);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, g.len, g.off, (int64_t)n + 1));
@@ -673,6 +706,18 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     if (hl.bad || hl.n_heavy + hl.n_light != n)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u live units numbered, the peel counted %u", hl.n_heavy + hl.n_light, n);
     g.nh = hl.n_heavy;
+    g.ng = hl.n_giant;
+    // K = h-index of the live keys: no level of the remainder is above it, so no value needs to start above it
+    int32_t K = 0x7FFFFFFF;
+    {
+        std::vector<uint32_t> kh(kKeyBins);
+        KOMB_HIP(ctx, d2h(ctx, kh.data(), g.khist, kKeyBins * sizeof(uint32_t)));
+        uint64_t ge = 0;
+        for (int32_t k = (int32_t)kKeyBins - 1; k >= 0; --k) {
+            ge += kh[(size_t)k];
+            if (ge >= (uint64_t)k) { if (k < (int32_t)kKeyBins - 1) K = k; break; }     // the last bin is open-ended: no bound from it
+        }
+    }
     stamp(1);
     after_number(g);
     void *d_items = nullptr;
@@ -691,6 +736,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     int64_t gn = ((int64_t)n + kBlock - 1) / kBlock;
     const int grid_n = (int)(gn > 1024 ? 1024 : gn);
     k_local_check<<<grid_n, kBlock, 0, s>>>(g, d_lctrl);
+    if (K != 0x7FFFFFFF) k_local_clamp<<<grid_n, kBlock, 0, s>>>(g, K);
     stamp(2);
 
     int launches = 0;
@@ -704,8 +750,8 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
         float t[4] = {0, 0, 0, 0};
         for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
         for (auto &e : ev) (void)hipEventDestroy(e);
-        fprintf(stderr, "komb local finish: %u units (%u heavy), %u items; number+scan %.1f us, collect %.1f us, %d sweeps (%d launches, %u evaluations) %.1f us, scatter %.1f us\n",
-                n, g.nh, total, t[0] * 1e3f, t[1] * 1e3f, hl.iters, launches, hl.evals, t[2] * 1e3f, t[3] * 1e3f);
+        fprintf(stderr, "komb local finish: %u units (%u heavy, %u of them long; bound %d), %u items; number+scan %.1f us, collect %.1f us, %d sweeps (%d launches, %u evaluations) %.1f us, scatter %.1f us\n",
+                n, g.nh, g.ng, K == 0x7FFFFFFF ? -1 : K, total, t[0] * 1e3f, t[1] * 1e3f, hl.iters, launches, hl.evals, t[2] * 1e3f, t[3] * 1e3f);
     }
 #ifdef KOMB_LOCAL_TIMERS
     {
@@ -728,7 +774,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
         ls->sweeps = hl.iters; ls->launches = launches; ls->items = total; ls->evals = hl.evals;
     }
     bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
-    bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cnt); bufs.release(d_cctrl); bufs.release(d_present);
+    bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.giant); bufs.release(g.khist); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cnt); bufs.release(d_cctrl); bufs.release(d_present);
     return KOMB_OK;
 }
 

@@ -18,7 +18,7 @@ with komb_amd.KombAccel() as a:
     print(f"graph build {time.time() - t0:.2f} s", flush=True)
     deg, core = a.run_core()
     st = a.stats()
-    print(f"k-core {st['ms_core']:.1f} ms, max coreness {st['max_coreness']}, |E| = {st['ne']}", flush=True)
+    print(f"k-core {st['ms_core']:.1f} ms (local finish {st['ms_core_local']:.1f} ms, {st['core_local_units']} units, {st['core_local_sweeps']} sweeps), max coreness {st['max_coreness']}, |E| = {st['ne']}", flush=True)
     assert core.max() <= deg.max() and np.all(core <= deg)
     for i in range(2):
         a.truss_run()
