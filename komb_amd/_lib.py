@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkomb_accel.so")
+# KOMB_ACCEL_LIB selects another build of the same ABI (a tuning variant, a system-wide install)
+LIB_PATH = os.environ.get("KOMB_ACCEL_LIB") or os.path.join(_HERE, "lib", "libkomb_accel.so")
 
 KOMB_OK = 0
 KOMB_ERR_ARG, KOMB_ERR_DEVICE, KOMB_ERR_NOMEM, KOMB_ERR_LIMIT, KOMB_ERR_STATE = -1, -2, -3, -4, -5

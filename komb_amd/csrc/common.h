@@ -87,7 +87,8 @@ struct LocalCtrl {
     uint32_t evals;          // unit evaluations, all sweeps
     uint32_t n_light, n_heavy;   // numbering counters (k_local_number)
     uint32_t n_giant;        // heavy units with more than kMedMax items
-    uint32_t pad[4];
+    uint32_t n_chunk;        // chunks of kChunk items they are counted in
+    uint32_t pad[3];
 };
 static_assert(sizeof(LocalCtrl) == 64, "LocalCtrl layout");
 

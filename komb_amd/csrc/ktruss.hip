@@ -229,11 +229,23 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 //              the two ends meet precisely).
 // Tasks whose rows exceed the LDS budget fall back to global binary search and
 // global atomics for all three roles.
+#ifndef KOMB_TRI_CAP
+#define KOMB_TRI_CAP 512
+#endif
+#ifndef KOMB_TRI_EU
+#define KOMB_TRI_EU 4
+#endif
+#ifndef KOMB_TRI_U
+#define KOMB_TRI_U 2
+#endif
+#ifndef KOMB_TRI_CAND
+#define KOMB_TRI_CAND 192
+#endif
 constexpr int kTriV = 16;
-constexpr int kTriCap = 512;
-constexpr int kTriU = 2;                       // probe items per lane per trip
+constexpr int kTriCap = KOMB_TRI_CAP;
+constexpr int kTriU = KOMB_TRI_U;              // probe items per lane per trip
 constexpr int kTriBuf = 128;                   // parked triangles per wave (handled once >= 64 are waiting)
-constexpr int kTriCand = 192;                  // parked lookup candidates per wave (searched once >= 64 are waiting)
+constexpr int kTriCand = KOMB_TRI_CAND;        // parked lookup candidates per wave (searched once >= 64 are waiting)
 constexpr int kTriWaves = kBlock / kWave;
 
 enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
@@ -241,7 +253,7 @@ enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
 // BACK: other_or_cursor[x] starts at off[x+1]-1, the last position of x's slice, and is counted DOWN: the
 // returning atomic is the third-role write position itself (no load of off[x+1] from a second random line)
 template <int MODE, class OffT = uint32_t, bool BACK = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
-__global__ __launch_bounds__(kBlock, 4) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
+__global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
                                                       const OffT *__restrict__ off, int2 *__restrict__ inc, int ablate)
