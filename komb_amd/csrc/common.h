@@ -87,8 +87,9 @@ struct LocalCtrl {
     uint32_t evals;          // unit evaluations, all sweeps
     uint32_t n_light, n_heavy;   // numbering counters (k_local_number)
     uint32_t n_giant;        // heavy units with more than kMedMax items
-    uint32_t n_chunk;        // chunks of kChunk items they are counted in
-    uint32_t pad[3];
+    uint32_t n_chunk;        // chunks of kGiantChunk items they are counted in
+    uint32_t pad0;
+    unsigned long long key_sum;  // sum of the live keys = items of the remainder (k_local_number)
 };
 static_assert(sizeof(LocalCtrl) == 64, "LocalCtrl layout");
 
@@ -104,6 +105,13 @@ inline FinishMode finish_mode(FinishMode dflt)
     if (e && !strcmp(e, "local")) return FIN_LOCAL;
     if (e && !strcmp(e, "lds")) return FIN_LDS;
     if (e && !strcmp(e, "none")) return FIN_NONE;
+    return dflt;
+}
+// The fixed point costs ~ sweeps x items, the peel ~ its items once + a latency per sub-round: a remainder with more items
+// than this is not handed over (the peel goes on and offers a smaller one).  KOMB_LOCAL_ITEMS overrides.
+inline uint64_t local_item_limit(uint64_t dflt)
+{
+    if (const char *e = getenv("KOMB_LOCAL_ITEMS")) return strtoull(e, nullptr, 10);
     return dflt;
 }
 inline uint32_t local_limit(uint64_t units, uint64_t divisor)

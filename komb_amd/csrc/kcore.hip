@@ -112,8 +112,13 @@ struct CoreCollect {
 };
 
 // Fixed-point problem: item = a live neighbour, value = its current bound.
+// remainders with more slots than this -- or a sixth of the graph's, if that is more -- stay with the peel (see
+// local_item_limit; measured: C3 hands over 25M of 200M slots, 3x C3 75M of 600M, the alpha = 2.2 stress shape does best
+// with 24M of 215M and loses 20% with 73M)
+constexpr uint64_t kCoreLocalItems = 32ull << 20;
 struct CoreLocal {
-    static constexpr int kU = 8;         // light unit: <= 512 live neighbours (one batch = 64 lanes x 8 values)
+    static constexpr int kU = 8;
+    static constexpr int kGroups = 1;         // light unit: <= 512 live neighbours (one batch = 64 lanes x 8 values)
     static constexpr int kN = 1;
     const uint32_t *nbr;
     __device__ __forceinline__ void ids(uint32_t pos, uint32_t (&id)[1]) const { id[0] = nbr[pos]; }
@@ -263,7 +268,7 @@ int core_run(komb_ctx *ctx)
         KOMB_HIP(ctx, hipMemsetAsync(d_livebits, 0, live_words * sizeof(unsigned long long), s));
         LocalStats ls;
         const int rc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)nv, ctx->d_core, d_degw, Q.live[hc.live_sel],
-            (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), 0, ctx->d_core,
+            (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), local_item_limit(std::max<uint64_t>(kCoreLocalItems, (uint64_t)ctx->ne / 3)), 0, ctx->d_core,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 CoreCollect C{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, ctx->d_core, d_livebits, num, lg.off, lg.cur, (uint32_t *)items};
                 k_peel_step<CoreCollect><<<grid, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);
@@ -279,6 +284,7 @@ int core_run(komb_ctx *ctx)
         (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
         for (auto &e : ev) (void)hipEventDestroy(e);
         KOMB_TRY(rc);
+        if (ls.refused) { ctx->h_ctrl[0].done = 0; ctx->h_ctrl[0].tail_limit = ls.new_limit; return KOMB_OK; }
         stt.core_local_units = (int32_t)ls.units; stt.core_local_sweeps = ls.sweeps; stt.core_local_items = (int64_t)ls.items;
         stt.ms_core_local = (double)ms;
         PeelCtrl done = hc;

@@ -680,8 +680,14 @@ struct TrussCollect {
 };
 
 // Fixed-point problem: item = a live triangle, value = the smaller bound of its other two edges.
+// remainders with more live triangle entries than this stay with the peel (see local_item_limit)
+constexpr uint64_t kTrussLocalItems = 32ull << 20;
 struct TrussLocal {
     static constexpr int kU = 8;         // light unit: <= 512 live triangles (one batch = 64 lanes x 8 values)
+#ifndef KOMB_TRUSS_GROUPS
+#define KOMB_TRUSS_GROUPS 8
+#endif
+    static constexpr int kGroups = KOMB_TRUSS_GROUPS;
     static constexpr int kN = 2;
     const uint2 *cpair;
     __device__ __forceinline__ void ids(uint32_t pos, uint32_t (&id)[2]) const
@@ -1017,13 +1023,13 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
     // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
-    const FinishMode fin = finish_mode(FIN_LDS);
+    const FinishMode fin = finish_mode(FIN_LOCAL);
     uint32_t tail_limit = 0;
     if (fin == FIN_LDS) {
         tail_limit = kTailEdges;
         if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
         if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
-    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 512);
+    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 32);
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
@@ -1085,7 +1091,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         (void)hipEventRecord(ev[0], s);
         LocalStats ls;
         const int lrc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)m, d_stamp, d_sup, Q.live[hc.live_sel],
-            (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), 2, d_truss,
+            (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), local_item_limit(kTrussLocalItems), 2, d_truss,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 TrussCollect C{(uint32_t)m, d_off, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
                 k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);
@@ -1100,6 +1106,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
         for (auto &e : ev) (void)hipEventDestroy(e);
         KOMB_TRY(lrc);
+        if (ls.refused) { ctx->h_ctrl[0].done = 0; ctx->h_ctrl[0].tail_limit = ls.new_limit; return KOMB_OK; }
         st.truss_local_units = (int32_t)ls.units; st.truss_local_sweeps = ls.sweeps; st.truss_local_items = (int64_t)ls.items;
         st.ms_truss_local = (double)ms;
         PeelCtrl fin_c = hc;

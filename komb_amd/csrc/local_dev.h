@@ -76,6 +76,9 @@ static __global__ __launch_bounds__(kNumBlock) void k_local_number(const int32_t
     __shared__ uint32_t sh_cnt[kNumBlock / kWave][2];
     __shared__ uint32_t sh_base[2];
     __shared__ uint32_t sh_kh[kKeyBins];
+    __shared__ unsigned long long sh_ks;
+    unsigned long long ks = 0ull;
+    if (threadIdx.x == 0) sh_ks = 0ull;
     for (uint32_t i = threadIdx.x; i < kKeyBins; i += kNumBlock) sh_kh[i] = 0u;
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     for (uint32_t i0 = blockIdx.x * kNumBlock; i0 < n_in; i0 += gridDim.x * kNumBlock) {
@@ -103,6 +106,7 @@ static __global__ __launch_bounds__(kNumBlock) void k_local_number(const int32_t
         }
         __syncthreads();
         if (u < 0) continue;
+        ks += (unsigned long long)(uint32_t)k;
         const uint32_t id = heavy ? sh_base[0] + bh + (uint32_t)__popcll(mh & lanemask_lt())
                                   : n_live - 1u - (sh_base[1] + bl + (uint32_t)__popcll(ml & lanemask_lt()));
         if (id >= n_live) { atomicAdd(&ctrl->bad, 1u); continue; }      // more live units than the control block said
@@ -114,8 +118,11 @@ static __global__ __launch_bounds__(kNumBlock) void k_local_number(const int32_t
             g.giant[atomicAdd(&ctrl->n_giant, 1u)] = make_uint4(id, atomicAdd(&ctrl->n_chunk, nch), nch, 0u);
         }
     }
+    for (int o = 32; o > 0; o >>= 1) ks += __shfl_xor(ks, o);
+    if (lane == 0 && ks) atomicAdd(&sh_ks, ks);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kKeyBins; i += kNumBlock) if (sh_kh[i]) atomicAdd(&g.khist[i], sh_kh[i]);
+    if (threadIdx.x == 0 && sh_ks) atomicAdd(&ctrl->key_sum, sh_ks);
 }
 
 // the chunk queue of the longest units, one workgroup per unit
@@ -170,6 +177,7 @@ static __global__ __launch_bounds__(kBlock) void k_local_check(LocalGraph g, Loc
 
 // ---- 3. one sweep.  Problem concept (all __device__):
 //   static constexpr int kU;                     values per lane of a light batch (light unit: <= 64 * kU items)
+//   static constexpr int kGroups;                light groups per wavefront aimed at (see the light path)
 //   static constexpr int kN;                     units an item refers to (k-core: the neighbour; k-truss: the other two edges)
 //   void ids(pos, uint32_t (&id)[kN]) const;     the item's unit ids
 // The value of an item is the smallest current value of its units.  When a unit drops from a to h in sweep k it marks
@@ -202,6 +210,16 @@ struct LocalNotify {
         for (int i = 0; i < P::kN; ++i) v[i] = val[id[i]];
 #pragma unroll
         for (int i = 0; i < P::kN; ++i) hit[i] = v[i] > h && (all || v[i] <= a || mark_cur[id[i]] == k);
+    }
+    // kN == 1 and the item's value v0 as the evaluation read it: no second gather of the value, and the mark is looked at
+    // only where v0 > a.  v0 may be stale (too high) -- then its unit is being evaluated in this sweep, which the mark says
+    __device__ __forceinline__ void load_known(const P &p, uint32_t pos, int32_t v0, const int32_t *mark_cur, int32_t h, int32_t a, int32_t k, bool active, bool all)
+    {
+        static_assert(P::kN == 1, "one unit per item");
+        hit[0] = false;
+        if (!active || v0 <= h) return;
+        p.ids(pos, id);
+        hit[0] = all || v0 <= a || mark_cur[id[0]] == k;
     }
     __device__ __forceinline__ void store(int32_t *mark_next, int32_t k) const
     {
@@ -289,6 +307,9 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
         // medium units: wavefront w takes queue entries w, w + 8, ...
         const uint32_t nm = sh_mn;
         uint16_t *vb = sh_med[w];
+#ifdef KOMB_LOCAL_EXP
+        if (KOMB_LOCAL_EXP & 2) continue;
+#endif
         for (uint32_t mi = (uint32_t)w; mi < nm; mi += kLocWaves) {
             const uint32_t hu = sh_m[mi];
             const int32_t cap = g.val[hu];                       // written by this wavefront only
@@ -321,7 +342,11 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             if (!skip_notify) for (uint32_t j0 = (uint32_t)lane; j0 < len; j0 += kWave * 8) {
                 LocalNotify<P> nt[8];
 #pragma unroll
-                for (int x = 0; x < 8; ++x) { const uint32_t j = j0 + (uint32_t)x * kWave; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len, full); }
+                for (int x = 0; x < 8; ++x) {
+                    const uint32_t j = j0 + (uint32_t)x * kWave;
+                    if constexpr (P::kN == 1) nt[x].load_known(p, beg + j, j < len ? (int32_t)vb[j] : 0, mark_cur, H, cap, k, j < len, full);
+                    else nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len, full);
+                }
 #pragma unroll
                 for (int x = 0; x < 8; ++x) nt[x].store(mark_next, k);
             }
@@ -338,7 +363,9 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     const uint32_t nlight = g.n - g.nh;
     const uint32_t nw = gridDim.x * kLocWaves;
     uint32_t gsz = kWave;
-    while (gsz > 1 && (nlight + gsz - 1) / gsz < nw) gsz >>= 1;
+    // at least P::kGroups groups per wavefront while groups stay >= 8 units (measured at C3: k-truss units are short, its
+    // sweep time fell 5.4 -> 3.2 ms going from 1 to 8; k-core's rose 3%)
+    while (gsz > 1 && (nlight + gsz - 1) / gsz < (gsz > 8 ? (uint32_t)P::kGroups : 1u) * nw) gsz >>= 1;      // a few groups per wavefront: the slowest wavefront sets the sweep's time
     const uint32_t ngrp = (nlight + gsz - 1) / gsz;
     for (uint32_t grp = blockIdx.x * kLocWaves + (uint32_t)w; grp < ngrp; grp += nw) {
         const uint32_t u = g.nh + grp * gsz + (uint32_t)lane;
@@ -433,7 +460,8 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 for (int x = 0; x < kU; ++x) {
                     const int o = owner_of(x);
                     const int32_t th = __shfl(thr_n, o), old = __shfl(mcap, o);
-                    nt[x].load(p, item_pos(x, o), g.val, mark_cur, th, old, k, r[x] >= 0 && th != 0x7FFFFFFF, full);
+                    if constexpr (P::kN == 1) nt[x].load_known(p, item_pos(x, o), r[x], mark_cur, th, old, k, r[x] >= 0 && th != 0x7FFFFFFF, full);
+                    else nt[x].load(p, item_pos(x, o), g.val, mark_cur, th, old, k, r[x] >= 0 && th != 0x7FFFFFFF, full);
                 }
 #pragma unroll
                 for (int x = 0; x < kU; ++x) nt[x].store(mark_next, k);
@@ -504,6 +532,9 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 const uint32_t c0 = sh_pick[3];
                 if (c0 == 0xFFFFFFFFu) continue;                 // another workgroup finishes this unit
                 if (tid == 0) ++n_evals;
+#ifdef KOMB_LOCAL_EXP
+                if (KOMB_LOCAL_EXP & 1) continue;
+#endif
                 if (c0 >= (uint32_t)cap) continue;               // still has cap items >= cap: unchanged
                 lo = (int32_t)c0;                                // the c0 items >= cap are >= c0 as well
             }
@@ -700,6 +731,8 @@ struct LocalStats {
     int32_t max_val = 0;
     int sweeps = 0, launches = 0;
     uint64_t items = 0, evals = 0;
+    bool refused = false;            // the remainder has more items than the caller's limit: nothing was done,
+    uint32_t new_limit = 0;          // ... the peel's control block now says done = 0, tail_limit = new_limit
 };
 
 // The whole hand-over: number -> scan -> collect (peel engine, `launch_collect`) -> check -> sweep (`run_fix`) ->
@@ -710,7 +743,7 @@ struct LocalStats {
 // (k-core builds its bitmap of live vertices there).
 template <class LaunchCollect, class RunFix, class AfterNumber>
 int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_ctrl, uint32_t units, const int32_t *marker,
-                 const int32_t *key, const int32_t *live_list, uint32_t light_max, size_t item_bytes, int32_t add, int32_t *out,
+                 const int32_t *key, const int32_t *live_list, uint32_t light_max, size_t item_bytes, uint64_t item_limit, int32_t add, int32_t *out,
                  LaunchCollect &&launch_collect, RunFix &&run_fix, LocalStats *ls, AfterNumber &&after_number)
 {
     hipStream_t s = ctx->stream;
@@ -750,16 +783,38 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, hipMemsetAsync(d_lctrl, 0, sizeof(LocalCtrl), s));
     KOMB_HIP(ctx, hipMemsetAsync(g.len + n, 0, sizeof(uint32_t), s));
     KOMB_HIP(ctx, hipMemsetAsync(d_present, 0, present_words * sizeof(uint32_t), s));
+    void *d_items = nullptr;
+    auto release_all = [&]() {
+        bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
+        bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.giant); bufs.release(g.gchunk); bufs.release(g.gacc);
+        bufs.release(g.khist); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cnt); bufs.release(d_cctrl); bufs.release(d_present);
+    };
     g.n = n; g.nh = 0; g.ng = 0; g.nchunk = 0;
     int64_t gb = ((int64_t)n_in + kNumBlock - 1) / kNumBlock;
     k_local_number<<<(int)(gb < 1 ? 1 : (gb > 1024 ? 1024 : gb)), kNumBlock, 0, s>>>(list, n_in, n, marker, key, light_max, d_num, g, d_lctrl);
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, g.len, g.off, (int64_t)n + 1));
     LocalCtrl hl{};
-    uint32_t total = 0;
-    KOMB_HIP(ctx, hipMemcpyAsync(&hl, d_lctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s));
-    KOMB_HIP(ctx, d2h(ctx, &total, g.off + n, sizeof(uint32_t)));
+    KOMB_HIP(ctx, d2h(ctx, &hl, d_lctrl, sizeof(LocalCtrl)));
     if (hl.bad || hl.n_heavy + hl.n_light != n)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u live units numbered, the peel counted %u", hl.n_heavy + hl.n_light, n);
+    if (hl.key_sum > item_limit || hl.key_sum >= 0xFFFFFFFFull) {
+        // too many items for the fixed point to pay (or for 32-bit slice offsets): the peel goes on, and offers the remainder
+        // again once it is small enough that -- at this density or twice it -- its items fit
+        const uint64_t lim = item_limit < 0xFFFFFFFFull ? item_limit : 0xFFFFFFFFull;
+        uint64_t nl = (uint64_t)((double)n * ((double)lim / (double)hl.key_sum) * 0.5);
+        if (nl >= n) nl = n / 2;
+        const uint32_t patch[2] = {(uint32_t)nl, 0u};
+        KOMB_HIP(ctx, hipMemcpy(&d_ctrl->tail_limit, &patch[0], sizeof(uint32_t), hipMemcpyHostToDevice));
+        KOMB_HIP(ctx, hipMemcpy(&d_ctrl->done, &patch[1], sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (dbg) fprintf(stderr, "komb local finish: refused %u units with %llu items (limit %llu); next offer at <= %u units\n", n, (unsigned long long)hl.key_sum, (unsigned long long)item_limit, (uint32_t)nl);
+        if (ls) { ls->refused = true; ls->new_limit = (uint32_t)nl; }
+        release_all();
+        return KOMB_OK;
+    }
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, g.len, g.off, (int64_t)n + 1));
+    uint32_t total = 0;
+    KOMB_HIP(ctx, d2h(ctx, &total, g.off + n, sizeof(uint32_t)));
+    if ((uint64_t)total != hl.key_sum)
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: slice offsets end at %u, the live keys sum to %llu", total, (unsigned long long)hl.key_sum);
     g.nh = hl.n_heavy;
     g.ng = hl.n_giant;
     g.nchunk = hl.n_chunk;
@@ -781,7 +836,6 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     }
     stamp(1);
     after_number(g);
-    void *d_items = nullptr;
     KOMB_HIP(ctx, bufs.alloc((unsigned char **)&d_items, (size_t)total * item_bytes));
 
     // collect: SCAN (every live unit is a hit) + PROCESS of the peel engine on its own control block
@@ -834,8 +888,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
         ls->units = n; ls->heavy = g.nh; ls->levels = hl.levels; ls->max_val = hl.max_val;
         ls->sweeps = hl.iters; ls->launches = launches; ls->items = total; ls->evals = hl.evals;
     }
-    bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
-    bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.giant); bufs.release(g.gchunk); bufs.release(g.gacc); bufs.release(g.khist); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cnt); bufs.release(d_cctrl); bufs.release(d_present);
+    release_all();
     return KOMB_OK;
 }
 
