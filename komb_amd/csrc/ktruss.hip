@@ -247,8 +247,18 @@ constexpr int kTriU = KOMB_TRI_U;              // probe items per lane per trip
 constexpr int kTriBuf = 128;                   // parked triangles per wave (handled once >= 64 are waiting)
 constexpr int kTriCand = KOMB_TRI_CAND;        // parked lookup candidates per wave (searched once >= 64 are waiting)
 constexpr int kTriWaves = kBlock / kWave;
+#ifndef KOMB_TRI_SIGW
+#define KOMB_TRI_SIGW 8
+#endif
+constexpr int kTriSigW = KOMB_TRI_SIGW;          // 32-bit words of a source row's Bloom signature (a power of two)
+constexpr int kTriSigShift = 32 - 5 - (kTriSigW == 2 ? 1 : kTriSigW == 4 ? 2 : kTriSigW == 8 ? 3 : 4);
 
 enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
+
+#ifdef KOMB_TRI_PROFILE
+// debug: when every wavefront of the enumeration started and ended (100 MHz clock), to see its tail
+__device__ unsigned long long g_tri_prof[2 * 16384];
+#endif
 
 // BACK: other_or_cursor[x] starts at off[x+1]-1, the last position of x's slice, and is counted DOWN: the
 // returning atomic is the third-role write position itself (no load of off[x+1] from a second random line)
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
     __shared__ uint32_t sh_ra1[kTriWaves][kWave];
     __shared__ uint3 sh_tri[kTriWaves][kTriBuf];
     __shared__ uint3 sh_cand[kTriWaves][kTriCand];
-    __shared__ uint32_t sh_sig[kTriWaves][2 * kTriV];
+    __shared__ uint32_t sh_sig[kTriWaves][kTriSigW * kTriV];
     __shared__ uint32_t sh_ri[kTriWaves][kWave];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
@@ -280,6 +290,9 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
 
+#ifdef KOMB_TRI_PROFILE
+    if (lane == 0 && gw < 16384) g_tri_prof[2 * gw] = wall_clock64();
+#endif
     for (int64_t task = task_lo + gw; task < task_hi; task += nw) {
       const int64_t v0t = task * kTriV;
       const int nvt_all = (int)min((int64_t)kTriV, nv - v0t);
@@ -305,17 +318,17 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
         int task_steps = 0;                                     // binary-search trips for the longest owned row
         if (staged) {
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { s_col[k] = ocol[S0 + k]; s_cnt[k] = 0u; }
-            if (lane < 2 * kTriV) s_sig[lane] = 0u;
+            for (int x = lane; x < kTriSigW * kTriV; x += kWave) s_sig[x] = 0u;
             uint32_t rl = (lane < nvt) ? s_orow[lane + 1] - s_orow[lane] : 0u;
             for (int o = 32; o > 0; o >>= 1) rl = max(rl, (uint32_t)__shfl_xor((int)rl, o));
             task_steps = 32 - __clz((int)rl);
             __builtin_amdgcn_wave_barrier();
-            // 64-bit Bloom signature of every owned row: a probe whose bit is clear cannot be in the row
+            // Bloom signature (32 * kTriSigW bits) of every owned row: a probe whose bit is clear cannot be in the row
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
                 int lo = 0, hi = nvt - 1;
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_orow[mid] <= S0 + k) lo = mid; else hi = mid - 1; }
-                const uint32_t hb = ((uint32_t)s_col[k] * 0x9E3779B1u) >> 26;
-                atomicOr(&s_sig[2 * lo + (int)(hb >> 5)], 1u << (hb & 31u));
+                const uint32_t hb = ((uint32_t)s_col[k] * 0x9E3779B1u) >> kTriSigShift;
+                atomicOr(&s_sig[kTriSigW * lo + (int)(hb >> 5)], 1u << (hb & 31u));
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -336,7 +349,8 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                     } else {
                         // slices [off[x], off[x+1]) -- capacity-bounded (single pass) or exact (after a
                         // counting pass): own-role entries grow from the front, third-role from the back
-                        OffT pe, pi;
+                        OffT pe = 0, pi = 0;
+                        if (!(ablate & 16)) {
                         if (staged) {
                             pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
                             pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
@@ -344,10 +358,15 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                             pe = off[e] + atomicAdd(&own[e], 1u);
                             pi = off[i] + atomicAdd(&own[i], 1u);
                         }
+                        }
+                        if (!(ablate & 32)) {
                         const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                        inc[pj] = make_int2((int)e, (int)i);
+                        }
+                        if (!(ablate & 16)) {
                         inc[pe] = make_int2((int)i, (int)jj);
                         inc[pi] = make_int2((int)e, (int)jj);
-                        inc[pj] = make_int2((int)e, (int)i);
+                        }
                     }
                 }
             }
@@ -440,8 +459,8 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                         uint32_t r = 0;
                         if (valid[k] && !(ablate & 2)) {
                             r = s_ri[t[k]];
-                            const uint32_t hb = ((uint32_t)wv[k] * 0x9E3779B1u) >> 26;
-                            cand = (s_sig[2 * r + (hb >> 5)] >> (hb & 31u)) & 1u;
+                            const uint32_t hb = ((uint32_t)wv[k] * 0x9E3779B1u) >> kTriSigShift;
+                            cand = (s_sig[kTriSigW * r + (hb >> 5)] >> (hb & 31u)) & 1u;
                         }
                         const uint64_t cm = __ballot(cand);
                         if (cm) {
@@ -478,6 +497,9 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
         }
       }   // sub-ranges
     }
+#ifdef KOMB_TRI_PROFILE
+    if (lane == 0 && gw < 16384) g_tri_prof[2 * gw + 1] = wall_clock64();
+#endif
 }
 
 __global__ __launch_bounds__(kBlock) void k_total_u32(const uint32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ total)
@@ -938,6 +960,21 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 k_back_cursors<<<ge, kBlock, 0, s>>>(d_offc, m, d_other);
                 k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, ablate);
             }
+#ifdef KOMB_TRI_PROFILE
+            {
+                std::vector<unsigned long long> pr(2 * 16384);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_tri_prof), pr.size() * sizeof(unsigned long long));
+                unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> dur, endt;
+                const int nwv = gt * kTriWaves < 16384 ? gt * kTriWaves : 16384;
+                for (int i = 0; i < nwv; ++i) { if (pr[2 * i] < t0) t0 = pr[2 * i]; if (pr[2 * i + 1] > t1) t1 = pr[2 * i + 1]; }
+                for (int i = 0; i < nwv; ++i) { dur.push_back((pr[2 * i + 1] - pr[2 * i]) / 100.0); endt.push_back((pr[2 * i + 1] - t0) / 100.0); }
+                std::sort(dur.begin(), dur.end()); std::sort(endt.begin(), endt.end());
+                auto q = [&](std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                fprintf(stderr, "komb tri profile: %d waves, span %.0f us; wave busy time us: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; end time us: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f\n",
+                        nwv, (t1 - t0) / 100.0, dur.front(), q(dur, .1), q(dur, .5), q(dur, .9), q(dur, .99), dur.back(), q(endt, .1), q(endt, .5), q(endt, .9), q(endt, .99), endt.back());
+            }
+#endif
             st.ms_tri_fill = ctx->timer.stop(s);
             st.ms_tri_count = 0.0;
         } else {

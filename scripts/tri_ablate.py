@@ -6,9 +6,9 @@ nv, ncl = 10_000_000, 24_250_000
 uv = komb_amd.gen_hug_edges(nv, ncl, 2.6, 42)
 a = komb_amd.KombAccel(); a.from_edges(nv, uv); del uv
 a.truss_run()
-for mode in ("single", "twopass"):
+for mode in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("single", "twopass")):
     if mode == "twopass": os.environ["KOMB_TWO_PASS"] = "1"
-    for ab in (0, 4, 1, 2, 3, 7, 8):
+    for ab in (0, 4, 16, 32, 48, 1, 2, 3, 7, 8):   # 16: no own-role stores, 32: no third-role atomic + store
         os.environ["KOMB_TRI_ABLATE"] = str(ab)
         try:
             a.truss_run()
