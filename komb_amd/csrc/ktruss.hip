@@ -214,8 +214,10 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 // One wavefront owns kTriV consecutive source vertices.  Their oriented rows
 // are one contiguous range [S0,S1) of ocol, staged in LDS together with one
 // counter per slot.  The probe items -- every element of N+(b) for every owned
-// edge (a->b) -- are flattened over the 64 lanes (prefix sum + binary search in
-// LDS); each item is looked up in the staged row of a by binary search in LDS.
+// edge (a->b) -- are cut into chunks of 4 consecutive elements of one row, the
+// chunks are flattened over the 64 lanes (prefix sum + binary search in LDS);
+// each item is looked up in the staged row of a (row signature first, then a
+// binary search in LDS for the survivors).
 // Of a triangle's three edges, e and i belong to the owned rows, so their
 // counts / write cursors are LDS atomics private to the wave; only j needs a
 // global atomic.  Hits are rare (~4% of the probes): they are parked in an LDS
@@ -230,20 +232,18 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 // Tasks whose rows exceed the LDS budget fall back to global binary search and
 // global atomics for all three roles.
 #ifndef KOMB_TRI_CAP
-#define KOMB_TRI_CAP 512
+#define KOMB_TRI_CAP 256
 #endif
 #ifndef KOMB_TRI_EU
 #define KOMB_TRI_EU 4
 #endif
-#ifndef KOMB_TRI_U
-#define KOMB_TRI_U 2
-#endif
 #ifndef KOMB_TRI_CAND
-#define KOMB_TRI_CAND 192
+#define KOMB_TRI_CAND 320
 #endif
 constexpr int kTriV = 16;
 constexpr int kTriCap = KOMB_TRI_CAP;
-constexpr int kTriU = KOMB_TRI_U;              // probe items per lane per trip
+constexpr int kTriR = 4;                       // consecutive elements of one row N+(b) a lane probes per trip (one 16-byte load)
+struct __attribute__((packed, aligned(4))) Int4U { int32_t x, y, z, w; };      // 16 bytes at a 4-byte aligned address
 constexpr int kTriBuf = 128;                   // parked triangles per wave (handled once >= 64 are waiting)
 constexpr int kTriCand = KOMB_TRI_CAND;        // parked lookup candidates per wave (searched once >= 64 are waiting)
 constexpr int kTriWaves = kBlock / kWave;
@@ -280,13 +280,14 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
     __shared__ uint3 sh_cand[kTriWaves][kTriCand];
     __shared__ uint32_t sh_sig[kTriWaves][kTriSigW * kTriV];
     __shared__ uint32_t sh_ri[kTriWaves][kWave];
+    __shared__ uint32_t sh_len[kTriWaves][kWave];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     int32_t *s_col = sh_col[w];
     uint32_t *s_cnt = sh_cnt[w], *s_orow = sh_orow[w], *s_pref = sh_pref[w];
     uint32_t *s_rb0 = sh_rb0[w], *s_ra0 = sh_ra0[w], *s_ra1 = sh_ra1[w];
     uint3 *s_tri = sh_tri[w], *s_cand = sh_cand[w];
-    uint32_t *s_sig = sh_sig[w], *s_ri = sh_ri[w];
+    uint32_t *s_sig = sh_sig[w], *s_ri = sh_ri[w], *s_len = sh_len[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
 
@@ -427,60 +428,62 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 rb0 = orow[b];
                 lenb = orow[b + 1] - rb0;
             }
-            const uint32_t incl = wave_incl_scan(lenb);
+            // The probe items of the 64 edges are cut into chunks of kTriR consecutive elements of ONE row N+(b) and the
+            // chunks are flattened over the lanes: one owner search and one 16-byte load per kTriR probes (a probe per lane
+            // cost an owner search -- 8 LDS reads -- each; the kernel is bound by its LDS traffic)
+            const uint32_t incl = wave_incl_scan((lenb + (uint32_t)kTriR - 1u) / (uint32_t)kTriR);
             const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
             __builtin_amdgcn_wave_barrier();
-            s_pref[lane] = incl; s_rb0[lane] = rb0; s_ra0[lane] = ra0; s_ra1[lane] = ra1; s_ri[lane] = ri;
+            s_pref[lane] = incl; s_rb0[lane] = rb0; s_ra0[lane] = ra0; s_ra1[lane] = ra1; s_ri[lane] = ri; s_len[lane] = lenb;
             __builtin_amdgcn_wave_barrier();
-            // kTriU items per lane per trip: the owner search, the gather of w and the row search of
-            // the items are independent chains, so their latencies overlap
-            for (uint32_t it0 = 0; it0 < ((ablate & 8) ? 0u : total); it0 += kWave * kTriU) {
-                int t[kTriU];
-                uint32_t j[kTriU];
-                bool valid[kTriU];
+            for (uint32_t it0 = 0; it0 < ((ablate & 8) ? 0u : total); it0 += kWave) {
+                const uint32_t it = it0 + (uint32_t)lane;
+                const bool live = it < total;
+                int t = 0;                                    // owner: smallest t with s_pref[t] > it (branchless, 6 fixed steps)
 #pragma unroll
-                for (int k = 0; k < kTriU; ++k) {
-                    const uint32_t it = it0 + (uint32_t)(k * kWave + lane);
-                    valid[k] = it < total;
-                    int lo = 0;                               // owner: smallest t with s_pref[t] > it (branchless, 6 fixed steps)
-#pragma unroll
-                    for (int st = kWave / 2; st > 0; st >>= 1) lo += (s_pref[lo + st - 1] <= it) ? st : 0;
-                    t[k] = lo;
-                    const uint32_t first = lo ? s_pref[lo - 1] : 0u;
-                    j[k] = s_rb0[lo] + (it - first);          // slot of w in row b
-                }
-                int32_t wv[kTriU];
-#pragma unroll
-                for (int k = 0; k < kTriU; ++k) wv[k] = (valid[k] && !(ablate & 1)) ? ocol[j[k]] : (int32_t)j[k];
+                for (int st = kWave / 2; st > 0; st >>= 1) t += (s_pref[t + st - 1] <= it) ? st : 0;
+                const uint32_t first = t ? s_pref[t - 1] : 0u;
+                const uint32_t c0 = (it - first) * (uint32_t)kTriR;           // first element of the chunk, relative to the row
+                const uint32_t j0 = s_rb0[t] + c0;                            // its slot in row b
+                const uint32_t nin = live ? min((uint32_t)kTriR, s_len[t] - c0) : 0u;    // elements of the chunk inside the row
                 if (staged) {
+                    int32_t wv[kTriR];
+                    if (live && !(ablate & 1)) {
+                        // the rows are 4-byte aligned only; the array is padded so that the last chunk may read past its row
+                        const Int4U q = *reinterpret_cast<const Int4U *>(ocol + j0);
+                        wv[0] = q.x; wv[1] = q.y; wv[2] = q.z; wv[3] = q.w;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < kTriU; ++k) {
+                        for (int k = 0; k < kTriR; ++k) wv[k] = (int32_t)(j0 + (uint32_t)k);
+                    }
+                    const uint32_t r = s_ri[t];
+#pragma unroll
+                    for (int k = 0; k < kTriR; ++k) {
                         bool cand = false;
-                        uint32_t r = 0;
-                        if (valid[k] && !(ablate & 2)) {
-                            r = s_ri[t[k]];
+                        if ((uint32_t)k < nin && !(ablate & 2)) {
                             const uint32_t hb = ((uint32_t)wv[k] * 0x9E3779B1u) >> kTriSigShift;
                             cand = (s_sig[kTriSigW * r + (hb >> 5)] >> (hb & 31u)) & 1u;
                         }
                         const uint64_t cm = __ballot(cand);
                         if (cm) {
                             if (cand) s_cand[n_cand + (uint32_t)__popcll(cm & lanemask_lt())] =
-                                make_uint3((p0 + (uint32_t)t[k]) | (r << 16), j[k], (uint32_t)wv[k]);
+                                make_uint3((p0 + (uint32_t)t) | (r << 16), j0 + (uint32_t)k, (uint32_t)wv[k]);
                             n_cand += (uint32_t)__popcll(cm);
                         }
                     }
-                    if (n_cand >= (uint32_t)kTriCand - kWave * kTriU) search_cands();
+                    if (n_cand >= (uint32_t)kTriCand - kWave * kTriR) search_cands();
                 } else {
 #pragma unroll
-                    for (int k = 0; k < kTriU; ++k) {
-                        const bool look = valid[k] && !(ablate & 2);
-                        uint32_t l = look ? s_ra0[t[k]] : 0u, h = look ? s_ra1[t[k]] : 0u;
+                    for (int k = 0; k < kTriR; ++k) {
+                        const bool look = (uint32_t)k < nin && !(ablate & 2);
+                        const int32_t wvk = look ? ocol[j0 + (uint32_t)k] : 0;
+                        uint32_t l = look ? s_ra0[t] : 0u, h = look ? s_ra1[t] : 0u;
                         const uint32_t rend = h;
-                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wv[k]) l = mid + 1; else h = mid; }
-                        const bool hit = l < rend && ocol[S0 + l] == wv[k] && !(ablate & 4);
+                        while (l < h) { const uint32_t mid = (l + h) >> 1; if (ocol[S0 + mid] < wvk) l = mid + 1; else h = mid; }
+                        const bool hit = l < rend && ocol[S0 + l] == wvk && !(ablate & 4);
                         const uint64_t hm = __ballot(hit);
                         if (hm) {
-                            if (hit) s_tri[n_tri + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint3(p0 + (uint32_t)t[k], l, j[k]);
+                            if (hit) s_tri[n_tri + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint3(p0 + (uint32_t)t, l, j0 + (uint32_t)k);
                             n_tri += (uint32_t)__popcll(hm);
                             if (n_tri >= (uint32_t)kTriBuf - kWave) flush_tris();
                         }
@@ -827,7 +830,7 @@ static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cc, d_cb, nchunks + 1));
     uint32_t kept = 0;
     KOMB_HIP(ctx, d2h(ctx, &kept, d_cb + nchunks, sizeof(uint32_t)));
-    KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept));
+    KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept + 4));        // + 4: the triangle enumeration reads 16 bytes at a time
     KOMB_HIP(ctx, bufs.alloc(out_src, (size_t)kept));
     k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits);
     if ((int64_t)kept * 4 < nv) k_rowptr_search<<<grid_for(nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
