@@ -238,13 +238,15 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 #define KOMB_TRI_EU 4
 #endif
 #ifndef KOMB_TRI_CAND
-#define KOMB_TRI_CAND 320
+#define KOMB_TRI_CAND 128
 #endif
 constexpr int kTriV = 16;
 constexpr int kTriCap = KOMB_TRI_CAP;
 constexpr int kTriR = 4;                       // consecutive elements of one row N+(b) a lane probes per trip (one 16-byte load)
 struct __attribute__((packed, aligned(4))) Int4U { int32_t x, y, z, w; };      // 16 bytes at a 4-byte aligned address
-constexpr int kTriBuf = 128;                   // parked triangles per wave (handled once >= 64 are waiting)
+struct __attribute__((packed, aligned(4))) UInt2U { uint32_t x, y; };
+constexpr int kTriBuf = 128;                   // parked triangles per wave on the unstaged path (handled once >= 64 are waiting)
+constexpr int kTriRec = 384;                   // triangle records a staged task keeps until it is done (own-role entries, 8 bytes each)
 constexpr int kTriCand = KOMB_TRI_CAND;        // parked lookup candidates per wave (searched once >= 64 are waiting)
 constexpr int kTriWaves = kBlock / kWave;
 #ifndef KOMB_TRI_SIGW
@@ -262,13 +264,27 @@ __device__ unsigned long long g_tri_prof[2 * 16384];
 
 // BACK: other_or_cursor[x] starts at off[x+1]-1, the last position of x's slice, and is counted DOWN: the
 // returning atomic is the third-role write position itself (no load of off[x+1] from a second random line)
-template <int MODE, class OffT = uint32_t, bool BACK = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
+// DENSE (TRI_SINGLE over capacity-bounded slices): the own-role entries do not go to the slices at all.  A staged
+// task keeps one 8-byte record per triangle in LDS and, when it is done, writes the own-role entries of all its edges
+// as ONE compact block of `dense` (claimed from `dense_cursor` in chunks, see below), edge after edge:
+// ownoff[e] = where edge e's entries start.  176 M scattered 8-byte stores (one HBM line each) become a coalesced
+// stream.  A task with more triangles than the record buffer holds, and a row too long to stage, fall back to the
+// slices (ownoff[e] = kOwnSpill); k_compact_inc reads either.
+constexpr unsigned long long kOwnSpill = ~0ull;
+constexpr uint32_t kOwnChunk = 4096;                // entries a wavefront claims from dense_cursor at a time (one atomic per ~15 tasks)
+
+template <int MODE, class OffT = uint32_t, bool BACK = false, bool DENSE = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
 __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
-                                                      const OffT *__restrict__ off, int2 *__restrict__ inc, int ablate)
+                                                      const OffT *__restrict__ off, int2 *__restrict__ inc,
+                                                      int2 *__restrict__ dense, unsigned long long *dense_cursor,
+                                                      unsigned long long *__restrict__ ownoff, int ablate)
 {
-    // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all
+    // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all,
+    // 16 = no own-role stores, 32 = no third-role atomic + store
+    static_assert(kTriCap <= 256, "edge indices and cursors of a staged task are kept in 8 bits");
+    static_assert(kTriRec * sizeof(uint2) >= kTriBuf * sizeof(uint3), "the unstaged path parks its triangles in the record buffer");
     __shared__ int32_t sh_col[kTriWaves][kTriCap];
     __shared__ uint32_t sh_cnt[kTriWaves][kTriCap];
     __shared__ uint32_t sh_orow[kTriWaves][kTriV + 1];
@@ -276,20 +292,24 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
     __shared__ uint32_t sh_rb0[kTriWaves][kWave];
     __shared__ uint32_t sh_ra0[kTriWaves][kWave];
     __shared__ uint32_t sh_ra1[kTriWaves][kWave];
-    __shared__ uint3 sh_tri[kTriWaves][kTriBuf];
+    __shared__ uint2 sh_rec[kTriWaves][kTriRec];
     __shared__ uint3 sh_cand[kTriWaves][kTriCand];
     __shared__ uint32_t sh_sig[kTriWaves][kTriSigW * kTriV];
     __shared__ uint32_t sh_ri[kTriWaves][kWave];
     __shared__ uint32_t sh_len[kTriWaves][kWave];
+    __shared__ uint8_t sh_rid[kTriWaves][kTriCap];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
     int32_t *s_col = sh_col[w];
     uint32_t *s_cnt = sh_cnt[w], *s_orow = sh_orow[w], *s_pref = sh_pref[w];
     uint32_t *s_rb0 = sh_rb0[w], *s_ra0 = sh_ra0[w], *s_ra1 = sh_ra1[w];
-    uint3 *s_tri = sh_tri[w], *s_cand = sh_cand[w];
+    uint2 *s_rec = sh_rec[w];
+    uint3 *s_tri = reinterpret_cast<uint3 *>(sh_rec[w]), *s_cand = sh_cand[w];
     uint32_t *s_sig = sh_sig[w], *s_ri = sh_ri[w], *s_len = sh_len[w];
+    uint8_t *s_rid = sh_rid[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+    unsigned long long chunk_pos = 0, chunk_end = 0;             // this wavefront's claim on `dense` (wave-uniform)
 
 #ifdef KOMB_TRI_PROFILE
     if (lane == 0 && gw < 16384) g_tri_prof[2 * gw] = wall_clock64();
@@ -316,13 +336,9 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
         const uint32_t E = S1 - S0;
         if (E == 0) continue;
         const bool staged = E <= (uint32_t)kTriCap;
-        int task_steps = 0;                                     // binary-search trips for the longest owned row
         if (staged) {
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { s_col[k] = ocol[S0 + k]; s_cnt[k] = 0u; }
             for (int x = lane; x < kTriSigW * kTriV; x += kWave) s_sig[x] = 0u;
-            uint32_t rl = (lane < nvt) ? s_orow[lane + 1] - s_orow[lane] : 0u;
-            for (int o = 32; o > 0; o >>= 1) rl = max(rl, (uint32_t)__shfl_xor((int)rl, o));
-            task_steps = 32 - __clz((int)rl);
             __builtin_amdgcn_wave_barrier();
             // Bloom signature (32 * kTriSigW bits) of every owned row: a probe whose bit is clear cannot be in the row
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
@@ -330,10 +346,13 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_orow[mid] <= S0 + k) lo = mid; else hi = mid - 1; }
                 const uint32_t hb = ((uint32_t)s_col[k] * 0x9E3779B1u) >> kTriSigShift;
                 atomicOr(&s_sig[kTriSigW * lo + (int)(hb >> 5)], 1u << (hb & 31u));
+                s_rid[k] = (uint8_t)lo;                                   // the edge's source row, for the batches below
             }
         }
         __builtin_amdgcn_wave_barrier();
 
+        // ---- unstaged sub-range (one row longer than the LDS budget): triangles are parked and handled 64 at a time,
+        // all three roles through global cursors
         uint32_t n_tri = 0;                                     // parked triangles (wave-uniform)
         auto flush_tris = [&]() {
             __builtin_amdgcn_wave_barrier();
@@ -341,33 +360,16 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 const uint32_t x = b0 + (uint32_t)lane;
                 if (x < n_tri) {
                     const uint3 tr = s_tri[x];
-                    const uint32_t e_rel = tr.x, i_rel = tr.y, jj = tr.z;
-                    const uint32_t e = S0 + e_rel, i = S0 + i_rel;
+                    const uint32_t e = S0 + tr.x, i = S0 + tr.y, jj = tr.z;
                     if (MODE == TRI_COUNT) {
-                        if (staged) { atomicAdd(&s_cnt[e_rel], 1u); atomicAdd(&s_cnt[i_rel], 1u); }
-                        else { atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); }
-                        atomicAdd(&other_or_cursor[jj], 1u);
+                        atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); atomicAdd(&other_or_cursor[jj], 1u);
                     } else {
-                        // slices [off[x], off[x+1]) -- capacity-bounded (single pass) or exact (after a
-                        // counting pass): own-role entries grow from the front, third-role from the back
-                        OffT pe = 0, pi = 0;
-                        if (!(ablate & 16)) {
-                        if (staged) {
-                            pe = off[e] + atomicAdd(&s_cnt[e_rel], 1u);
-                            pi = off[i] + atomicAdd(&s_cnt[i_rel], 1u);
-                        } else {
-                            pe = off[e] + atomicAdd(&own[e], 1u);
-                            pi = off[i] + atomicAdd(&own[i], 1u);
-                        }
-                        }
-                        if (!(ablate & 32)) {
+                        const OffT pe = off[e] + atomicAdd(&own[e], 1u);
+                        const OffT pi = off[i] + atomicAdd(&own[i], 1u);
                         const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
-                        inc[pj] = make_int2((int)e, (int)i);
-                        }
-                        if (!(ablate & 16)) {
                         inc[pe] = make_int2((int)i, (int)jj);
                         inc[pi] = make_int2((int)e, (int)jj);
-                        }
+                        inc[pj] = make_int2((int)e, (int)i);
                     }
                 }
             }
@@ -375,36 +377,81 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             n_tri = 0;
         };
 
-        // staged tasks: probes that pass the signature test are parked too and looked up densely
+        // ---- staged sub-range.  A triangle's own-role cursors are LDS atomics; its third-role entry is written at once
+        // (one returning global atomic + one store); its own-role entries wait in the record buffer:
+        // record = (e_rel | i_rel << 8 | cursor_e << 16 | cursor_i << 24, j).
+        uint32_t n_rec = 0;                                     // wave-uniform
+        bool spilled = false;                                   // wave-uniform: the own-role entries of this sub-range go to the slices
+        auto flush_recs_to_slices = [&]() {                     // own-role entries -> inc[off[edge] + cursor]
+            __builtin_amdgcn_wave_barrier();
+            if (MODE == TRI_SINGLE && !(ablate & 16)) {
+                for (uint32_t b0 = 0; b0 < n_rec; b0 += kWave) {
+                    const uint32_t x = b0 + (uint32_t)lane;
+                    if (x < n_rec) {
+                        const uint2 rc = s_rec[x];
+                        const uint32_t e = S0 + (rc.x & 0xFFu), i = S0 + ((rc.x >> 8) & 0xFFu);
+                        inc[off[e] + ((rc.x >> 16) & 0xFFu)] = make_int2((int)i, (int)rc.y);
+                        inc[off[i] + (rc.x >> 24)] = make_int2((int)e, (int)rc.y);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_rec = 0;
+        };
+
+        // probes that pass the signature test are parked and looked up densely, 64 at a time
         uint32_t n_cand = 0;                                    // wave-uniform
         auto search_cands = [&]() {
             __builtin_amdgcn_wave_barrier();
             for (uint32_t b0 = 0; b0 < n_cand; b0 += kWave) {
                 const uint32_t x = b0 + (uint32_t)lane;
-                bool hit = false;
-                uint32_t e_rel = 0, l = 0, jj = 0;
+                uint32_t e_rel = 0, l = 0, jj = 0, rend = 0, n = 0;
+                int32_t wvv = 0;
                 if (x < n_cand) {
                     const uint3 c = s_cand[x];
                     e_rel = c.x & 0xFFFFu; jj = c.y;
                     const uint32_t r = c.x >> 16;
-                    const int32_t wvv = (int32_t)c.z;
+                    wvv = (int32_t)c.z;
                     l = s_orow[r] - S0;
-                    const uint32_t rend = s_orow[r + 1] - S0;
-                    uint32_t n = rend - l;
-                    for (int st = 0; st < task_steps; ++st) {   // branchless lower_bound, wave-uniform trip count
-                        const uint32_t half = n >> 1;
-                        const uint32_t probe = min(l + half, (uint32_t)kTriCap - 1u);
-                        const bool go = n > 0 && s_col[probe] < wvv;
-                        l = go ? l + half + 1u : l;
-                        n = go ? n - half - 1u : half;
-                    }
-                    hit = l < rend && s_col[min(l, (uint32_t)kTriCap - 1u)] == wvv && !(ablate & 4);
+                    rend = s_orow[r + 1] - S0;
+                    n = rend - l;
                 }
+                // branchless lower_bound; the trip count is that of the longest row among these 64 candidates
+                while (__ballot(n > 0)) {
+                    const uint32_t half = n >> 1;
+                    const uint32_t probe = min(l + half, (uint32_t)kTriCap - 1u);
+                    const bool go = n > 0 && s_col[probe] < wvv;
+                    l = go ? l + half + 1u : l;
+                    n = go ? n - half - 1u : half;
+                }
+                const bool hit = x < n_cand && l < rend && s_col[min(l, (uint32_t)kTriCap - 1u)] == wvv && !(ablate & 4);
                 const uint64_t hm = __ballot(hit);
-                if (hm) {
-                    if (hit) s_tri[n_tri + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint3(e_rel, l, jj);
-                    n_tri += (uint32_t)__popcll(hm);
-                    if (n_tri >= (uint32_t)kTriBuf - kWave) flush_tris();
+                if (!hm) continue;
+                if (hit) {
+                    const uint32_t ce = atomicAdd(&s_cnt[e_rel], 1u), ci = atomicAdd(&s_cnt[l], 1u);
+                    if (MODE == TRI_COUNT) atomicAdd(&other_or_cursor[jj], 1u);
+                    else {
+                        const uint32_t e = S0 + e_rel, i = S0 + l;
+                        if (!(ablate & 32)) {
+                            const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                            inc[pj] = make_int2((int)e, (int)i);
+                        }
+                        if (spilled) {
+                            if (!(ablate & 16)) {
+                                inc[off[e] + ce] = make_int2((int)i, (int)jj);
+                                inc[off[i] + ci] = make_int2((int)e, (int)jj);
+                            }
+                        } else s_rec[n_rec + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint2(e_rel | (l << 8) | (ce << 16) | (ci << 24), jj);
+                    }
+                }
+                if (MODE == TRI_SINGLE && !spilled) {
+                    n_rec += (uint32_t)__popcll(hm);
+                    if (n_rec > (uint32_t)kTriRec - kWave) {
+                        // more triangles than the buffer holds.  DENSE: the whole sub-range goes to the slices from here
+                        // on; otherwise the destination is the same anyway
+                        flush_recs_to_slices();
+                        if (DENSE) { spilled = true; if (lane == 0) atomicAdd(dense_cursor + 1, 1ull); }     // statistics
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -418,15 +465,17 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             uint32_t rb0 = 0, lenb = 0, ra0 = 0, ra1 = 0, ri = 0;
             if (valid) {
                 int lo = 0, hi = nvt - 1;                     // source vertex: last idx with s_orow[idx] <= S0+rel
-                while (lo < hi) {
+                if (staged) lo = (int)s_rid[rel];
+                else while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     if (s_orow[mid] <= S0 + rel) lo = mid; else hi = mid - 1;
                 }
                 ra0 = s_orow[lo] - S0; ra1 = s_orow[lo + 1] - S0;
                 ri = (uint32_t)lo;
                 const int32_t b = staged ? s_col[rel] : ocol[S0 + rel];
-                rb0 = orow[b];
-                lenb = orow[b + 1] - rb0;
+                const UInt2U rb = *reinterpret_cast<const UInt2U *>(orow + b);     // orow[b], orow[b + 1] in one load
+                rb0 = rb.x;
+                lenb = rb.y - rb0;
             }
             // The probe items of the 64 edges are cut into chunks of kTriR consecutive elements of ONE row N+(b) and the
             // chunks are flattened over the lanes: one owner search and one 16-byte load per kTriR probes (a probe per lane
@@ -469,9 +518,9 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                             if (cand) s_cand[n_cand + (uint32_t)__popcll(cm & lanemask_lt())] =
                                 make_uint3((p0 + (uint32_t)t) | (r << 16), j0 + (uint32_t)k, (uint32_t)wv[k]);
                             n_cand += (uint32_t)__popcll(cm);
+                            if (n_cand >= (uint32_t)kWave) search_cands();     // at most 63 are waiting when the next 64 arrive
                         }
                     }
-                    if (n_cand >= (uint32_t)kTriCand - kWave * kTriR) search_cands();
                 } else {
 #pragma unroll
                     for (int k = 0; k < kTriR; ++k) {
@@ -492,11 +541,56 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (!staged) {
+            flush_tris();
+            if (DENSE) for (uint32_t k = (uint32_t)lane; k < E; k += kWave) ownoff[S0 + k] = kOwnSpill;
+            continue;
+        }
         search_cands();
-        flush_tris();
-        if (staged) {
+        if (MODE == TRI_SINGLE && DENSE && !spilled) {
+            // the own-role entries of this sub-range as one block of `dense`: exclusive prefix of the cursors (into s_col,
+            // which is done with), a claim on the wavefront's chunk, the offsets, the entries
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) own[S0 + k] = s_cnt[k];
+            uint32_t run = 0;
+            for (uint32_t k0 = 0; k0 < E; k0 += kWave) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                const uint32_t c = k < E ? s_cnt[k] : 0u;
+                const uint32_t ic = wave_incl_scan(c);
+                if (k < E) s_col[k] = (int32_t)(run + ic - c);
+                run += (uint32_t)__shfl((int)ic, kWave - 1);
+            }
+            unsigned long long base = 0;
+            if (run) {
+                if (chunk_pos + run > chunk_end) {               // (wave-uniform) the block does not fit what is left of the chunk
+                    const uint32_t want = run > kOwnChunk ? run : kOwnChunk;
+                    unsigned long long got = 0;
+                    if (lane == 0) got = atomicAdd(dense_cursor, (unsigned long long)want);
+                    const uint32_t glo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+                    const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
+                    chunk_pos = ((unsigned long long)ghi << 32) | glo;
+                    chunk_end = chunk_pos + want;
+                }
+                base = chunk_pos;
+                chunk_pos += run;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { own[S0 + k] = s_cnt[k]; ownoff[S0 + k] = base + (uint32_t)s_col[k]; }
+            if (!(ablate & 16)) for (uint32_t b0 = 0; b0 < n_rec; b0 += kWave) {
+                const uint32_t x = b0 + (uint32_t)lane;
+                if (x < n_rec) {
+                    const uint2 rc = s_rec[x];
+                    const uint32_t er = rc.x & 0xFFu, ir = (rc.x >> 8) & 0xFFu;
+                    dense[base + (uint32_t)s_col[er] + ((rc.x >> 16) & 0xFFu)] = make_int2((int)(S0 + ir), (int)rc.y);
+                    dense[base + (uint32_t)s_col[ir] + (rc.x >> 24)] = make_int2((int)(S0 + er), (int)rc.y);
+                }
+            }
+        } else {
+            if (MODE == TRI_SINGLE) flush_recs_to_slices();
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
+                own[S0 + k] = s_cnt[k];
+                if (MODE == TRI_SINGLE && DENSE) ownoff[S0 + k] = kOwnSpill;
+            }
         }
       }   // sub-ranges
     }
@@ -535,24 +629,33 @@ __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restric
 }
 // capacity of edge (a->b)'s slice in the single-pass layout: |N(a) & N(b)| <= d(a) - 1, a being the
 // lower-(degree,id) endpoint.  total accumulates the 64-bit sum (the 32-bit offsets must not wrap).
-__global__ __launch_bounds__(kBlock) void k_slice_caps(const int32_t *__restrict__ osrc, const int32_t *__restrict__ deg, int64_t m,
+// total[1]: bound on the OWN-role entries alone (the triangles an edge a->x closes with the other out-neighbours of a:
+// at most d+(a) - 1), the capacity of the dense own-role region.
+__global__ __launch_bounds__(kBlock) void k_slice_caps(const int32_t *__restrict__ osrc, const int32_t *__restrict__ deg,
+                                                       const uint32_t *__restrict__ orow, int64_t m,
                                                        uint32_t *__restrict__ cap, unsigned long long *__restrict__ total)
 {
-    unsigned long long t = 0;
+    unsigned long long t = 0, to = 0;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
-        const uint32_t c = (uint32_t)(deg[osrc[e]] - 1);
+        const int32_t a = osrc[e];
+        const uint32_t c = (uint32_t)(deg[a] - 1);
         cap[e] = c;
         t += c;
+        to += orow[a + 1] - orow[a] - 1u;
     }
     block_add_u64(t, total);
+    block_add_u64(to, total + 1);
 }
 
 // Dense index from the bounded slices: 64 consecutive edges per wavefront, their entries flattened
 // over the lanes; the dense slices of consecutive edges are contiguous, so the writes are one
 // coalesced stream.  Entry k of edge x sits at offc[x]+k (k < own[x]) or offc[x+1]-1-(k-own[x]).
+// With a dense own-role region (own_dense / ownoff, see k_triangles) the own-role entries of edge x are
+// own_dense[ownoff[x] + k] unless ownoff[x] is kOwnSpill.
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void k_compact_inc(const OffT *__restrict__ offc, const uint32_t *__restrict__ own,
                                                         const uint32_t *__restrict__ off, const int2 *__restrict__ sparse,
+                                                        const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
                                                         int2 *__restrict__ dense, int64_t m)
 {
     __shared__ uint32_t sh_end[kBlock / kWave][kWave];
@@ -565,7 +668,8 @@ __global__ __launch_bounds__(kBlock) void k_compact_inc(const OffT *__restrict__
         const int64_t e = bt * kWave + lane;
         uint32_t d0 = 0, len = 0, ow = 0;
         OffT c0 = 0, c1 = 0;
-        if (e < m) { d0 = off[e]; len = off[e + 1] - d0; c0 = offc[e]; c1 = offc[e + 1]; ow = own[e]; }
+        unsigned long long oo = kOwnSpill;
+        if (e < m) { d0 = off[e]; len = off[e + 1] - d0; c0 = offc[e]; c1 = offc[e + 1]; ow = own[e]; if (ownoff) oo = ownoff[e]; }
         const uint32_t incl = wave_incl_scan(len);
         const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
         const uint32_t dbase = (uint32_t)__shfl((int)d0, 0);
@@ -584,10 +688,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_inc(const OffT *__restrict__
             const uint32_t first = t ? s_end[t - 1] : 0u;
             const OffT tc0 = (OffT)__shfl((unsigned long long)c0, t), tc1 = (OffT)__shfl((unsigned long long)c1, t);
             const uint32_t tow = (uint32_t)__shfl((int)ow, t);
+            const unsigned long long too = __shfl(oo, t);
             if (it < total) {
                 const uint32_t k = it - first;
-                const OffT sp = k < tow ? tc0 + k : tc1 - 1u - (k - tow);
-                dense[dbase + it] = sparse[sp];
+                if (k < tow && too != kOwnSpill) dense[dbase + it] = own_dense[too + k];
+                else {
+                    const OffT sp = k < tow ? tc0 + k : tc1 - 1u - (k - tow);
+                    dense[dbase + it] = sparse[sp];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -931,6 +1039,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     uint32_t *d_cap = nullptr, *d_offc = nullptr;
     unsigned long long *d_offc64 = nullptr;    // the same offsets in 64 bits when the slices exceed 2^32 entries (KOMB_OFF64=1 forces them)
     int2 *d_sparse = nullptr;
+    int2 *d_owndense = nullptr;                // own-role entries as compact per-task blocks (see k_triangles, DENSE)
+    unsigned long long *d_ownoff = nullptr, *d_dcur = nullptr;
 #ifdef KOMB_DEBUG_SWITCHES
     const int ablate = getenv("KOMB_TRI_ABLATE") ? atoi(getenv("KOMB_TRI_ABLATE")) : 0;    // breaks results on purpose: debug builds only
 #else
@@ -942,9 +1052,12 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&d_offc, (size_t)m + 1));
         KOMB_HIP(ctx, hipMemsetAsync(d_cap + m, 0, sizeof(uint32_t), s));
         ctx->timer.start(s);
-        k_slice_caps<<<ge, kBlock, 0, s>>>(d_osrc, d_deg, m, d_cap, d_mom + 6);
-        unsigned long long cap_total = 0;
-        KOMB_HIP(ctx, d2h(ctx, &cap_total, d_mom + 6, sizeof(cap_total)));
+        k_slice_caps<<<ge, kBlock, 0, s>>>(d_osrc, d_deg, d_orow, m, d_cap, d_mom + 6);
+        unsigned long long cap_both[2] = {0, 0};
+        KOMB_HIP(ctx, d2h(ctx, cap_both, d_mom + 6, sizeof(cap_both)));
+        const unsigned long long cap_total = cap_both[0];
+        // dense own-role region: the bound, + what the wavefronts' chunked claims can leave unused
+        const unsigned long long own_cap = cap_both[1] + cap_both[1] / 8 + (unsigned long long)gt * kTriWaves * kOwnChunk + kOwnChunk;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         if (cap_total * sizeof(int2) > (unsigned long long)(free_b * 0.8)) single = false;
@@ -956,12 +1069,28 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 else KOMB_TRY(prim_exclusive_sum_u32_u64(ctx, d_cap, d_offc64, m + 1));
             } else KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cap, d_offc, m + 1));
             if (single && bufs.alloc(&d_sparse, (size_t)cap_total) != hipSuccess) { (void)hipGetLastError(); single = false; }
+            // the dense own-role region is an optimisation: without the memory for it the slices take those entries too
+            if (single && !getenv("KOMB_NO_OWN_DENSE")) {
+                (void)hipMemGetInfo(&free_b, &total_b);
+                if (own_cap * sizeof(int2) + (size_t)m * 8 < (unsigned long long)(free_b * 0.8) &&
+                    bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess && bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess &&
+                    bufs.alloc(&d_dcur, 2) == hipSuccess) {
+                    KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 2 * sizeof(unsigned long long), s));
+                } else {
+                    (void)hipGetLastError();
+                    bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
+                    d_owndense = nullptr; d_ownoff = nullptr; d_dcur = nullptr;
+                }
+            }
         }
         if (single) {
-            if (d_offc64) k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, ablate);
-            else {
+            if (d_offc64) {
+                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, d_ownoff, ablate);
+                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, nullptr, ablate);
+            } else {
                 k_back_cursors<<<ge, kBlock, 0, s>>>(d_offc, m, d_other);
-                k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, ablate);
+                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, d_ownoff, ablate);
+                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, nullptr, ablate);
             }
 #ifdef KOMB_TRI_PROFILE
             {
@@ -983,12 +1112,13 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         } else {
             (void)ctx->timer.stop(s);
             bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64); d_offc64 = nullptr;
+            bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur); d_owndense = nullptr; d_ownoff = nullptr; d_dcur = nullptr;
         }
     }
     if (!single) {
         const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
         ctx->timer.start(s);
-        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, ablate);
+        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, nullptr, ablate);
         st.ms_tri_count = ctx->timer.stop(s);
     }
     k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, (single && !d_offc64) ? d_offc : nullptr, m + 1, d_cnt, d_mom + 5);
@@ -1029,16 +1159,23 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (single) {
         ctx->timer.start(s);
         const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
-        if (d_offc64) k_compact_inc<unsigned long long><<<gc, kBlock, 0, s>>>(d_offc64, d_own, d_off, d_sparse, d_inc, m);
-        else k_compact_inc<uint32_t><<<gc, kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_inc, m);
+        if (d_offc64) k_compact_inc<unsigned long long><<<gc, kBlock, 0, s>>>(d_offc64, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
+        else k_compact_inc<uint32_t><<<gc, kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
         st.ms_compact = ctx->timer.stop(s);
+        if (d_dcur && getenv("KOMB_TRI_DEBUG")) {
+            unsigned long long dc[2] = {0, 0};
+            KOMB_HIP(ctx, d2h(ctx, dc, d_dcur, sizeof(dc)));
+            fprintf(stderr, "komb triangles: dense own-role region: %llu entries claimed (%llu would be exact for all), %llu task ranges overflowed their record buffer\n",
+                    dc[0], 2ull * (unsigned long long)total / 3ull, dc[1]);
+        }
         bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64);
+        bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
     } else {
         // second enumeration, same writer as the single-pass layout but into the EXACT slices: own-role
         // entries from the front and third-role entries from the back meet precisely -- no compaction
         ctx->timer.start(s);
         k_back_cursors<<<ge, kBlock, 0, s>>>(d_off, m, d_other);
-        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, ablate);
+        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, nullptr, ablate);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;

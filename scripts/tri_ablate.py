@@ -13,6 +13,6 @@ for mode in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("single", "twopas
         try:
             a.truss_run()
         except Exception as e:
-            print(mode, ab, "error", str(e)[:80]); continue
+            print(mode, ab, "error", str(e)[:60])
         s = a.stats()
         print(f"{mode:8s} ablate={ab}: count {s['ms_tri_count']:.2f} fill {s['ms_tri_fill']:.2f} compact {s['ms_compact']:.2f}", flush=True)
