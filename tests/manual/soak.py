@@ -1,5 +1,6 @@
 """Randomised soak: many graphs of assorted shapes, k-core and k-truss (with support) against the CPU oracle,
-each under a random choice of the hand-over thresholds of the two LDS tails and of the index layout.
+each under a random choice of the finish (local fixed point / LDS tails / none), its hand-over thresholds and item
+limit, and of the index layout (single / two pass, 32 / 64-bit slice offsets, dense or slice-resident own-role entries).
     python tests/manual/soak.py [n_graphs] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -41,7 +42,10 @@ with komb_amd.KombAccel() as a:
         os.environ["KOMB_LOCAL_LIMIT"] = str(rng.choice([0, 40, 900, 20000, 4000000000]))
         os.environ["KOMB_TAIL"] = str(rng.choice([0, 50, 700, 5000, 32768, 65534]))
         os.environ["KOMB_CORE_TAIL"] = str(rng.choice([0, 9, 200, 1024]))
-        for k, on in (("KOMB_TWO_PASS", rng.random() < 0.3), ("KOMB_OFF64", rng.random() < 0.3)):
+        items = str(rng.choice(["", "0", "60", "5000", "200000"]))       # item limit of the local finish ("" = the default): small ones exercise the refusal
+        if items: os.environ["KOMB_LOCAL_ITEMS"] = items
+        else: os.environ.pop("KOMB_LOCAL_ITEMS", None)
+        for k, on in (("KOMB_TWO_PASS", rng.random() < 0.3), ("KOMB_OFF64", rng.random() < 0.3), ("KOMB_NO_OWN_DENSE", rng.random() < 0.3)):
             if on: os.environ[k] = "1"
             else: os.environ.pop(k, None)
         a.from_edges(nv, uv)
@@ -55,7 +59,7 @@ with komb_amd.KombAccel() as a:
             np.save(f"gpurun_out/soak_fail_{g}.npy", uv)
             print(f"MISMATCH graph {g} kind {kind} nv {nv} env FINISH={os.environ['KOMB_FINISH']} LOCAL_LIMIT={os.environ['KOMB_LOCAL_LIMIT']} "
                   f"TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
-                  f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')}", flush=True)
+                  f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')} NO_OWN_DENSE={os.environ.get('KOMB_NO_OWN_DENSE')} LOCAL_ITEMS={os.environ.get('KOMB_LOCAL_ITEMS')}", flush=True)
         if g % 100 == 99:
             print(f"{g + 1} graphs, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {n_graphs} graphs, {bad} mismatches, {time.time() - t0:.0f} s")
