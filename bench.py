@@ -121,15 +121,24 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", action="store_true",
-                    help="N > 1: every rank decomposes a graph of its own (seed + rank) -- KOMB's one-graph-per-sample shape "
-                         "(KOMB.py --file-list); no exchange on the data path, weak scaling.  Default: the SAME graph on every "
-                         "rank, support counting sharded by vertex range + one all-reduce (BASELINE configs[3])")
+                    help="(the default for N > 1, accepted for older command lines) every rank decomposes a graph of its own "
+                         "(seed + rank) -- KOMB's one-graph-per-sample shape (KOMB.py --file-list): the units are sharded over the "
+                         "ranks with no exchange on the data path, weak scaling")
+    ap.add_argument("--same-graph", action="store_true",
+                    help="N > 1: the SAME graph on every rank (BASELINE configs[3]).  One decomposition does not shard: only its "
+                         "support counting does, and that pays back its all-reduce from ~8 ranks on at best (DESIGN.md section 6); "
+                         "so the ranks run replicas unless --shard is given")
+    ap.add_argument("--shard", action="store_true",
+                    help="with --same-graph: support counting sharded by source-vertex range + one all-reduce of the support vector")
     ap.add_argument("--no-build", action="store_true",
                     help="load the prebuilt libkomb_accel.so, spawn no compiler (use under rocprofv3)")
     ap.add_argument("--faithful", action="store_true",
                     help="also time the runTruss-faithful variant (max-core induced subgraph); off by default so that a "
                          "rocprofv3 run of the default command sees only the timed workload's launches")
     args = ap.parse_args()
+    args.batch = args.gpus > 1 and not args.same_graph
+    if args.shard and not args.same_graph:
+        raise SystemExit("--shard needs --same-graph")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start one rank per GPU ourselves -- as a CHILD process and
@@ -176,7 +185,9 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)   # ranks != 0 wait here for rank 0's build
         ok = 0
         why = "one-device rehearsal"
-        if not one_device:
+        if not args.shard:
+            why = "no exchange on the data path"
+        elif not one_device:
             try:
                 data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
                 probe = torch.ones(1, dtype=torch.int32, device="cuda")
@@ -219,11 +230,11 @@ def main():
     if world > 1:
         from komb_amd import distributed as kd
 
-    # Same graph on N ranks: what can be sharded profitably is the support-counting enumeration (the
-    # exchange is one all-reduce of the |E|+1 support words, ~3 ms at C3; the sharded count saves 12.3 ms x (1 - 1/N) but
-    # the exact two-pass index it needs costs ~0.2 ms more than the single pass) -- a gain from N = 8 on, a loss below.
-    # So: N >= 8 shards the counting, 1 < N < 8 runs replicas (every rank the whole single-GPU path, no exchange).
-    shard = world >= int(os.environ.get("KOMB_SHARD_FROM", "8")) and not args.batch
+    # N > 1 by default: every rank its own graph (batch), nothing exchanged.  --same-graph: replicas, or with --shard the
+    # support-counting enumeration split by source-vertex range + one all-reduce of the |E|+1 support words (DESIGN.md
+    # section 6 has the arithmetic: the split saves at most ~9 ms x (1 - 1/N) of a 32 ms step and costs the all-reduce
+    # plus a two-pass index build, so it cannot scale -- it is there because BASELINE configs[3] names it, not to be fast).
+    shard = world > 1 and args.shard
 
     def step():
         if shard:
@@ -320,7 +331,7 @@ def main():
             "metric": "peeled edges/sec (k-truss)", "value": ne_total * args.steps / dt,
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if (args.batch and world > 1) else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "scaling": "strong" if (world > 1 and not args.batch) else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": desc, "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
                        "max_degree": st["max_degree"], "max_trussness": st["max_trussness"],
                        "max_coreness": core_stats["max_coreness"],
@@ -332,8 +343,7 @@ def main():
                        (f"batch: {world} independent graphs (seed + rank), one per GPU, no exchange on the data path" if args.batch else
                         (f"same graph on {world} ranks: triangle-support counting sharded by source-vertex range + one all-reduce of the "
                          f"per-edge support vector ({exchange}); incidence fill, peel and gather replicated on every rank") if shard else
-                        f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange (sharding the "
-                        f"support counting pays from 8 ranks on)")},
+                        f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange")},
             "phases_ms": phase,
             "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
                       "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],
