@@ -93,11 +93,22 @@ struct LocalCtrl {
 };
 static_assert(sizeof(LocalCtrl) == 64, "LocalCtrl layout");
 
+// debug builds only: the dense SCAN without its vector loads (KOMB_SCAN_SCALAR)
+inline int scan_scalar_switch()
+{
+#ifdef KOMB_DEBUG_SWITCHES
+    return getenv("KOMB_SCAN_SCALAR") ? 1 : 0;
+#else
+    return 0;
+#endif
+}
+
 // How a peel ends (KOMB_FINISH): "local" hands the remainder to the h-index fixed point of local_dev.h once at
-// most KOMB_LOCAL_LIMIT units (default: a fraction of all units) are left at a level boundary; "lds" uses the
-// single-workgroup LDS tails (truss_tail.h, core_tail.h; thresholds KOMB_TAIL / KOMB_CORE_TAIL); "none" keeps the
-// whole peel in the general engine.  None of them changes a result.  Defaults, from the measurements in DESIGN.md:
-// k-core "local" (|V| = 1M: 5.3 -> 3.1 ms, |V| = 10M: 16.8 -> 12.0 ms), k-truss "lds" (the two tie there).
+// most KOMB_LOCAL_LIMIT units (default: a fraction of all units) are left at a level boundary and it has at most
+// KOMB_LOCAL_ITEMS items (else it is refused and offered again later); "lds" uses the single-workgroup LDS tails
+// (truss_tail.h, core_tail.h; thresholds KOMB_TAIL / KOMB_CORE_TAIL); "none" keeps the whole peel in the general
+// engine.  None of them changes a result.  Default for both peels: "local" (MI355X: k-core |V| = 1M 5.3 -> 3.0 ms,
+// |V| = 10M 16.8 -> 10.7 ms; k-truss peel |E| = 10M 3.7 -> 2.9 ms, |E| = 100M 13.0 -> 11.1 ms against "lds").
 enum FinishMode : int { FIN_LOCAL = 0, FIN_LDS = 1, FIN_NONE = 2 };
 inline FinishMode finish_mode(FinishMode dflt)
 {

@@ -207,7 +207,7 @@ int core_run(komb_ctx *ctx)
     const size_t heavy_cap = (size_t)(2 * ctx->ne) / 32 + 64;    // sum over units with > kLight items of ceil(items / kChunk) <= 3/128 of all items
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
     CoreTailBufs T{};
-    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, getenv("KOMB_SCAN_SCALAR") ? 1 : 0};
+    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, scan_scalar_switch()};
     KOMB_HIP(ctx, bufs.alloc(&d_degw, (size_t)nv));
     for (int i = 0; i < 2; ++i) {
         KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)nv));

@@ -1185,7 +1185,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     phase.next("truss: peel");
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
     PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
-    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, getenv("KOMB_SCAN_SCALAR") ? 1 : 0};
+    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, scan_scalar_switch()};
     const size_t heavy_cap = (size_t)total / 32 + 64;             // see kcore.hip
     KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
     KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));

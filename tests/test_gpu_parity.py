@@ -216,8 +216,8 @@ def test_full_size_c2_properties(K, O):
 
 
 def test_index_layouts_agree(K, O, monkeypatch):
-    """Single-pass (degree-bounded slices + compaction, 32- and 64-bit slice offsets) and two-pass (exact
-    slices) incidence builds must give the same supports and trussness."""
+    """Single-pass (degree-bounded slices + compaction, 32- and 64-bit slice offsets, own-role entries in dense per-task
+    blocks or in the slices) and two-pass (exact slices) incidence builds must give the same supports and trussness."""
     uv = K.gen_hug_edges(40000, 110000, 2.3, 21)
     with K.KombAccel() as a:
         a.from_edges(40000, uv)
@@ -236,6 +236,17 @@ def test_index_layouts_agree(K, O, monkeypatch):
         monkeypatch.delenv("KOMB_OFF64", raising=False)
         for x, y in zip(r1, r3):
             assert np.array_equal(x, y)
+        # own-role entries kept in the bounded slices instead of the dense per-task blocks (what a run without the
+        # memory for the dense region does, and what a task with more triangles than its record buffer does)
+        for off64 in (False, True):
+            monkeypatch.setenv("KOMB_NO_OWN_DENSE", "1")
+            if off64:
+                monkeypatch.setenv("KOMB_OFF64", "1")
+            r4 = a.run_truss(with_support=True)
+            monkeypatch.delenv("KOMB_NO_OWN_DENSE", raising=False)
+            monkeypatch.delenv("KOMB_OFF64", raising=False)
+            for x, y in zip(r1, r4):
+                assert np.array_equal(x, y)
         rowptr, col = a.get_csr()
         assert np.array_equal(r1[2], O.trussness(rowptr, col))
 
@@ -504,7 +515,7 @@ def _local_cases(K):
     cases.append(("hub", 150001, np.concatenate([star, ring, np.stack(np.triu_indices(40, 1), axis=1) + 1]).astype(np.int64)))
     # books: a spine edge with k pages (k triangles on one edge: light below 256, heavy above, two histogram
     # passes from 4096 on), plus a clique on some pages to keep several levels alive
-    for k in (255, 256, 257, 700, 5000):
+    for k in (255, 256, 257, 700, 5000, 20000):      # 20000: the spine edge is counted in three chunks by three workgroups
         pages = np.arange(2, k + 2)
         uv = np.concatenate([[[0, 1]], np.stack([np.zeros(k, int), pages], 1), np.stack([np.ones(k, int), pages], 1),
                              np.stack(np.triu_indices(12, 1), axis=1) + 2])
@@ -553,5 +564,16 @@ def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
                     assert st["truss_local_units"] == int((sup > 0).sum()), name
                     assert st["truss_levels"] == len(np.unique(want_tr)), name
             assert ran_core > 0 and (ran_truss > 0 or want_tr.max() <= 2), name
+            # a remainder with more items than the limit is refused: the peel goes on and offers a smaller one later
+            for items in ("0", "3000"):
+                monkeypatch.setenv("KOMB_LOCAL_ITEMS", items)
+                for limit in ("4000000000", "20000"):
+                    monkeypatch.setenv("KOMB_LOCAL_LIMIT", limit)
+                    assert np.array_equal(a.run_core()[1], want_core), (name, items, limit)
+                    assert np.array_equal(a.run_truss()[2], want_tr), (name, items, limit)
+                    st = a.stats()
+                    assert st["truss_local_items"] <= int(items) and st["core_local_items"] <= int(items), (name, items, limit)
+            monkeypatch.delenv("KOMB_LOCAL_ITEMS", raising=False)
     monkeypatch.delenv("KOMB_LOCAL_LIMIT", raising=False)
+    monkeypatch.delenv("KOMB_LOCAL_ITEMS", raising=False)
     monkeypatch.delenv("KOMB_FINISH", raising=False)
