@@ -377,26 +377,31 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             n_tri = 0;
         };
 
-        // ---- staged sub-range.  A triangle's own-role cursors are LDS atomics; its third-role entry is written at once
-        // (one returning global atomic + one store); its own-role entries wait in the record buffer:
-        // record = (e_rel | i_rel << 8 | cursor_e << 16 | cursor_i << 24, j).
-        uint32_t n_rec = 0;                                     // wave-uniform
-        bool spilled = false;                                   // wave-uniform: the own-role entries of this sub-range go to the slices
-        auto flush_recs_to_slices = [&]() {                     // own-role entries -> inc[off[edge] + cursor]
+        // ---- staged sub-range.  A triangle's own-role cursors are LDS atomics taken when it is found; the rest waits in
+        // the record buffer: record = (e_rel | i_rel << 8 | cursor_e << 16 | cursor_i << 24, j).  The records are worked off
+        // densely, 64 per pass (`drain`): the third-role entry (one returning global atomic + one store) and -- when the
+        // own-role entries go to the slices (exact slices, or a DENSE sub-range that has spilled) -- the two own-role stores.
+        // A DENSE sub-range keeps its records until it is done.
+        uint32_t n_rec = 0, n_done = 0;                         // wave-uniform: records, records whose third role is written
+        bool spilled = !DENSE;                                  // wave-uniform: own-role entries go to inc[off[edge] + cursor]
+        auto drain = [&](uint32_t lo, uint32_t hi, bool third, bool own_role) {
             __builtin_amdgcn_wave_barrier();
-            if (MODE == TRI_SINGLE && !(ablate & 16)) {
-                for (uint32_t b0 = 0; b0 < n_rec; b0 += kWave) {
-                    const uint32_t x = b0 + (uint32_t)lane;
-                    if (x < n_rec) {
-                        const uint2 rc = s_rec[x];
-                        const uint32_t e = S0 + (rc.x & 0xFFu), i = S0 + ((rc.x >> 8) & 0xFFu);
-                        inc[off[e] + ((rc.x >> 16) & 0xFFu)] = make_int2((int)i, (int)rc.y);
-                        inc[off[i] + (rc.x >> 24)] = make_int2((int)e, (int)rc.y);
+            if (MODE == TRI_SINGLE) for (uint32_t b0 = lo; b0 < hi; b0 += kWave) {
+                const uint32_t x = b0 + (uint32_t)lane;
+                if (x < hi) {
+                    const uint2 rc = s_rec[x];
+                    const uint32_t e = S0 + (rc.x & 0xFFu), i = S0 + ((rc.x >> 8) & 0xFFu), jj = rc.y;
+                    if (third && !(ablate & 32)) {
+                        const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                        inc[pj] = make_int2((int)e, (int)i);
+                    }
+                    if (own_role && !(ablate & 16)) {
+                        inc[off[e] + ((rc.x >> 16) & 0xFFu)] = make_int2((int)i, (int)jj);
+                        inc[off[i] + (rc.x >> 24)] = make_int2((int)e, (int)jj);
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            n_rec = 0;
         };
 
         // probes that pass the signature test are parked and looked up densely, 64 at a time
@@ -430,27 +435,24 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 if (hit) {
                     const uint32_t ce = atomicAdd(&s_cnt[e_rel], 1u), ci = atomicAdd(&s_cnt[l], 1u);
                     if (MODE == TRI_COUNT) atomicAdd(&other_or_cursor[jj], 1u);
-                    else {
-                        const uint32_t e = S0 + e_rel, i = S0 + l;
-                        if (!(ablate & 32)) {
-                            const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
-                            inc[pj] = make_int2((int)e, (int)i);
-                        }
-                        if (spilled) {
-                            if (!(ablate & 16)) {
-                                inc[off[e] + ce] = make_int2((int)i, (int)jj);
-                                inc[off[i] + ci] = make_int2((int)e, (int)jj);
-                            }
-                        } else s_rec[n_rec + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint2(e_rel | (l << 8) | (ce << 16) | (ci << 24), jj);
-                    }
+                    else s_rec[n_rec + (uint32_t)__popcll(hm & lanemask_lt())] = make_uint2(e_rel | (l << 8) | (ce << 16) | (ci << 24), jj);
                 }
-                if (MODE == TRI_SINGLE && !spilled) {
+                if (MODE == TRI_SINGLE) {
                     n_rec += (uint32_t)__popcll(hm);
+                    if (n_rec - n_done >= (uint32_t)kWave) {                 // 64 or more are waiting: one dense pass over all of them
+                        drain(n_done, n_rec, true, spilled);
+                        n_done = n_rec;
+                    }
                     if (n_rec > (uint32_t)kTriRec - kWave) {
-                        // more triangles than the buffer holds.  DENSE: the whole sub-range goes to the slices from here
-                        // on; otherwise the destination is the same anyway
-                        flush_recs_to_slices();
-                        if (DENSE) { spilled = true; if (lane == 0) atomicAdd(dense_cursor + 1, 1ull); }     // statistics
+                        // the buffer is full.  A DENSE sub-range gives up its block: everything kept so far, and what follows,
+                        // goes to the slices
+                        if (DENSE && !spilled) {
+                            drain(n_done, n_rec, true, false);
+                            drain(0, n_rec, false, true);
+                            spilled = true;
+                            if (lane == 0) atomicAdd(dense_cursor + 1, 1ull);     // statistics
+                        } else drain(n_done, n_rec, true, true);
+                        n_rec = 0; n_done = 0;
                     }
                 }
             }
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             continue;
         }
         search_cands();
+        if (MODE == TRI_SINGLE) { drain(n_done, n_rec, true, spilled); n_done = n_rec; }
         if (MODE == TRI_SINGLE && DENSE && !spilled) {
             // the own-role entries of this sub-range as one block of `dense`: exclusive prefix of the cursors (into s_col,
             // which is done with), a claim on the wavefront's chunk, the offsets, the entries
@@ -585,7 +588,6 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 }
             }
         } else {
-            if (MODE == TRI_SINGLE) flush_recs_to_slices();
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
                 own[S0 + k] = s_cnt[k];
