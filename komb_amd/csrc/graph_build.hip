@@ -122,8 +122,8 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
     graph_free(ctx);
     if (nv < 0 || nv > INT32_MAX - 1 || n_raw < 0 || (n_raw > 0 && !uv))
         KOMB_FAIL(ctx, KOMB_ERR_ARG, "graph_from_edges: bad nv=%lld n_raw=%lld", (long long)nv, (long long)n_raw);
-    if (2 * n_raw > INT32_MAX)
-        KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph_from_edges: %lld raw pairs exceed the 2^30 design limit", (long long)n_raw);
+    if (n_raw > (int64_t)1 << 36)                        // (what bounds a graph is its simple form: 2^32-16 slots, checked below)
+        KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph_from_edges: %lld raw pairs", (long long)n_raw);
     hipStream_t s = ctx->stream;
     Range r_all("komb_graph_from_edges");
     ctx->timer.start(s);

@@ -20,13 +20,13 @@ struct TempBuf {                             // scratch from the context's cachi
 
 int prim_sort_u64(komb_ctx *ctx, uint64_t *keys, uint64_t *tmp_keys, int64_t n, int end_bit, uint64_t **sorted)
 {
-    if (n > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "sort: %lld keys exceed the 2^31-1 primitive limit", (long long)n);
+    // (64-bit item counts: the raw pair list of a graph near the 2^32-slot limit has more than 2^31 keys)
     hipcub::DoubleBuffer<uint64_t> db(keys, tmp_keys);
     size_t bytes = 0;
-    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, db, (int)n, 0, end_bit, ctx->stream));
+    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, db, (long long)n, 0, end_bit, ctx->stream));
     TempBuf t(ctx);
     KOMB_HIP(ctx, t.get(bytes));
-    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(t.p, bytes, db, (int)n, 0, end_bit, ctx->stream));
+    KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(t.p, bytes, db, (long long)n, 0, end_bit, ctx->stream));
     KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *sorted = db.Current();
     return KOMB_OK;
@@ -34,16 +34,15 @@ int prim_sort_u64(komb_ctx *ctx, uint64_t *keys, uint64_t *tmp_keys, int64_t n, 
 
 int prim_unique_u64(komb_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, int64_t *n_out)
 {
-    if (n > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "unique: %lld keys exceed the 2^31-1 primitive limit", (long long)n);
-    int *d_num = nullptr;
-    KOMB_HIP(ctx, hipMalloc(&d_num, sizeof(int)));
+    long long *d_num = nullptr;
+    KOMB_HIP(ctx, hipMalloc(&d_num, sizeof(long long)));
     size_t bytes = 0;
-    hipError_t e = hipcub::DeviceSelect::Unique(nullptr, bytes, in, out, d_num, (int)n, ctx->stream);
+    hipError_t e = hipcub::DeviceSelect::Unique(nullptr, bytes, in, out, d_num, (int64_t)n, ctx->stream);
     TempBuf t(ctx);
     if (e == hipSuccess) e = t.get(bytes);
-    if (e == hipSuccess) e = hipcub::DeviceSelect::Unique(t.p, bytes, in, out, d_num, (int)n, ctx->stream);
-    int h = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_num, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipcub::DeviceSelect::Unique(t.p, bytes, in, out, d_num, (int64_t)n, ctx->stream);
+    long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_num, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_num);
     KOMB_HIP(ctx, e);
