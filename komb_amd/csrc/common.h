@@ -125,6 +125,11 @@ inline uint64_t local_item_limit(uint64_t dflt)
     if (const char *e = getenv("KOMB_LOCAL_ITEMS")) return strtoull(e, nullptr, 10);
     return dflt;
 }
+inline uint32_t local_density_limit(uint32_t dflt)          // items per unit above which a remainder stays with the peel (0 = no rule)
+{
+    if (const char *e = getenv("KOMB_LOCAL_DENSITY")) return (uint32_t)strtoul(e, nullptr, 10);
+    return dflt;
+}
 inline uint32_t local_limit(uint64_t units, uint64_t divisor)
 {
     uint64_t l = units / divisor;

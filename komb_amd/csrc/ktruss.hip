@@ -817,6 +817,9 @@ struct TrussCollect {
 // Fixed-point problem: item = a live triangle, value = the smaller bound of its other two edges.
 // remainders with more live triangle entries than this stay with the peel (see local_item_limit)
 constexpr uint64_t kTrussLocalItems = 32ull << 20;
+// ... and so do remainders with more live triangles per edge than this (measured: 24 at C3 and 105 on the alpha = 2.3 shape
+// gain 2 and 9 ms, 280 on the alpha = 2.1 shape loses 4)
+constexpr uint32_t kTrussLocalDensity = 160;
 struct TrussLocal {
     static constexpr int kU = 8;         // light unit: <= 512 live triangles (one batch = 64 lanes x 8 values)
 #ifndef KOMB_TRUSS_GROUPS
@@ -1270,7 +1273,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         (void)hipEventRecord(ev[0], s);
         LocalStats ls;
         const int lrc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)m, d_stamp, d_sup, Q.live[hc.live_sel],
-            (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), local_item_limit(kTrussLocalItems), 2, d_truss,
+            (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), local_item_limit(kTrussLocalItems), local_density_limit(kTrussLocalDensity), 2, d_truss,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 TrussCollect C{(uint32_t)m, d_off, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
                 k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);

@@ -42,6 +42,9 @@ with komb_amd.KombAccel() as a:
         os.environ["KOMB_LOCAL_LIMIT"] = str(rng.choice([0, 40, 900, 20000, 4000000000]))
         os.environ["KOMB_TAIL"] = str(rng.choice([0, 50, 700, 5000, 32768, 65534]))
         os.environ["KOMB_CORE_TAIL"] = str(rng.choice([0, 9, 200, 1024]))
+        dens = str(rng.choice(["", "0", "3", "40"]))                     # density rule of the k-truss local finish ("" = default 160, 0 = off)
+        if dens: os.environ["KOMB_LOCAL_DENSITY"] = dens
+        else: os.environ.pop("KOMB_LOCAL_DENSITY", None)
         items = str(rng.choice(["", "0", "60", "5000", "200000"]))       # item limit of the local finish ("" = the default): small ones exercise the refusal
         if items: os.environ["KOMB_LOCAL_ITEMS"] = items
         else: os.environ.pop("KOMB_LOCAL_ITEMS", None)

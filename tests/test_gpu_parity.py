@@ -540,6 +540,7 @@ def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
             st = a.stats()
             assert st["core_local_units"] == 0 and st["truss_local_units"] == 0
             monkeypatch.setenv("KOMB_FINISH", "local")
+            monkeypatch.setenv("KOMB_LOCAL_DENSITY", "0")                 # take every remainder, however dense
             ran_core = ran_truss = 0
             for limit in ("4000000000", None, "20000", "1500", "100"):
                 if limit is None:
@@ -574,6 +575,13 @@ def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
                     st = a.stats()
                     assert st["truss_local_items"] <= int(items) and st["core_local_items"] <= int(items), (name, items, limit)
             monkeypatch.delenv("KOMB_LOCAL_ITEMS", raising=False)
+            # default density rule: a remainder with more than 160 triangles per edge stays with the peel for good
+            monkeypatch.delenv("KOMB_LOCAL_DENSITY", raising=False)
+            monkeypatch.setenv("KOMB_LOCAL_LIMIT", "4000000000")
+            assert np.array_equal(a.run_truss()[2], want_tr), name
+            st = a.stats()
+            assert st["truss_local_units"] == 0 or st["truss_local_items"] <= 160 * st["truss_local_units"], name
     monkeypatch.delenv("KOMB_LOCAL_LIMIT", raising=False)
     monkeypatch.delenv("KOMB_LOCAL_ITEMS", raising=False)
+    monkeypatch.delenv("KOMB_LOCAL_DENSITY", raising=False)
     monkeypatch.delenv("KOMB_FINISH", raising=False)
