@@ -11,6 +11,13 @@ HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 N=1 workload = BASELINE.json configs[2] (|V|=10M, |E|~100M, full k-truss, the
 configuration the metric is quoted on).  --config c2 selects configs[1]
 (|V|=1M, |E|~10M); the k-core time of the same graph is reported alongside.
+
+N>1: every rank decomposes a graph of its own (the same generator, seed + rank)
+on its own GPU -- KOMB's one-graph-per-sample shape; nothing is exchanged on the
+data path, `value` = the edges of all the ranks' graphs / the slowest rank's time,
+"scaling": "weak".  One decomposition does not shard profitably (DESIGN.md section
+6): --same-graph [--shard] run the same graph on every rank as replicas / with the
+support count sharded + one all-reduce ("strong"), for the record.
 """
 import argparse
 import json
