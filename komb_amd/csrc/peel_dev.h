@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
         // one 16-byte vector each, and stores the four classification bytes as one word.
         const bool vec = !from_list && !Q.scalar_scan;
         const int32_t *s_marker = p.scan_marker(), *s_key = p.scan_key();
-        uint32_t n_light = 0, n_chunks = 0, n_hits = 0, n_surv = 0;   // n_chunks per lane, others wave-uniform
+        uint32_t n_light = 0, n_chunks = 0, n_hits = 0, n_surv = 0;   // per lane until the sums after the sweep
         int32_t lmin = 0x7FFFFFFF;
         const uint64_t tile = (uint64_t)kPeelBlock * kScanU;
         auto index_of = [&](uint64_t tb, int k) -> uint64_t {
@@ -422,12 +422,14 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
             for (int k = 0; k < kScanU; ++k) {
                 const uint64_t idx = index_of(tb, k);
                 if (!whole && idx < n_in) Q.code[idx] = code[k];      // pass B reads this byte instead of the unit's state
-                const bool hit = code[k] == SC_LIGHT || code[k] == SC_HEAVY;
-                n_light += (uint32_t)__popcll(__ballot(code[k] == SC_LIGHT));
-                n_hits += (uint32_t)__popcll(__ballot(hit));
-                if (emit) n_surv += (uint32_t)__popcll(__ballot(code[k] == SC_SURVIVOR));
+                // per-lane tallies, summed over the wavefront once at the end (three ballots + popcounts per unit made the
+                // sweep issue-bound: ~190 instructions per 64 units, 1.6 TB/s)
+                n_light += code[k] == SC_LIGHT ? 1u : 0u;
+                n_hits += (code[k] == SC_LIGHT || code[k] == SC_HEAVY) ? 1u : 0u;
+                n_surv += (emit && code[k] == SC_SURVIVOR) ? 1u : 0u;
             }
         }
+        n_light = wave_sum(n_light); n_hits = wave_sum(n_hits); n_surv = wave_sum(n_surv);
         n_chunks = wave_sum(n_chunks);
         lmin = wave_min(lmin);
         if (lane == 0) { sh_w[w][0] = n_light; sh_w[w][1] = n_chunks; sh_w[w][2] = n_hits; sh_w[w][3] = n_surv; sh_min[w] = lmin; }
