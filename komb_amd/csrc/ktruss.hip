@@ -240,7 +240,10 @@ __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ 
 #ifndef KOMB_TRI_CAND
 #define KOMB_TRI_CAND 128
 #endif
-constexpr int kTriV = 16;
+#ifndef KOMB_TRI_V
+#define KOMB_TRI_V 16
+#endif
+constexpr int kTriV = KOMB_TRI_V;               // consecutive source vertices per task (<= 63: lane l holds orow[v0 + l])
 constexpr int kTriCap = KOMB_TRI_CAP;
 constexpr int kTriR = 4;                       // consecutive elements of one row N+(b) a lane probes per trip (one 16-byte load)
 struct __attribute__((packed, aligned(4))) Int4U { int32_t x, y, z, w; };      // 16 bytes at a 4-byte aligned address
