@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
                                                       const OffT *__restrict__ off, int2 *__restrict__ inc,
-                                                      int2 *__restrict__ dense, unsigned long long *dense_cursor,
+                                                      int2 *__restrict__ dense, unsigned long long *dense_cursor, unsigned long long dense_cap,
                                                       unsigned long long *__restrict__ ownoff, int ablate)
 {
     // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all,
@@ -553,7 +553,9 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
         }
         search_cands();
         if (MODE == TRI_SINGLE) { drain(n_done, n_rec, true, spilled); n_done = n_rec; }
-        if (MODE == TRI_SINGLE && DENSE && !spilled) {
+        bool to_dense = MODE == TRI_SINGLE && DENSE && !spilled;     // wave-uniform
+        unsigned long long base = 0;
+        if (to_dense) {
             // the own-role entries of this sub-range as one block of `dense`: exclusive prefix of the cursors (into s_col,
             // which is done with), a claim on the wavefront's chunk, the offsets, the entries
             __builtin_amdgcn_wave_barrier();
@@ -565,7 +567,6 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 if (k < E) s_col[k] = (int32_t)(run + ic - c);
                 run += (uint32_t)__shfl((int)ic, kWave - 1);
             }
-            unsigned long long base = 0;
             if (run) {
                 if (chunk_pos + run > chunk_end) {               // (wave-uniform) the block does not fit what is left of the chunk
                     const uint32_t want = run > kOwnChunk ? run : kOwnChunk;
@@ -575,10 +576,17 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                     const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
                     chunk_pos = ((unsigned long long)ghi << 32) | glo;
                     chunk_end = chunk_pos + want;
+                    if (chunk_end > dense_cap) {
+                        // the region is sized by a bound on the entries plus a share for the chunks' unused tails; blocks of
+                        // an unlucky size in a graph that meets the bound can exceed it: this sub-range goes to the slices
+                        to_dense = false;
+                        chunk_pos = 0; chunk_end = 0;
+                    }
                 }
-                base = chunk_pos;
-                chunk_pos += run;
+                if (to_dense) { base = chunk_pos; chunk_pos += run; }
             }
+        }
+        if (to_dense) {
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { own[S0 + k] = s_cnt[k]; ownoff[S0 + k] = base + (uint32_t)s_col[k]; }
             if (!(ablate & 16)) for (uint32_t b0 = 0; b0 < n_rec; b0 += kWave) {
@@ -591,6 +599,7 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 }
             }
         } else {
+            if (MODE == TRI_SINGLE && DENSE && !spilled) drain(0, n_rec, false, true);      // no room in the region: own-role entries of every record to the slices
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
                 own[S0 + k] = s_cnt[k];
@@ -1065,7 +1074,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, d2h(ctx, cap_both, d_mom + 6, sizeof(cap_both)));
         const unsigned long long cap_total = cap_both[0];
         // dense own-role region: the bound, + what the wavefronts' chunked claims can leave unused
-        const unsigned long long own_cap = cap_both[1] + cap_both[1] / 8 + (unsigned long long)gt * kTriWaves * kOwnChunk + kOwnChunk;
+        unsigned long long own_cap = cap_both[1] + cap_both[1] / 8 + (unsigned long long)gt * kTriWaves * kOwnChunk + kOwnChunk;
+        if (const char *oc = getenv("KOMB_OWN_DENSE_CAP")) own_cap = strtoull(oc, nullptr, 10) + 1;      // (tests: a region that runs out)
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         if (cap_total * sizeof(int2) > (unsigned long long)(free_b * 0.8)) single = false;
@@ -1093,12 +1103,12 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
         if (single) {
             if (d_offc64) {
-                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, d_ownoff, ablate);
-                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, nullptr, ablate);
+                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate);
+                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate);
             } else {
                 k_back_cursors<<<ge, kBlock, 0, s>>>(d_offc, m, d_other);
-                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, d_ownoff, ablate);
-                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, nullptr, ablate);
+                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate);
+                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate);
             }
 #ifdef KOMB_TRI_PROFILE
             {
@@ -1126,7 +1136,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (!single) {
         const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
         ctx->timer.start(s);
-        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, nullptr, ablate);
+        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate);
         st.ms_tri_count = ctx->timer.stop(s);
     }
     k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, (single && !d_offc64) ? d_offc : nullptr, m + 1, d_cnt, d_mom + 5);
@@ -1183,7 +1193,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         // entries from the front and third-role entries from the back meet precisely -- no compaction
         ctx->timer.start(s);
         k_back_cursors<<<ge, kBlock, 0, s>>>(d_off, m, d_other);
-        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, nullptr, ablate);
+        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, 0ull, nullptr, ablate);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;

@@ -238,6 +238,12 @@ def test_index_layouts_agree(K, O, monkeypatch):
             assert np.array_equal(x, y)
         # own-role entries kept in the bounded slices instead of the dense per-task blocks (what a run without the
         # memory for the dense region does, and what a task with more triangles than its record buffer does)
+        # a dense region that runs out half way: the tasks that find no room fall back to the slices one by one
+        monkeypatch.setenv("KOMB_OWN_DENSE_CAP", "70000")
+        r5 = a.run_truss(with_support=True)
+        monkeypatch.delenv("KOMB_OWN_DENSE_CAP", raising=False)
+        for x, y in zip(r1, r5):
+            assert np.array_equal(x, y)
         for off64 in (False, True):
             monkeypatch.setenv("KOMB_NO_OWN_DENSE", "1")
             if off64:
