@@ -257,6 +257,36 @@ def test_index_layouts_agree(K, O, monkeypatch):
         assert np.array_equal(r1[2], O.trussness(rowptr, col))
 
 
+def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
+    """A graph whose capacity-bounded slices hold more than 2^32 entries by themselves (dense uniform random, 30 000
+    vertices, ~12.5 M edges of degree ~830: sum over edges of d(lower endpoint) - 1 ~ 1e10), so the single pass runs with
+    64-bit slice offsets without KOMB_OFF64.  Checked against the two-pass index (exact slices, 32-bit offsets) and through
+    the size-independent properties; the oracle would need minutes here."""
+    rng = np.random.default_rng(77)
+    nv = 30000
+    uv = rng.integers(0, nv, (12_600_000, 2)).astype(np.int64)
+    for k in ("KOMB_OFF64", "KOMB_TWO_PASS", "KOMB_NO_OWN_DENSE"):
+        monkeypatch.delenv(k, raising=False)
+    with K.KombAccel() as a:
+        a.from_edges(nv, uv)
+        del uv
+        deg, core = a.run_core()
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        st = a.stats()
+        lower = np.minimum(deg[eu], deg[ev])                                # d(a) of the lower-(degree, id) endpoint a
+        assert int((lower.astype(np.int64) - 1).sum()) > 2**32           # the bound the slices are sized by, beyond 32 bits
+        assert st["ms_tri_count"] == 0 and st["ms_compact"] > 0             # ... and still the single pass
+        assert sup.sum(dtype=np.int64) == 3 * st["triangles"]
+        assert np.all(tr >= 2) and np.all(tr <= sup + 2)
+        assert np.all(np.minimum(core[eu], core[ev]) >= tr - 1)
+        monkeypatch.setenv("KOMB_TWO_PASS", "1")
+        r2 = a.run_truss(with_support=True)
+        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+        assert a.stats()["ms_tri_count"] > 0
+        for x, y in zip((eu, ev, tr, sup), r2):
+            assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("two_pass", [False, True])
 def test_cliques_and_hubs(K, O, monkeypatch, two_pass):
     """Complete graphs: long oriented rows (the LDS staging falls back to global search), every
