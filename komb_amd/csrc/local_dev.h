@@ -38,7 +38,7 @@ constexpr int kLocWaves = kLocBlock / kWave;
 constexpr int kLocHB = 4096;                   // histogram bins of the heavy path
 constexpr int kLocBins = kLocHB / kLocBlock;   // bins per thread in the suffix search
 constexpr int kCntWays = 8;                    // per-sweep counters are spread over this many 128-byte lines
-constexpr int kCntWords = (5 * kCntWays + 3) * 32;   // 4 ring slots of change counters + 1 of evaluation counters, 3 queue heads
+constexpr int kCntWords = (5 * kCntWays + 5) * 32;   // 4 ring slots of change counters + 1 of evaluation counters, 3 queue heads, 2 list lengths
 constexpr int kCntTimerWords = 6 * 12 * 2;     // -DKOMB_LOCAL_TIMERS: 6 sweeps x 12 64-bit stopwatch sums behind the counters
 constexpr int kHvU = 8;                        // items per thread per trip on the workgroup path (independent load chains)
 constexpr uint32_t kKeyBins = 4096;            // histogram of the live keys at hand-over (bound on the largest level)
@@ -61,6 +61,7 @@ struct LocalGraph {                            // the compacted remainder
     uint32_t nchunk;
     unsigned long long *gacc;    // [ng] (chunks arrived << 32) | items >= value so far, this sweep
     uint32_t *khist;         // [kKeyBins] how many units have live key k (the last bin: k >= kKeyBins - 1)
+    uint32_t *list;          // [n - nh] the light units marked for the sweep at hand, compacted by k_local_list just before it
 };
 
 // ---- 1. numbering.  `list` (or all `units` when null) holds the candidates; live = alive marker in `marker`;
@@ -175,6 +176,36 @@ static __global__ __launch_bounds__(kBlock) void k_local_check(LocalGraph g, Loc
     if (blockIdx.x == 0 && threadIdx.x == 0 && (ctrl->n_heavy != g.nh || ctrl->n_heavy + ctrl->n_light != g.n)) atomicAdd(&ctrl->bad, 1u);
 }
 
+// ---- the light units marked for sweep k, as a list (launched before every sweep).  A sweep that looks at the marks group by
+// group costs a batch's chain of dependent loads for every group with ONE marked unit in it -- a sweep with 10% of the
+// units marked took as long as a full one; from the list the cost follows the number of marked units and the wavefronts
+// share them evenly.  One reservation per workgroup; cnt[(5 * kCntWays + 3 + (k & 1)) * 32] = the list's length (zeroed
+// by the sweep before).
+constexpr int kListBlock = 1024;
+static __global__ __launch_bounds__(kListBlock) void k_local_list(uint32_t *cnt, LocalGraph g, int32_t k)
+{
+    __shared__ uint32_t sh_n[kListBlock / kWave];
+    __shared__ uint32_t sh_base;
+    const int32_t *mark_cur = g.mark[k & 1];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    uint32_t *tail = cnt + (5 * kCntWays + 3 + (k & 1)) * 32;
+    const uint32_t nlight = g.n - g.nh;
+    for (uint32_t i0 = blockIdx.x * kListBlock; i0 < nlight; i0 += gridDim.x * kListBlock) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool m = i < nlight && mark_cur[g.nh + i] == k;
+        const uint64_t bm = __ballot(m);
+        __syncthreads();
+        if (lane == 0) sh_n[w] = (uint32_t)__popcll(bm);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int x = 0; x < kListBlock / kWave; ++x) { const uint32_t c = sh_n[x]; if (x < w) before += c; total += c; }
+        if (threadIdx.x == 0) sh_base = total ? atomicAdd(tail, total) : 0u;
+        __syncthreads();
+        if (m) g.list[sh_base + before + (uint32_t)__popcll(bm & lanemask_lt())] = g.nh + i;
+    }
+}
+
 // ---- 3. one sweep.  Problem concept (all __device__):
 //   static constexpr int kU;                     values per lane of a light batch (light unit: <= 64 * kU items)
 //   static constexpr int kGroups;                light groups per wavefront aimed at (see the light path)
@@ -275,6 +306,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     __syncthreads();                                     // sh_pick and sh_m are reused below
     if (blockIdx.x == 0 && tid < (uint32_t)kCntWays) cnt[(((k + 1) & 3) * kCntWays + tid) * 32] = 0u;   // nobody reads or adds to that slot in this launch
     if (blockIdx.x == 0 && tid == 0) cnt[(5 * kCntWays + ((k + 1) % 3)) * 32] = 0u;                    // next sweep's queue of the longest units
+    if (blockIdx.x == 0 && tid == 1) cnt[(5 * kCntWays + 3 + ((k + 1) & 1)) * 32] = 0u;                // ... and the length of its list of marked light units
     uint32_t n_changed = 0, n_evals = 0;                 // meaningful in thread 0 (heavy) / lane 0 of each wave (light)
 #ifdef KOMB_LOCAL_TIMERS
     // per-wave stopwatch (100 MHz): [0] heavy-mark scan, [1] medium units, [2] workgroup units, [3] group setup (marks,
@@ -360,7 +392,8 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     // lane range.  The items of the few units that change are loaded again for the notification.
     uint32_t *s_end = sh_end[w];
     uint32_t (*s_a)[kWave] = sh_a[w];
-    const uint32_t nlight = g.n - g.nh;
+    // (a full sweep walks all light ids, any other the list k_local_list has just made of the marked ones)
+    const uint32_t nlight = full ? g.n - g.nh : cnt[(5 * kCntWays + 3 + (k & 1)) * 32];
     const uint32_t nw = gridDim.x * kLocWaves;
     uint32_t gsz = kWave;
     // at least P::kGroups groups per wavefront while groups stay >= 8 units (measured at C3: k-truss units are short, its
@@ -368,8 +401,9 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     while (gsz > 1 && (nlight + gsz - 1) / gsz < (gsz > 8 ? (uint32_t)P::kGroups : 1u) * nw) gsz >>= 1;      // a few groups per wavefront: the slowest wavefront sets the sweep's time
     const uint32_t ngrp = (nlight + gsz - 1) / gsz;
     for (uint32_t grp = blockIdx.x * kLocWaves + (uint32_t)w; grp < ngrp; grp += nw) {
-        const uint32_t u = g.nh + grp * gsz + (uint32_t)lane;
-        const bool act = (uint32_t)lane < gsz && u < g.n && (full || mark_cur[u] == k);
+        const uint32_t li = grp * gsz + (uint32_t)lane;
+        const bool act = (uint32_t)lane < gsz && li < nlight;
+        const uint32_t u = !act ? 0u : full ? g.nh + li : g.list[li];
         const uint64_t am = __ballot(act);
         if (!am) continue;
         const uint32_t na = (uint32_t)__popcll(am);
@@ -677,6 +711,8 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
 {
     hipStream_t s = ctx->stream;
     const int grid = 512;                                 // two 512-thread workgroups per CU (<= 96 VGPRs)
+    const uint32_t nlight_all = g.n - g.nh;
+    const int list_grid = (int)std::min<uint32_t>(256u, (nlight_all + kListBlock - 1) / kListBlock ? (nlight_all + kListBlock - 1) / kListBlock : 1u);
     hipEvent_t ev[2] = {nullptr, nullptr};
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
@@ -699,7 +735,9 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
     if (per_sweep) { sw.resize(1); (void)hipEventCreate(&sw[0]); (void)hipEventRecord(sw[0], s); }
     while (!finished && (uint64_t)launches < max_launches && k < 0x3FFFFFF0) {
         for (int i = 0; i < kLocBatch; ++i) {
-            ++k; k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, d_cnt, g, p, k, full_thr); ++launches;
+            ++k;
+            k_local_list<<<list_grid, kListBlock, 0, s>>>(d_cnt, g, k);
+            k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, d_cnt, g, p, k, full_thr); ++launches;
             if (per_sweep && sw.size() < 600) { hipEvent_t e2; (void)hipEventCreate(&e2); (void)hipEventRecord(e2, s); sw.push_back(e2); }
         }
         if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -771,6 +809,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, bufs.alloc(&g.mark[1], (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.gid, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.cur, (size_t)n));
+    KOMB_HIP(ctx, bufs.alloc(&g.list, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.giant, (size_t)n));                // at most n entries of 16 bytes; the pool hands out what is asked for
     KOMB_HIP(ctx, bufs.alloc(&g.khist, (size_t)kKeyBins));
     KOMB_HIP(ctx, hipMemsetAsync(g.khist, 0, kKeyBins * sizeof(uint32_t), s));
@@ -786,7 +825,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     void *d_items = nullptr;
     auto release_all = [&]() {
         bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
-        bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.giant); bufs.release(g.gchunk); bufs.release(g.gacc);
+        bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.list); bufs.release(g.giant); bufs.release(g.gchunk); bufs.release(g.gacc);
         bufs.release(g.khist); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cnt); bufs.release(d_cctrl); bufs.release(d_present);
     };
     g.n = n; g.nh = 0; g.ng = 0; g.nchunk = 0;
