@@ -43,6 +43,7 @@ constexpr int kCntTimerWords = 6 * 12 * 2;     // -DKOMB_LOCAL_TIMERS: 6 sweeps 
 constexpr int kHvU = 8;                        // items per thread per trip on the workgroup path (independent load chains)
 constexpr uint32_t kKeyBins = 4096;            // histogram of the live keys at hand-over (bound on the largest level)
 constexpr uint32_t kMedMax = 2048;             // heavy units up to this many items are evaluated by one wavefront (values staged in LDS)
+constexpr int kGiantWin = 8;                   // drops of at most this much are read off counters kept during the count: no second pass
 constexpr uint32_t kGiantChunk = 8192;              // the longest units are counted in chunks of this many items, a workgroup each
 constexpr int kLocBatch = 6;                   // launches queued between two looks at the control block
 
@@ -60,6 +61,8 @@ struct LocalGraph {                            // the compacted remainder
     uint4 *gchunk;           // [nchunk] {id, index in giant[], chunk of the unit, chunks of the unit}: the queue all workgroups share
     uint32_t nchunk;
     unsigned long long *gacc;    // [ng] (chunks arrived << 32) | items >= value so far, this sweep
+    uint32_t *gwin;          // [ng * kGiantWin] items with value == the unit's value - 1 - b, b = 0 .. kGiantWin-1, so far, this sweep
+    int4 *gnote;             // [ng] {new value, old value, sweep was full, sweep}: the notification a changed unit owes (k_local_giant_notify)
     uint32_t *khist;         // [kKeyBins] how many units have live key k (the last bin: k >= kKeyBins - 1)
     uint32_t *list;          // [n - nh] the light units marked for the sweep at hand, compacted by k_local_list just before it
 };
@@ -132,7 +135,8 @@ static __global__ __launch_bounds__(kBlock) void k_local_chunks(LocalGraph g)
     for (uint32_t gi = blockIdx.x; gi < g.ng; gi += gridDim.x) {
         const uint4 u = g.giant[gi];
         for (uint32_t j = threadIdx.x; j < u.z; j += kBlock) g.gchunk[u.y + j] = make_uint4(u.x, gi, j, u.z);
-        if (threadIdx.x == 0) g.gacc[gi] = 0ull;
+        if (threadIdx.x == 0) { g.gacc[gi] = 0ull; g.gnote[gi] = make_int4(0, 0, 0, 0); }
+        if (threadIdx.x < (uint32_t)kGiantWin) g.gwin[gi * kGiantWin + threadIdx.x] = 0u;
     }
 }
 
@@ -541,38 +545,76 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
             const uint32_t beg = g.off[hu], len = g.off[hu + 1] - beg;
             int32_t lo = 0, hi = cap - 1, H = cap;
             {
-                uint32_t ge = 0;
+                uint32_t ge = 0, wn[kGiantWin];
+#pragma unroll
+                for (int b = 0; b < kGiantWin; ++b) wn[b] = 0u;
                 const uint32_t c_end = min(len, (cj + 1u) * kGiantChunk);
                 for (uint32_t j0 = cj * kGiantChunk + tid; j0 < c_end; j0 += kHvU * kLocBlock) {      // kHvU independent load chains in flight
                     int32_t r[kHvU];
 #pragma unroll
                     for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; r[x] = j < c_end ? local_value(p, beg + j, g.val) : -1; }
 #pragma unroll
-                    for (int x = 0; x < kHvU; ++x) ge += r[x] >= cap ? 1u : 0u;
+                    for (int x = 0; x < kHvU; ++x) {
+                        ge += r[x] >= cap ? 1u : 0u;
+                        const uint32_t below = (uint32_t)(cap - 1 - r[x]);          // 0 .. kGiantWin-1: just under the unit's value
+#pragma unroll
+                        for (int b = 0; b < kGiantWin; ++b) wn[b] += below == (uint32_t)b ? 1u : 0u;
+                    }
                 }
                 ge = wave_sum(ge);
+#pragma unroll
+                for (int b = 0; b < kGiantWin; ++b) wn[b] = wave_sum(wn[b]);
                 __syncthreads();
-                if (lane == 0) sh_part[w] = ge;
+                if (lane == 0) {
+                    sh_part[w] = ge;
+#pragma unroll
+                    for (int b = 0; b < kGiantWin; ++b) sh_hist[w * kGiantWin + b] = wn[b];
+                }
                 __syncthreads();
-                if (tid == 0) {
-                    uint32_t mine = 0;
-                    for (int i = 0; i < kLocWaves; ++i) mine += sh_part[i];
-                    const unsigned long long old = atomicAdd(&g.gacc[gi], (1ull << 32) | (unsigned long long)mine);
-                    const bool last = (uint32_t)(old >> 32) == nch - 1u;
-                    if (last) g.gacc[gi] = 0ull;                 // every chunk of this sweep has arrived; the next use is the next launch
-                    sh_pick[3] = last ? (uint32_t)old + mine : 0xFFFFFFFFu;
+                if (w == 0) {
+                    // the window counters first, then -- once they are performed -- count and arrival in one 64-bit atomic
+                    if (lane < kGiantWin) {
+                        uint32_t t = 0;
+                        for (int i = 0; i < kLocWaves; ++i) t += sh_hist[i * kGiantWin + lane];
+                        if (t) atomicAdd(&g.gwin[gi * kGiantWin + (uint32_t)lane], t);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) {
+                        uint32_t mine = 0;
+                        for (int i = 0; i < kLocWaves; ++i) mine += sh_part[i];
+                        const unsigned long long old = atomicAdd(&g.gacc[gi], (1ull << 32) | (unsigned long long)mine);
+                        const bool last = (uint32_t)(old >> 32) == nch - 1u;
+                        if (last) g.gacc[gi] = 0ull;             // every chunk of this sweep has arrived; the next use is the next launch
+                        sh_pick[3] = last ? (uint32_t)old + mine : 0xFFFFFFFFu;
+                    }
                 }
                 __syncthreads();
                 const uint32_t c0 = sh_pick[3];
                 if (c0 == 0xFFFFFFFFu) continue;                 // another workgroup finishes this unit
                 if (tid == 0) ++n_evals;
+                // every chunk has arrived: the window counters are complete; take them (and leave zeros for the next sweep)
+                if (tid < (uint32_t)kGiantWin) sh_hist[tid] = atomicExch(&g.gwin[gi * kGiantWin + tid], 0u);
+                __syncthreads();
 #ifdef KOMB_LOCAL_EXP
                 if (KOMB_LOCAL_EXP & 1) continue;
 #endif
                 if (c0 >= (uint32_t)cap) continue;               // still has cap items >= cap: unchanged
                 lo = (int32_t)c0;                                // the c0 items >= cap are >= c0 as well
+                // a small drop is read off the window: count(items >= cap-1-b) = c0 + win[0..b]
+                {
+                    uint32_t run = c0;
+                    int32_t found = -1;
+                    for (int b = 0; b < kGiantWin && cap - 1 - b >= 0; ++b) {
+                        run += sh_hist[b];
+                        if (run >= (uint32_t)(cap - 1 - b)) { found = cap - 1 - b; break; }
+                    }
+                    __syncthreads();                             // (sh_hist is reused by the refinement)
+                    if (found >= 0) H = found;
+                    else hi = cap - 1 - kGiantWin;               // below the window
+                }
             }
-            for (;;) {
+            if (H == cap && hi < 0) H = 0;
+            while (H == cap) {
                 // histogram of the values in [lo, hi], `above` = values > hi, all from ONE pass over the items
                 const uint32_t width = (uint32_t)(hi - lo) + 1u;
                 int sh = 0;
@@ -632,15 +674,10 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 lo = nlo; hi = nhi;
                 if (sh == 0) { H = lo; break; }
             }
-            if (H < cap) {
-                if (tid == 0) { g.val[hu] = H; ++n_changed; }
-                if (!skip_notify) for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
-                    LocalNotify<P> nt[kHvU];
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len, full); }
-#pragma unroll
-                    for (int x = 0; x < kHvU; ++x) nt[x].store(mark_next, k);
-                }
+            if (H < cap && tid == 0) {
+                // the marks this drop owes are written by k_local_giant_notify, chunk by chunk, right after this launch
+                g.val[hu] = H; ++n_changed;
+                if (!skip_notify) g.gnote[gi] = make_int4(H, cap, full ? 1 : 0, k);
             }
         }
     }
@@ -664,6 +701,29 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
         uint32_t *mine = cnt + ((k & 3) * kCntWays + (blockIdx.x % kCntWays)) * 32;
         if (c) atomicAdd(mine, c);
         if (e) atomicAdd(cnt + (4 * kCntWays + (blockIdx.x % kCntWays)) * 32, e);
+    }
+}
+
+// ---- the notifications of the longest units that dropped in sweep k (launched after it when there are such units): a
+// workgroup per chunk, so a hub of 10^5 items marks its neighbours in microseconds instead of one workgroup's 50.
+template <class P>
+__global__ __launch_bounds__(kLocBlock) void k_local_giant_notify(LocalGraph g, P p, int32_t k)
+{
+    const int32_t *mark_cur = g.mark[k & 1];
+    int32_t *mark_next = g.mark[(k + 1) & 1];
+    for (uint32_t c = blockIdx.x; c < g.nchunk; c += gridDim.x) {
+        const uint4 ch = g.gchunk[c];                            // {id, index in giant[], chunk, chunks}
+        const int4 nt4 = g.gnote[ch.y];
+        if (nt4.w != k) continue;                                // (uniform: every thread read the same words)
+        const uint32_t beg = g.off[ch.x], len = g.off[ch.x + 1] - beg;
+        const uint32_t c_end = min(len, (ch.z + 1u) * kGiantChunk);
+        for (uint32_t j0 = ch.z * kGiantChunk + threadIdx.x; j0 < c_end; j0 += kHvU * kLocBlock) {
+            LocalNotify<P> nt[kHvU];
+#pragma unroll
+            for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; nt[x].load(p, beg + j, g.val, mark_cur, nt4.x, nt4.y, k, j < c_end, nt4.z != 0); }
+#pragma unroll
+            for (int x = 0; x < kHvU; ++x) nt[x].store(mark_next, k);
+        }
     }
 }
 
@@ -738,6 +798,7 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
             ++k;
             k_local_list<<<list_grid, kListBlock, 0, s>>>(d_cnt, g, k);
             k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, d_cnt, g, p, k, full_thr); ++launches;
+            if (g.nchunk) k_local_giant_notify<P><<<(int)std::min<uint32_t>(g.nchunk, 1024u), kLocBlock, 0, s>>>(g, p, k);
             if (per_sweep && sw.size() < 600) { hipEvent_t e2; (void)hipEventCreate(&e2); (void)hipEventRecord(e2, s); sw.push_back(e2); }
         }
         if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -825,7 +886,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     void *d_items = nullptr;
     auto release_all = [&]() {
         bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
-        bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.list); bufs.release(g.giant); bufs.release(g.gchunk); bufs.release(g.gacc);
+        bufs.release(g.mark[0]); bufs.release(g.mark[1]); bufs.release(g.gid); bufs.release(g.list); bufs.release(g.giant); bufs.release(g.gchunk); bufs.release(g.gacc); bufs.release(g.gwin); bufs.release(g.gnote);
         bufs.release(g.khist); bufs.release(g.cur); bufs.release(d_lctrl); bufs.release(d_cnt); bufs.release(d_cctrl); bufs.release(d_present);
     };
     g.n = n; g.nh = 0; g.ng = 0; g.nchunk = 0;
@@ -865,6 +926,8 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     if (g.ng) {
         KOMB_HIP(ctx, bufs.alloc(&g.gchunk, (size_t)g.nchunk));
         KOMB_HIP(ctx, bufs.alloc(&g.gacc, (size_t)g.ng));
+        KOMB_HIP(ctx, bufs.alloc(&g.gwin, (size_t)g.ng * kGiantWin));
+        KOMB_HIP(ctx, bufs.alloc(&g.gnote, (size_t)g.ng));
         k_local_chunks<<<(int)(g.ng > 1024u ? 1024u : g.ng), kBlock, 0, s>>>(g);
     }
     // K = h-index of the live keys: no level of the remainder is above it, so no value needs to start above it
