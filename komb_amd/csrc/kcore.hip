@@ -268,7 +268,7 @@ int core_run(komb_ctx *ctx)
         KOMB_HIP(ctx, hipMemsetAsync(d_livebits, 0, live_words * sizeof(unsigned long long), s));
         LocalStats ls;
         const int rc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)nv, ctx->d_core, d_degw, Q.live[hc.live_sel],
-            (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), local_item_limit(std::max<uint64_t>(kCoreLocalItems, (uint64_t)ctx->ne / 3)), 0u, 0, ctx->d_core,
+            (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), local_item_limit(std::max<uint64_t>(kCoreLocalItems, (uint64_t)ctx->ne / 3)), 0u, false, 0, ctx->d_core,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 CoreCollect C{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, ctx->d_core, d_livebits, num, lg.off, lg.cur, (uint32_t *)items};
                 k_peel_step<CoreCollect><<<grid, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);

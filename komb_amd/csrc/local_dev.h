@@ -65,7 +65,11 @@ struct LocalGraph {                            // the compacted remainder
     int4 *gnote;             // [ng] {new value, old value, sweep was full, sweep}: the notification a changed unit owes (k_local_giant_notify)
     uint32_t *khist;         // [kKeyBins] how many units have live key k (the last bin: k >= kKeyBins - 1)
     uint32_t *list;          // [n - nh] the light units marked for the sweep at hand, compacted by k_local_list just before it
+    uint32_t flags;          // kLocUseList: the sweeps read that list (else they walk the ids and test the marks);
+                             // kLocDeferNotify: a hub's notifications are written by k_local_giant_notify (else by the sweep itself)
 };
+constexpr uint32_t kLocUseList = 1u, kLocDeferNotify = 2u;
+constexpr uint32_t kLocDeferChunks = 256;        // hub chunks from which the notification kernel is used
 
 // ---- 1. numbering.  `list` (or all `units` when null) holds the candidates; live = alive marker in `marker`;
 // the live key is key[u].  Heavy units get ids from 0 up, light ones from n_live-1 down (the host knows n_live
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     uint32_t *s_end = sh_end[w];
     uint32_t (*s_a)[kWave] = sh_a[w];
     // (a full sweep walks all light ids, any other the list k_local_list has just made of the marked ones)
-    const uint32_t nlight = full ? g.n - g.nh : cnt[(5 * kCntWays + 3 + (k & 1)) * 32];
+    const bool walk = full || !(g.flags & kLocUseList);
+    const uint32_t nlight = walk ? g.n - g.nh : cnt[(5 * kCntWays + 3 + (k & 1)) * 32];
     const uint32_t nw = gridDim.x * kLocWaves;
     uint32_t gsz = kWave;
     // at least P::kGroups groups per wavefront while groups stay >= 8 units (measured at C3: k-truss units are short, its
@@ -406,8 +411,8 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
     const uint32_t ngrp = (nlight + gsz - 1) / gsz;
     for (uint32_t grp = blockIdx.x * kLocWaves + (uint32_t)w; grp < ngrp; grp += nw) {
         const uint32_t li = grp * gsz + (uint32_t)lane;
-        const bool act = (uint32_t)lane < gsz && li < nlight;
-        const uint32_t u = !act ? 0u : full ? g.nh + li : g.list[li];
+        const uint32_t u = (uint32_t)lane < gsz && li < nlight ? (walk ? g.nh + li : g.list[li]) : 0u;
+        const bool act = (uint32_t)lane < gsz && li < nlight && (full || !walk || mark_cur[u] == k);
         const uint64_t am = __ballot(act);
         if (!am) continue;
         const uint32_t na = (uint32_t)__popcll(am);
@@ -674,10 +679,20 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
                 lo = nlo; hi = nhi;
                 if (sh == 0) { H = lo; break; }
             }
-            if (H < cap && tid == 0) {
-                // the marks this drop owes are written by k_local_giant_notify, chunk by chunk, right after this launch
-                g.val[hu] = H; ++n_changed;
-                if (!skip_notify) g.gnote[gi] = make_int4(H, cap, full ? 1 : 0, k);
+            if (H < cap) {
+                if (tid == 0) {
+                    g.val[hu] = H; ++n_changed;
+                    // the marks this drop owes: written by k_local_giant_notify, chunk by chunk, right after this launch ...
+                    if (!skip_notify && (g.flags & kLocDeferNotify)) g.gnote[gi] = make_int4(H, cap, full ? 1 : 0, k);
+                }
+                // ... or, in a small remainder (where a third launch per sweep costs more than it saves), here
+                if (!skip_notify && !(g.flags & kLocDeferNotify)) for (uint32_t j0 = tid; j0 < len; j0 += kHvU * kLocBlock) {
+                    LocalNotify<P> nt[kHvU];
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) { const uint32_t j = j0 + (uint32_t)x * kLocBlock; nt[x].load(p, beg + j, g.val, mark_cur, H, cap, k, j < len, full); }
+#pragma unroll
+                    for (int x = 0; x < kHvU; ++x) nt[x].store(mark_next, k);
+                }
             }
         }
     }
@@ -796,9 +811,9 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
     while (!finished && (uint64_t)launches < max_launches && k < 0x3FFFFFF0) {
         for (int i = 0; i < kLocBatch; ++i) {
             ++k;
-            k_local_list<<<list_grid, kListBlock, 0, s>>>(d_cnt, g, k);
+            if (g.flags & kLocUseList) k_local_list<<<list_grid, kListBlock, 0, s>>>(d_cnt, g, k);
             k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, d_cnt, g, p, k, full_thr); ++launches;
-            if (g.nchunk) k_local_giant_notify<P><<<(int)std::min<uint32_t>(g.nchunk, 1024u), kLocBlock, 0, s>>>(g, p, k);
+            if (g.nchunk && (g.flags & kLocDeferNotify)) k_local_giant_notify<P><<<(int)std::min<uint32_t>(g.nchunk, 1024u), kLocBlock, 0, s>>>(g, p, k);
             if (per_sweep && sw.size() < 600) { hipEvent_t e2; (void)hipEventCreate(&e2); (void)hipEventRecord(e2, s); sw.push_back(e2); }
         }
         if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -842,7 +857,7 @@ struct LocalStats {
 // (k-core builds its bitmap of live vertices there).
 template <class LaunchCollect, class RunFix, class AfterNumber>
 int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_ctrl, uint32_t units, const int32_t *marker,
-                 const int32_t *key, const int32_t *live_list, uint32_t light_max, size_t item_bytes, uint64_t item_limit, uint32_t max_density, int32_t add, int32_t *out,
+                 const int32_t *key, const int32_t *live_list, uint32_t light_max, size_t item_bytes, uint64_t item_limit, uint32_t max_density, bool use_list, int32_t add, int32_t *out,
                  LaunchCollect &&launch_collect, RunFix &&run_fix, LocalStats *ls, AfterNumber &&after_number)
 {
     hipStream_t s = ctx->stream;
@@ -923,6 +938,14 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     g.nh = hl.n_heavy;
     g.ng = hl.n_giant;
     g.nchunk = hl.n_chunk;
+    // The list and the hubs' notification kernel are one more launch per sweep each (~5 us).  Measured at C2 / C3: the list
+    // takes 0.3 ms off the k-truss fixed point at both sizes and adds 0.1-0.2 ms to k-core's (its units are long: few
+    // groups have a single marked unit); the notification kernel pays where hubs are many (k-core at C3: 235 of them in
+    // ~600 chunks, -0.13 ms; 3 x C3: -2.4 ms) and costs 0.2-0.4 ms where they are few (C2, k-truss).
+    g.flags = (use_list ? kLocUseList : 0u) | (g.nchunk >= kLocDeferChunks ? kLocDeferNotify : 0u);
+#ifdef KOMB_DEBUG_SWITCHES
+    if (const char *e = getenv("KOMB_LOCAL_MODE")) g.flags = (uint32_t)atoi(e);      // 1 = list, 2 = notification kernel
+#endif
     if (g.ng) {
         KOMB_HIP(ctx, bufs.alloc(&g.gchunk, (size_t)g.nchunk));
         KOMB_HIP(ctx, bufs.alloc(&g.gacc, (size_t)g.ng));
