@@ -1,3 +1,5 @@
+"""Debug: which HIP runtime libraries a process maps when torch is imported before / after libkomb_accel.so (the load-order
+note in INTEGRATION.md section C).  usage: hipmaps.py torch_first|komb_first"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 order = sys.argv[1] if len(sys.argv) > 1 else "torch_first"

@@ -1,3 +1,4 @@
+"""One line per bench.py JSON file given: value, ms/step (helper for comparing runs).  usage: summ.py file.json ..."""
 import json,sys
 for f in sys.argv[1:]:
     d=json.loads(open(f).read().strip().splitlines()[-1])
