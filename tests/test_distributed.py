@@ -53,3 +53,26 @@ def test_processes_sharing_one_gpu(built):
     depend on when they start (this caught stale-state steps before every launch carried its index)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "share_stress.py"), "2", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rc [0, 0]" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--same-graph"], ["--same-graph", "--shard"]])
+def test_bench_two_ranks_on_one_gpu(built, extra):
+    """`python bench.py --gpus 2` started plainly: it spawns its two ranks itself (before anything has touched the GPU) and
+    rank 0 prints the one JSON line.  Both ranks share GPU 0 here (KOMB_BENCH_ONE_DEVICE=1, exchange over gloo).  Default:
+    one graph per rank, nothing exchanged, weak scaling; --same-graph: replicas; --same-graph --shard: the sharded support
+    count + all-reduce."""
+    import json
+    env = dict(os.environ, KOMB_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-build"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["metric"].startswith("peeled edges/sec")
+    assert d["scaling"] == ("strong" if extra else "weak")
+    par = d["config"]["parallelism"]
+    assert ("independent graphs" in par) if not extra else (("sharded" in par) if "--shard" in extra else ("replicas" in par))
+    assert "cpu_baseline" not in d                       # timed at N = 1 only
