@@ -190,8 +190,9 @@ static __global__ __launch_bounds__(kBlock) void k_local_check(LocalGraph g, Loc
 // share them evenly.  One reservation per workgroup; cnt[(5 * kCntWays + 3 + (k & 1)) * 32] = the list's length (zeroed
 // by the sweep before).
 constexpr int kListBlock = 1024;
-static __global__ __launch_bounds__(kListBlock) void k_local_list(uint32_t *cnt, LocalGraph g, int32_t k)
+static __global__ __launch_bounds__(kListBlock) void k_local_list(const LocalCtrl *ctrl, uint32_t *cnt, LocalGraph g, int32_t k)
 {
+    if (ctrl->done) return;                              // (launches queued behind the fixed point)
     __shared__ uint32_t sh_n[kListBlock / kWave];
     __shared__ uint32_t sh_base;
     const int32_t *mark_cur = g.mark[k & 1];
@@ -722,8 +723,9 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
 // ---- the notifications of the longest units that dropped in sweep k (launched after it when there are such units): a
 // workgroup per chunk, so a hub of 10^5 items marks its neighbours in microseconds instead of one workgroup's 50.
 template <class P>
-__global__ __launch_bounds__(kLocBlock) void k_local_giant_notify(LocalGraph g, P p, int32_t k)
+__global__ __launch_bounds__(kLocBlock) void k_local_giant_notify(const LocalCtrl *ctrl, LocalGraph g, P p, int32_t k)
 {
+    if (ctrl->done) return;
     const int32_t *mark_cur = g.mark[k & 1];
     int32_t *mark_next = g.mark[(k + 1) & 1];
     for (uint32_t c = blockIdx.x; c < g.nchunk; c += gridDim.x) {
@@ -811,9 +813,9 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
     while (!finished && (uint64_t)launches < max_launches && k < 0x3FFFFFF0) {
         for (int i = 0; i < kLocBatch; ++i) {
             ++k;
-            if (g.flags & kLocUseList) k_local_list<<<list_grid, kListBlock, 0, s>>>(d_cnt, g, k);
+            if (g.flags & kLocUseList) k_local_list<<<list_grid, kListBlock, 0, s>>>(d_ctrl, d_cnt, g, k);
             k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, d_cnt, g, p, k, full_thr); ++launches;
-            if (g.nchunk && (g.flags & kLocDeferNotify)) k_local_giant_notify<P><<<(int)std::min<uint32_t>(g.nchunk, 1024u), kLocBlock, 0, s>>>(g, p, k);
+            if (g.nchunk && (g.flags & kLocDeferNotify)) k_local_giant_notify<P><<<(int)std::min<uint32_t>(g.nchunk, 1024u), kLocBlock, 0, s>>>(d_ctrl, g, p, k);
             if (per_sweep && sw.size() < 600) { hipEvent_t e2; (void)hipEventCreate(&e2); (void)hipEventRecord(e2, s); sw.push_back(e2); }
         }
         if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
