@@ -12,12 +12,13 @@ N=1 workload = BASELINE.json configs[2] (|V|=10M, |E|~100M, full k-truss, the
 configuration the metric is quoted on).  --config c2 selects configs[1]
 (|V|=1M, |E|~10M); the k-core time of the same graph is reported alongside.
 
-N>1: every rank decomposes a graph of its own (the same generator, seed + rank)
-on its own GPU -- KOMB's one-graph-per-sample shape; nothing is exchanged on the
-data path, `value` = the edges of all the ranks' graphs / the slowest rank's time,
-"scaling": "weak".  One decomposition does not shard profitably (DESIGN.md section
-6): --same-graph [--shard] run the same graph on every rank as replicas / with the
-support count sharded + one all-reduce ("strong"), for the record.
+N>1 = BASELINE.json configs[3] (C4): the SAME graph on every rank, the triangle
+support counted in shards (source-vertex ranges) and summed with one RCCL
+all-reduce over xGMI, "scaling": "strong", `value` = |E| / the slowest rank's
+time.  DESIGN.md section 6 has the arithmetic of what this can and cannot gain.
+Opt-in, never the default line: --replicas (same graph, nothing sharded) and
+--batch (one graph per rank, seed + rank, nothing exchanged: weak scaling, its own
+metric name).
 """
 import argparse
 import json
@@ -128,24 +129,25 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", action="store_true",
-                    help="(the default for N > 1, accepted for older command lines) every rank decomposes a graph of its own "
-                         "(seed + rank) -- KOMB's one-graph-per-sample shape (KOMB.py --file-list): the units are sharded over the "
-                         "ranks with no exchange on the data path, weak scaling")
-    ap.add_argument("--same-graph", action="store_true",
-                    help="N > 1: the SAME graph on every rank (BASELINE configs[3]).  One decomposition does not shard: only its "
-                         "support counting does, and that pays back its all-reduce from ~8 ranks on at best (DESIGN.md section 6); "
-                         "so the ranks run replicas unless --shard is given")
-    ap.add_argument("--shard", action="store_true",
-                    help="with --same-graph: support counting sharded by source-vertex range + one all-reduce of the support vector")
+                    help="N > 1, opt-in: every rank decomposes a graph of its own (seed + rank) -- KOMB's one-graph-per-sample "
+                         "shape (KOMB.py --file-list); nothing is exchanged, weak scaling, reported under its own metric name")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1, opt-in: the same graph on every rank, every rank runs the whole single-GPU path, no exchange")
+    ap.add_argument("--same-graph", action="store_true", help="(the default for N > 1; accepted for older command lines)")
+    ap.add_argument("--shard", action="store_true", help="(the default for N > 1; accepted for older command lines)")
     ap.add_argument("--no-build", action="store_true",
                     help="load the prebuilt libkomb_accel.so, spawn no compiler (use under rocprofv3)")
     ap.add_argument("--faithful", action="store_true",
                     help="also time the runTruss-faithful variant (max-core induced subgraph); off by default so that a "
                          "rocprofv3 run of the default command sees only the timed workload's launches")
     args = ap.parse_args()
-    args.batch = args.gpus > 1 and not args.same_graph
-    if args.shard and not args.same_graph:
-        raise SystemExit("--shard needs --same-graph")
+    if args.batch and (args.replicas or args.same_graph or args.shard):
+        raise SystemExit("--batch runs one graph per rank: it cannot be combined with --replicas / --same-graph / --shard")
+    if args.replicas and args.shard:
+        raise SystemExit("--replicas runs the unsharded path on every rank: it cannot be combined with --shard")
+    args.batch = args.gpus > 1 and args.batch
+    # N > 1 default = BASELINE configs[3]: same graph, support counting sharded + one all-reduce
+    args.shard = args.gpus > 1 and not args.batch and not args.replicas
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start one rank per GPU ourselves -- as a CHILD process and
@@ -237,10 +239,9 @@ def main():
     if world > 1:
         from komb_amd import distributed as kd
 
-    # N > 1 by default: every rank its own graph (batch), nothing exchanged.  --same-graph: replicas, or with --shard the
-    # support-counting enumeration split by source-vertex range + one all-reduce of the |E|+1 support words (DESIGN.md
-    # section 6 has the arithmetic: the split saves at most ~9 ms x (1 - 1/N) of a 32 ms step and costs the all-reduce
-    # plus a two-pass index build, so it cannot scale -- it is there because BASELINE configs[3] names it, not to be fast).
+    # N > 1 by default (BASELINE configs[3]): the same graph on every rank, the support-counting enumeration split by
+    # source-vertex range + one all-reduce of the |E|+1 support words, the index build, peel and gather replicated
+    # (DESIGN.md section 6 has the arithmetic of what that can gain).  --replicas / --batch are opt-in.
     shard = world > 1 and args.shard
 
     def step():
@@ -335,11 +336,16 @@ def main():
             "whole_step_frac": sum(v[2] for v in kernels.values()) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }
         out = {
-            "metric": "peeled edges/sec (k-truss)", "value": ne_total * args.steps / dt,
+            "metric": ("peeled edges/sec (k-truss)" if not args.batch else
+                       f"aggregate peeled edges/sec (k-truss) over {world} independent graphs"),
+            "value": ne_total * args.steps / dt,
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and not args.batch) else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": desc, "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
+            "scaling": "weak" if args.batch else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": desc if world == 1 else
+                       (f"C4: the same graph as [{desc}] on {world} GPUs, k-truss with the triangle support sharded + all-reduce" if shard else
+                        f"{world} x [{desc}] ({'one graph per rank' if args.batch else 'replicas of one graph'})"),
+                       "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
                        "max_degree": st["max_degree"], "max_trussness": st["max_trussness"],
                        "max_coreness": core_stats["max_coreness"],
                        "truss_levels": st["truss_levels"], "truss_subrounds": st["truss_subrounds"],

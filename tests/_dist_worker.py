@@ -75,10 +75,42 @@ def rccl_main():
     dist.destroy_process_group()
 
 
+def c3_main():
+    """BASELINE configs[3]'s code path at the size it is quoted on: the C3 graph (|V|=10M, |E|=100.1M) on two ranks
+    sharing GPU 0, komb_truss_run_sharded (support counted per shard, all-reduced over gloo), against the recorded
+    known answer of the single-GPU path and -- on rank 0 -- against a single-rank run of the same build, value for value."""
+    import hashlib
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nv = 10_000_000
+    uv = komb_amd.gen_hug_edges(nv, 24_250_000, 2.6, 42)
+    with komb_amd.KombAccel(device=0) as a:
+        a.from_edges(nv, uv)
+        del uv
+        assert a.ne == 100_120_558
+        kd.truss_run_sharded(a)
+        st = a.stats()
+        assert st["ms_allreduce"] > 0 and st["triangles"] == 88_336_441
+        eu, ev, tr, sup = a.truss_fetch(with_support=True)
+        assert int(sup.sum(dtype=np.int64)) == 3 * 88_336_441
+        assert hashlib.sha256(tr.tobytes()).hexdigest()[:16] == "5970a467914854ea", "sharded C3 trussness differs from the known answer"
+        dist.barrier()
+        if rank == 0:
+            a.truss_run()
+            eu1, ev1, tr1, sup1 = a.truss_fetch(with_support=True)
+            assert np.array_equal(eu, eu1) and np.array_equal(ev, ev1) and np.array_equal(tr, tr1) and np.array_equal(sup, sup1)
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK c3", world)
+    dist.destroy_process_group()
+
+
 def main():
     mode = sys.argv[1]
     if mode == "rccl":
         return rccl_main()
+    if mode == "c3":
+        return c3_main()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     nv = 3000 if mode == "cpu" else 60000

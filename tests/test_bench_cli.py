@@ -10,9 +10,11 @@ def _run(*args):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300)
 
 
-def test_shard_needs_same_graph():
-    r = _run("--gpus", "2", "--shard")
-    assert r.returncode != 0 and "--shard needs --same-graph" in (r.stdout + r.stderr)
+def test_conflicting_multi_gpu_modes_are_refused():
+    r = _run("--gpus", "2", "--batch", "--shard")
+    assert r.returncode != 0 and "--batch runs one graph per rank" in (r.stdout + r.stderr)
+    r = _run("--gpus", "2", "--replicas", "--shard")
+    assert r.returncode != 0 and "--replicas runs the unsharded path" in (r.stdout + r.stderr)
 
 
 def test_world_size_mismatch_is_reported():

@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(mode, nproc, port):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+def _launch(mode, nproc, port, threads="2"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=threads)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py"), mode]
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
@@ -40,6 +40,13 @@ def test_world2_sharded_on_gpu(built):
 
 
 @pytest.mark.gpu
+def test_world2_sharded_c3_size(built):
+    """C4's code path at the size it is quoted on: two ranks (sharing GPU 0), the full C3 graph."""
+    r = _launch("c3", 2, 29614, threads="8")
+    assert r.returncode == 0 and "DIST_OK c3 2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_rccl_inplace_branch_single_rank(built):
     """backend "nccl" on the GPU box: the in-place RCCL branch of komb_amd.distributed's callback runs (one rank)."""
     r = _launch("rccl", 1, 29613)
@@ -56,12 +63,12 @@ def test_processes_sharing_one_gpu(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--same-graph"], ["--same-graph", "--shard"]])
+@pytest.mark.parametrize("extra", [[], ["--same-graph", "--shard"], ["--replicas"], ["--batch"]])
 def test_bench_two_ranks_on_one_gpu(built, extra):
     """`python bench.py --gpus 2` started plainly: it spawns its two ranks itself (before anything has touched the GPU) and
-    rank 0 prints the one JSON line.  Both ranks share GPU 0 here (KOMB_BENCH_ONE_DEVICE=1, exchange over gloo).  Default:
-    one graph per rank, nothing exchanged, weak scaling; --same-graph: replicas; --same-graph --shard: the sharded support
-    count + all-reduce."""
+    rank 0 prints the one JSON line.  Both ranks share GPU 0 here (KOMB_BENCH_ONE_DEVICE=1, exchange over gloo).  Default
+    (= BASELINE configs[3]; --same-graph --shard is the older spelling): the same graph on both ranks, the support count
+    sharded + all-reduce, strong scaling; --replicas: no sharding; --batch: one graph per rank, weak scaling, own metric name."""
     import json
     env = dict(os.environ, KOMB_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1",
@@ -71,8 +78,13 @@ def test_bench_two_ranks_on_one_gpu(built, extra):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["metric"].startswith("peeled edges/sec")
-    assert d["scaling"] == ("strong" if extra else "weak")
+    assert d["n_gpus"] == 2 and d["value"] > 0
     par = d["config"]["parallelism"]
-    assert ("independent graphs" in par) if not extra else (("sharded" in par) if "--shard" in extra else ("replicas" in par))
+    if extra == ["--batch"]:
+        assert d["scaling"] == "weak" and "independent graphs" in par and d["metric"].startswith("aggregate peeled edges/sec")
+    else:
+        assert d["scaling"] == "strong" and d["metric"] == "peeled edges/sec (k-truss)"
+        assert ("replicas" in par) if extra == ["--replicas"] else ("sharded" in par and d["config"]["workload"].startswith("C4"))
+        if extra != ["--replicas"]:
+            assert d["phases_ms"]["ms_allreduce"] > 0
     assert "cpu_baseline" not in d                       # timed at N = 1 only

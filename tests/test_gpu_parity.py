@@ -183,9 +183,18 @@ def test_repeat_runs_identical(K):
             assert np.array_equal(a.run_truss()[2], t1)
 
 
+def _oracle_trussness_fast(O, rowptr, col):
+    """Every trussness value from the oracle: the OpenMP variant of the native build when this box can build it
+    (tests/test_oracle.py ties it to orc_trussness), else the single-thread restatement."""
+    if O.native_lib() is not None:
+        import os
+        return O.trussness_native(rowptr, col, min(16, len(os.sched_getaffinity(0))))
+    return O.trussness(rowptr, col)
+
+
 def test_full_size_c2_properties(K, O):
-    """BASELINE config C2 (|V|=1M, |E|~10M): k-core against the oracle (it takes ~1 s),
-    k-truss through size-independent properties."""
+    """BASELINE config C2 (|V|=1M, |E|~10M): k-core, supports and EVERY trussness value against the oracle,
+    plus the size-independent properties."""
     nv = 1_000_000
     uv = K.gen_hug_edges(nv, 2_450_000, 2.6, 42)
     with K.KombAccel() as a:
@@ -204,6 +213,9 @@ def test_full_size_c2_properties(K, O):
         assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
         assert np.all(tr[sup == 0] == 2)                                 # triangle-free edge -> 2
         assert st["max_trussness"] == tr.max() and st["max_coreness"] == core.max()
+        osup, otri = O.support(rowptr, col)
+        assert np.array_equal(sup, osup) and st["triangles"] == otri
+        assert np.array_equal(tr, _oracle_trussness_fast(O, rowptr, col))      # full-value parity, every run
         # the top truss class is closed: every edge of the max-truss subgraph has
         # >= tmax-2 triangles inside it (checked with the oracle on that small subgraph)
         top = tr == tr.max()
@@ -416,6 +428,14 @@ def test_full_size_c3_known_answer(K, O):
         assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
         assert hashlib.sha256(core.tobytes()).hexdigest()[:16] == "120d47bf172d8b8f"
         assert hashlib.sha256(tr.tobytes()).hexdigest()[:16] == "5970a467914854ea"
+        # full-value parity, every run: all 100.1M trussness values against the oracle's OpenMP variant (~45 s on 16
+        # threads); without the native build the recorded hash above stays the only full-size check
+        if O.native_lib() is not None:
+            rowptr, col = a.get_csr()
+            import os
+            o_tr = O.trussness_native(rowptr, col, min(16, len(os.sched_getaffinity(0))))
+            assert np.array_equal(tr, o_tr)
+            del rowptr, col, o_tr
         # Independent of the recorded hash: (1) every truss class from 7 up, exactly.  The edges with trussness >= t ARE the
         # t-truss, and every higher truss lies inside it, so the oracle run on that subgraph alone (340k edges, all the levels
         # the peel's finish computes) must reproduce the GPU's values edge for edge.
