@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KOMB_ACCEL_ABI_VERSION 2
+#define KOMB_ACCEL_ABI_VERSION 3
 
 typedef enum komb_status {
     KOMB_OK          =  0,
@@ -62,8 +62,8 @@ typedef struct komb_stats {
     double  ms_orient;              /* truss: degree order + oriented CSR             */
     double  ms_tri_count;           /* truss: triangle enumeration, support counting  */
     double  ms_tri_fill;            /* truss: triangle enumeration, incidence fill    */
-    double  ms_compact;             /* truss: bounded slices -> dense index (1-pass)  */
-    double  ms_support;             /* = ms_tri_count + ms_tri_fill + ms_compact      */
+    double  ms_compact;             /* truss: blocks + sorted records (or bounded slices) -> dense index */
+    double  ms_support;             /* = ms_tri_count + ms_tri_fill + ms_sort + ms_compact */
     double  ms_allreduce;           /* truss: support all-reduce callback (sharded)   */
     double  ms_peel;                /* truss: all peel launches (SCAN + PROCESS)      */
     double  ms_gather;              /* truss: canonical-order result gather           */
@@ -75,6 +75,11 @@ typedef struct komb_stats {
     int32_t truss_local_units, truss_local_sweeps; /* edges handed over; sweeps                */
     double  ms_core_local;          /* part of ms_core: numbering + collect + sweeps + scatter */
     double  ms_truss_local;         /* part of ms_peel                                         */
+    /* index build by record stream (ABI version 3) */
+    double  ms_sort;                /* truss: sort of the incidence records by destination edge */
+    int64_t tri_records;            /* truss: record positions of the stream (incl. unused claim tails) */
+    int32_t index_layout;           /* truss: 0 = record stream, 1 = bounded slices, 2 = exact two-pass */
+    int32_t reserved0;
 } komb_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -40,6 +40,8 @@ class KombStats(ctypes.Structure):
         ("core_local_units", ctypes.c_int32), ("core_local_sweeps", ctypes.c_int32),
         ("truss_local_units", ctypes.c_int32), ("truss_local_sweeps", ctypes.c_int32),
         ("ms_core_local", ctypes.c_double), ("ms_truss_local", ctypes.c_double),
+        ("ms_sort", ctypes.c_double), ("tri_records", ctypes.c_int64),
+        ("index_layout", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 

@@ -294,6 +294,9 @@ int prim_exclusive_sum_u32_u64(komb_ctx *ctx, const uint32_t *in, unsigned long 
 int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, uint32_t *vals, uint32_t *vals_tmp,
                              int64_t n, int end_bit, int64_t **sorted_keys, uint32_t **sorted_vals);
 
+int prim_sort_pairs_u32_u64(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, unsigned long long *vals, unsigned long long *vals_alt,
+                            int64_t n, int begin_bit, int end_bit, uint32_t **sorted_keys, unsigned long long **sorted_vals);
+
 // ---- stages (each in its own translation unit)
 int core_run(komb_ctx *ctx);
 int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, komb_allreduce_fn fn, void *user);

@@ -30,7 +30,9 @@
 #include "truss_tail.h"
 #include "local_dev.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace komb {
 
@@ -276,14 +278,32 @@ __device__ unsigned long long g_tri_prof[2 * 16384];
 constexpr unsigned long long kOwnSpill = ~0ull;
 constexpr uint32_t kOwnChunk = 4096;                // entries a wavefront claims from dense_cursor at a time (one atomic per ~15 tasks)
 
-template <int MODE, class OffT = uint32_t, bool BACK = false, bool DENSE = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
+// STREAM (TRI_SINGLE, with DENSE): no slices at all.  Every incidence entry that does not go into a dense own-role block
+// -- the third-role entry of every triangle, and all three entries of a triangle whose task has no block (a spilled or
+// unstaged sub-range, a region that has run out) -- is appended as a record (key = the edge the entry belongs to, value =
+// the other two edges) to ONE stream, 64 records per store instruction, no atomic and no scattered store per triangle.
+// A wavefront claims kRecChunk positions of the stream at a time; what it leaves unused gets the sentinel key (larger
+// than every edge id).  The host then sorts the records by key (the destination-binned build of the index: DESIGN.md
+// section 4.2) and merges them with the dense blocks.  A claim beyond `cap` writes nothing: the host sees the cursor
+// pass the capacity and falls back to the exact two-pass build.
+constexpr uint32_t kRecChunk = 1024;
+struct TriStream {
+    uint32_t *key;                       // [cap]
+    int2 *val;                           // [cap]
+    unsigned long long *cursor;          // positions claimed so far
+    unsigned long long cap;
+    uint32_t sentinel;
+};
+
+template <int MODE, class OffT = uint32_t, bool BACK = false, bool DENSE = false, bool STREAM = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
 __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
                                                       const OffT *__restrict__ off, int2 *__restrict__ inc,
                                                       int2 *__restrict__ dense, unsigned long long *dense_cursor, unsigned long long dense_cap,
-                                                      unsigned long long *__restrict__ ownoff, int ablate)
+                                                      unsigned long long *__restrict__ ownoff, int ablate, TriStream ts)
 {
+    static_assert(!STREAM || (MODE == TRI_SINGLE && DENSE), "the record stream replaces the slices of the single pass");
     // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all,
     // 16 = no own-role stores, 32 = no third-role atomic + store
     static_assert(kTriCap <= 256, "edge indices and cursors of a staged task are kept in 8 bits");
@@ -313,6 +333,27 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
     unsigned long long chunk_pos = 0, chunk_end = 0;             // this wavefront's claim on `dense` (wave-uniform)
+    unsigned long long rec_pos = 0, rec_end = 0;                 // this wavefront's claim on the record stream (wave-uniform)
+    // all 64 lanes call: the lanes with `has` append (key, val) at consecutive positions of the wavefront's claim
+    auto rec_append = [&](bool has, uint32_t key, int2 val) {
+        const uint64_t m = __ballot(has);
+        if (!m) return;
+        const uint32_t c = (uint32_t)__popcll(m);
+        const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+        const uint32_t left = (uint32_t)min((unsigned long long)c, rec_end - rec_pos);    // (wave-uniform) positions left in the current claim
+        unsigned long long q = rec_pos + rank;
+        if (left < c) {                                          // the claim runs out inside this append: the rest goes to a new one
+            unsigned long long got = 0;
+            if (lane == 0) got = atomicAdd(ts.cursor, (unsigned long long)kRecChunk);
+            const uint32_t glo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+            const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
+            const unsigned long long fresh = ((unsigned long long)ghi << 32) | glo;
+            if (rank >= left) q = fresh + (rank - left);
+            rec_pos = fresh + (c - left);
+            rec_end = fresh + kRecChunk;
+        } else rec_pos += c;
+        if (has && q < ts.cap) { ts.key[q] = key; ts.val[q] = val; }
+    };
 
 #ifdef KOMB_TRI_PROFILE
     if (lane == 0 && gw < 16384) g_tri_prof[2 * gw] = wall_clock64();
@@ -366,7 +407,7 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                     const uint32_t e = S0 + tr.x, i = S0 + tr.y, jj = tr.z;
                     if (MODE == TRI_COUNT) {
                         atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); atomicAdd(&other_or_cursor[jj], 1u);
-                    } else {
+                    } else if (!STREAM) {
                         const OffT pe = off[e] + atomicAdd(&own[e], 1u);
                         const OffT pi = off[i] + atomicAdd(&own[i], 1u);
                         const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
@@ -374,6 +415,14 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                         inc[pi] = make_int2((int)e, (int)jj);
                         inc[pj] = make_int2((int)e, (int)i);
                     }
+                }
+                if (STREAM) {                                    // all three entries of these triangles are records
+                    const bool has = x < n_tri;
+                    const uint3 tr = has ? s_tri[x] : make_uint3(0u, 0u, 0u);
+                    const uint32_t e = S0 + tr.x, i = S0 + tr.y, jj = tr.z;
+                    rec_append(has, e, make_int2((int)i, (int)jj));
+                    rec_append(has, i, make_int2((int)e, (int)jj));
+                    rec_append(has, jj, make_int2((int)e, (int)i));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -389,7 +438,18 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
         bool spilled = !DENSE;                                  // wave-uniform: own-role entries go to inc[off[edge] + cursor]
         auto drain = [&](uint32_t lo, uint32_t hi, bool third, bool own_role) {
             __builtin_amdgcn_wave_barrier();
-            if (MODE == TRI_SINGLE) for (uint32_t b0 = lo; b0 < hi; b0 += kWave) {
+            if (MODE == TRI_SINGLE && STREAM) for (uint32_t b0 = lo; b0 < hi; b0 += kWave) {
+                const uint32_t x = b0 + (uint32_t)lane;
+                const bool has = x < hi;
+                const uint2 rc = has ? s_rec[x] : make_uint2(0u, 0u);
+                const uint32_t e = S0 + (rc.x & 0xFFu), i = S0 + ((rc.x >> 8) & 0xFFu), jj = rc.y;
+                if (third && !(ablate & 32)) rec_append(has, jj, make_int2((int)e, (int)i));
+                if (own_role && !(ablate & 16)) {
+                    rec_append(has, e, make_int2((int)i, (int)jj));
+                    rec_append(has, i, make_int2((int)e, (int)jj));
+                }
+            }
+            if (MODE == TRI_SINGLE && !STREAM) for (uint32_t b0 = lo; b0 < hi; b0 += kWave) {
                 const uint32_t x = b0 + (uint32_t)lane;
                 if (x < hi) {
                     const uint2 rc = s_rec[x];
@@ -602,12 +662,13 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             if (MODE == TRI_SINGLE && DENSE && !spilled) drain(0, n_rec, false, true);      // no room in the region: own-role entries of every record to the slices
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
-                own[S0 + k] = s_cnt[k];
+                own[S0 + k] = STREAM ? 0u : s_cnt[k];            // (STREAM: those entries are records, counted with the sorted stream)
                 if (MODE == TRI_SINGLE && DENSE) ownoff[S0 + k] = kOwnSpill;
             }
         }
       }   // sub-ranges
     }
+    if (STREAM) for (unsigned long long q = rec_pos + (unsigned long long)lane; q < rec_end && q < ts.cap; q += kWave) ts.key[q] = ts.sentinel;
 #ifdef KOMB_TRI_PROFILE
     if (lane == 0 && gw < 16384) g_tri_prof[2 * gw + 1] = wall_clock64();
 #endif
@@ -716,6 +777,164 @@ __global__ __launch_bounds__(kBlock) void k_compact_inc(const OffT *__restrict__
     }
 }
 
+// ---- the record stream of the single pass (k_triangles, STREAM): destination-binned build of the index
+// The records are radix-sorted by the key bits above kBinBits only: records of one BIN -- 2^kBinBits consecutive edge
+// ids -- become contiguous, in no particular order inside the bin.  One workgroup then finishes a bin out of LDS: a
+// histogram of the bin's keys gives every edge its record count (k_bin_count); after the scan of the supports, per-edge
+// write cursors in LDS place every record value in its edge's slice (k_bin_fill) -- LDS atomics and stores inside one
+// ~100 KB window of the index, instead of one global atomic and one scattered HBM line per triangle.
+constexpr int kBinBits = 11;
+constexpr uint32_t kBinEdges = 1u << kBinBits;
+
+// boff[b] = first sorted record whose bin is >= b, for b = 0 .. nb (the sentinel keys lie above every bin).  One thread
+// per bin, binary search: 25 k threads x 27 probes, no pass over the keys.
+__global__ __launch_bounds__(kBlock) void k_bin_offsets(const uint32_t *__restrict__ key, int64_t n, int64_t nb, uint32_t *__restrict__ boff)
+{
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b <= nb; b += (int64_t)gridDim.x * kBlock) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)(key[mid] >> kBinBits) < b) lo = mid + 1; else hi = mid;
+        }
+        boff[b] = (uint32_t)lo;
+    }
+}
+
+// sum over the vertices of d+(a) (d+(a) - 1): bound on the own-role entries (every edge a->x closes at most d+(a) - 1
+// triangles with the other out-neighbours of a); half of it bounds the triangles
+__global__ __launch_bounds__(kBlock) void k_own_bound(const uint32_t *__restrict__ orow, int64_t nv, unsigned long long *__restrict__ total)
+{
+    unsigned long long t = 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long d = orow[v + 1] - orow[v];
+        t += d ? d * (d - 1ull) : 0ull;
+    }
+    block_add_u64(t, total);
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_mismatch(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int64_t n,
+                                                           unsigned long long *__restrict__ bad)
+{
+    unsigned long long t = 0;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) t += a[e] != b[e] ? 1ull : 0ull;
+    block_add_u64(t, bad);
+}
+
+// supports of a bin's edges: dense own-role entries + records of the bin with that key (LDS histogram); 64-bit total on the side.
+// sum[] has m + 1 entries (sum[m] = 0: the scan's total lands there).
+__global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict__ key, const uint32_t *__restrict__ boff, int64_t nb,
+                                                      const uint32_t *__restrict__ own, int64_t m, uint32_t *__restrict__ sum,
+                                                      unsigned long long *__restrict__ total)
+{
+    __shared__ uint32_t sh_cnt[kBinEdges];
+    unsigned long long t = 0;
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int64_t x0 = b << kBinBits;
+        const uint32_t nx = (uint32_t)min((int64_t)kBinEdges, m - x0);
+        for (uint32_t i = threadIdx.x; i < kBinEdges; i += kBlock) sh_cnt[i] = 0u;
+        __syncthreads();
+        const uint32_t r0 = boff[b], r1 = boff[b + 1];
+        for (uint32_t r = r0 + threadIdx.x; r < r1; r += kBlock) atomicAdd(&sh_cnt[key[r] - (uint32_t)x0], 1u);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nx; i += kBlock) {
+            const uint32_t c = own[x0 + i] + sh_cnt[i];
+            sum[x0 + i] = c;
+            t += c;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sum[m] = 0u;
+    block_add_u64(t, total);
+}
+
+// Dense index of a bin's edges.  An edge's slice is [its records' values | its own-role entries]; the slices of a
+// bin's 2^kBinBits consecutive edges are one contiguous WINDOW of the index (~40 KB).  One workgroup per bin assembles
+// the window in LDS -- every record takes its position from a per-edge cursor (LDS atomic), the own-role entries are
+// copied out of the tasks' dense blocks -- and then writes it as one coalesced stream: no global atomic, no scattered
+// store, every line of the index written whole, once.  A window that does not fit the LDS buffer (hub edges) is written
+// in place instead.  All loads of a phase are issued before the first is used: two workgroups per CU, and the kernel
+// lives on memory-level parallelism.
+constexpr int kFinBlock = 512;
+constexpr uint32_t kWinCap = 7168;                 // entries of the LDS window (56 KB; with the two 8 KB tables: 2 workgroups per CU)
+constexpr int kFinE = (int)(kBinEdges / kFinBlock);          // consecutive edges per thread
+constexpr int kFinU = 4;                           // records per thread per trip
+static_assert(kFinE == 4, "a thread loads its edges' offsets and counts as one 16-byte vector each");
+__global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__restrict__ key, const int2 *__restrict__ val,
+                                                         const uint32_t *__restrict__ boff, int64_t nb,
+                                                         const uint32_t *__restrict__ own, const uint32_t *__restrict__ off,
+                                                         const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
+                                                         int2 *__restrict__ dense, int64_t m)
+{
+    __shared__ uint32_t sh_off[kBinEdges + 4];     // slice offsets relative to the window
+    __shared__ uint32_t sh_cur[kBinEdges];
+    __shared__ int2 sh_win[kWinCap];
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int64_t x0 = b << kBinBits;
+        const uint32_t nx = (uint32_t)min((int64_t)kBinEdges, m - x0);
+        const uint64_t r0 = boff[b], r1 = boff[b + 1];
+        const uint32_t base = off[x0];
+        // ---- the thread's 4 consecutive edges: offsets and own-role counts, then (for the edges that have some) where their blocks are
+        const uint32_t i0 = threadIdx.x * (uint32_t)kFinE;
+        uint32_t o[kFinE + 1], ow[kFinE];
+        unsigned long long oo[kFinE];
+        if (i0 + kFinE <= nx) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(off + x0 + i0);
+            const uint4 w = *reinterpret_cast<const uint4 *>(own + x0 + i0);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; o[4] = off[x0 + i0 + kFinE];
+            ow[0] = w.x; ow[1] = w.y; ow[2] = w.z; ow[3] = w.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u <= kFinE; ++u) o[u] = i0 + (uint32_t)u <= nx ? off[x0 + i0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) ow[u] = i0 + (uint32_t)u < nx ? own[x0 + i0 + u] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u) oo[u] = ow[u] ? ownoff[x0 + i0 + u] : 0ull;
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u)
+            if (i0 + (uint32_t)u < nx) { sh_off[i0 + u] = o[u] - base; sh_cur[i0 + u] = o[u] - base; }
+        if (i0 < nx && i0 + kFinE >= nx) sh_off[nx] = o[nx - i0] - base;
+        __syncthreads();
+        const uint32_t W = sh_off[nx];
+        const bool inwin = W <= kWinCap;                            // (workgroup-uniform)
+        // ---- records
+        for (uint64_t r = r0 + threadIdx.x; r < r1; r += (uint64_t)kFinBlock * kFinU) {
+            uint32_t k[kFinU];
+            int2 v[kFinU];
+#pragma unroll
+            for (int u = 0; u < kFinU; ++u) {
+                const uint64_t rr = r + (uint64_t)u * kFinBlock;
+                if (rr < r1) { k[u] = key[rr]; v[u] = val[rr]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kFinU; ++u) {
+                const uint64_t rr = r + (uint64_t)u * kFinBlock;
+                if (rr < r1) {
+                    const uint32_t p = atomicAdd(&sh_cur[k[u] - (uint32_t)x0], 1u);
+                    if (inwin) sh_win[p] = v[u]; else dense[base + p] = v[u];
+                }
+            }
+        }
+        // ---- own-role entries of the thread's edges: they end the edges' slices; the 4 edges' copies advance together
+        uint32_t most = 0;
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u) most = max(most, ow[u]);
+        for (uint32_t kk = 0; kk < most; ++kk) {
+            int2 t[kFinE];
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) t[u] = own_dense[oo[u] + kk];
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) {
+                const uint32_t p = o[u + 1] - base - ow[u] + kk;
+                if (inwin) sh_win[p] = t[u]; else dense[base + p] = t[u];
+            }
+        }
+        __syncthreads();
+        // ---- the window, as a stream
+        if (inwin) for (uint32_t j = threadIdx.x; j < W; j += kFinBlock) dense[base + j] = sh_win[j];
+        __syncthreads();
+    }
+}
 
 // peel state from the slice lengths.  Triangle-free edges are peeled here (trussness 2); init[0]
 // counts them and init[1] receives the smallest positive support = the first populated level.
@@ -1044,27 +1263,156 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)m + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
     unsigned long long *d_mom = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_mom, 8));
-    KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 8 * sizeof(unsigned long long), s));
+    KOMB_HIP(ctx, bufs.alloc(&d_mom, 12));                           // [0..4] graph moments, [5] sum of supports, [6,7] capacity bounds, [8] sharded-check mismatches
+    KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 12 * sizeof(unsigned long long), s));
     KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s));
     st.ms_allreduce = 0.0;
 
-    // Single-pass layout (one enumeration instead of two): every edge gets a slice sized by the bound
-    // sup(a->b) <= d(a)-1; ~26 GB at |E|=100M, which the 288 GB of HBM afford.  Used on one GPU when the
-    // bounded index fits 32-bit offsets and memory; otherwise (and when the support phase is sharded over
-    // ranks, which needs the counts first) the exact two-pass layout is used.
+    // Three layouts of the index build:
+    //   stream   (default) ONE enumeration; own-role entries leave a task as dense blocks, everything else as records of one
+    //            stream that is then sorted by destination edge and merged with the blocks -- no atomic and no scattered
+    //            store per triangle, no slices sized by a bound.  KOMB_INDEX=stream.
+    //   slices   ONE enumeration into slices sized by the bound sup(a->b) <= d(a)-1 (~26 GB at |E|=100M), third-role
+    //            entries through one returning atomic + one scattered store each, then a compaction.  KOMB_INDEX=slices.
+    //   two_pass count, scan, second enumeration into exact slices: the fallback when the others do not fit in memory.
+    //            KOMB_INDEX=two_pass (or KOMB_TWO_PASS=1).
+    // A sharded run (world > 1) first counts the supports of its own source-vertex range and sums them over the ranks
+    // (fn: the RCCL all-reduce), then builds the index whole with the layout above; the summed supports must equal the
+    // supports the build finds.
+    enum { IDX_STREAM = 0, IDX_SLICES = 1, IDX_TWO_PASS = 2 };
+    int layout = IDX_STREAM;
+    if (const char *ix = getenv("KOMB_INDEX")) {
+        if (!strcmp(ix, "slices")) layout = IDX_SLICES;
+        else if (!strcmp(ix, "two_pass")) layout = IDX_TWO_PASS;
+        else if (strcmp(ix, "stream")) KOMB_FAIL(ctx, KOMB_ERR_ARG, "KOMB_INDEX=%s: expected stream, slices or two_pass", ix);
+    }
+    if (getenv("KOMB_TWO_PASS")) layout = IDX_TWO_PASS;
     uint32_t *d_cap = nullptr, *d_offc = nullptr;
     unsigned long long *d_offc64 = nullptr;    // the same offsets in 64 bits when the slices exceed 2^32 entries (KOMB_OFF64=1 forces them)
     int2 *d_sparse = nullptr;
     int2 *d_owndense = nullptr;                // own-role entries as compact per-task blocks (see k_triangles, DENSE)
     unsigned long long *d_ownoff = nullptr, *d_dcur = nullptr;
+    uint32_t *d_cnt_ref = nullptr;             // world > 1: the all-reduced supports, kept to check the build against
+    uint32_t *d_toff = nullptr;                // stream: first sorted record of every bin
+    uint32_t *d_reckey = nullptr;              // stream: the sorted records' keys
+    int2 *d_recval = nullptr;                  // stream: ... and values
+    int64_t n_bins = 0;
+    const TriStream no_stream{nullptr, nullptr, nullptr, 0ull, 0u};
 #ifdef KOMB_DEBUG_SWITCHES
     const int ablate = getenv("KOMB_TRI_ABLATE") ? atoi(getenv("KOMB_TRI_ABLATE")) : 0;    // breaks results on purpose: debug builds only
 #else
     const int ablate = 0;
 #endif
-    bool single = (world == 1) && !getenv("KOMB_TWO_PASS");
-    if (single) {
+    st.ms_sort = 0.0; st.tri_records = 0; st.ms_compact = 0.0; st.ms_tri_count = 0.0; st.ms_tri_fill = 0.0;
+    st.index_layout = layout;
+    auto zero_counts = [&]() -> hipError_t { return hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s); };
+    bool have_counts = false;                  // d_cnt holds the supports (and d_mom[5] their sum)
+    if (world > 1) {
+        const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
+        ctx->timer.start(s);
+        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
+        st.ms_tri_count = ctx->timer.stop(s);
+        k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
+        // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
+        ctx->timer.start(s);
+        KOMB_HIP(ctx, hipStreamSynchronize(s));          // the buffer is complete when the callback runs
+        if (fn(user, d_cnt, (int64_t)m + 1) != 0)
+            KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
+        st.ms_allreduce = ctx->timer.stop(s);
+        KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
+        k_total_u32<<<ge, kBlock, 0, s>>>(d_cnt, m + 1, d_mom + 5);
+        have_counts = true;
+        if (layout != IDX_TWO_PASS) {
+            KOMB_HIP(ctx, bufs.alloc(&d_cnt_ref, (size_t)m + 1));
+            KOMB_HIP(ctx, hipMemcpyAsync(d_cnt_ref, d_cnt, ((size_t)m + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            KOMB_HIP(ctx, zero_counts());
+        }
+    }
+
+    if (layout == IDX_STREAM) {
+        // capacities: T <= sum_a C(d+(a), 2) triangles, at most three records each (a triangle of a task without a dense
+        // block), plus what the chunked claims leave unused; with less memory than that, a stream that runs out falls back
+        unsigned long long *d_bound = d_mom + 6;
+        k_own_bound<<<gv, kBlock, 0, s>>>(d_orow, nv, d_bound);
+        unsigned long long bound = 0;
+        KOMB_HIP(ctx, d2h(ctx, &bound, d_bound, sizeof(bound)));
+        const int gts = std::min(gt, 256 * KOMB_TRI_EU);             // resident workgroups only: every wavefront ends with one partly used claim
+        const unsigned long long slack = (unsigned long long)gts * kTriWaves * kRecChunk + kRecChunk;
+        unsigned long long own_cap = bound + bound / 8 + (unsigned long long)gts * kTriWaves * kOwnChunk + kOwnChunk;
+        if (const char *oc = getenv("KOMB_OWN_DENSE_CAP")) own_cap = strtoull(oc, nullptr, 10) + 1;      // (tests: a region that runs out)
+        if (getenv("KOMB_NO_OWN_DENSE")) own_cap = 1;                // (tests: every entry a record)
+        unsigned long long t_bound = bound / 2;
+        unsigned long long rec_cap = 3 * t_bound + (3 * t_bound) / 14 + slack;
+        if (const char *rc = getenv("KOMB_REC_CAP")) rec_cap = strtoull(rc, nullptr, 10) + 1;            // (tests: a stream that runs out)
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const unsigned long long budget = (unsigned long long)(free_b * 0.7);
+        if (own_cap * sizeof(int2) > budget / 2) own_cap = budget / 2 / sizeof(int2);
+        if (rec_cap * 12ull > budget / 2) rec_cap = budget / 2 / 12ull;
+        if (rec_cap > 0xFFFFFFF0ull) rec_cap = 0xFFFFFFF0ull;        // 32-bit record positions
+        int end_bit = 1;
+        // the sentinel key (1 << end_bit) - 1 lies at least a whole bin above the last edge id, so the sort by bin puts it last
+        while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)m + kBinEdges) ++end_bit;
+        const uint32_t sentinel = end_bit >= 32 ? 0xFFFFFFFFu : (uint32_t)((1ull << end_bit) - 1ull);
+        uint32_t *d_key = nullptr; int2 *d_val = nullptr;
+        bool ok = bufs.alloc(&d_key, (size_t)rec_cap) == hipSuccess && bufs.alloc(&d_val, (size_t)rec_cap) == hipSuccess &&
+                  bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess && bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess &&
+                  bufs.alloc(&d_dcur, 4) == hipSuccess;
+        unsigned long long n_claimed = 0;
+        if (ok) {
+            KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 4 * sizeof(unsigned long long), s));
+            const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel};
+            ctx->timer.start(s);
+            k_triangles<TRI_SINGLE, uint32_t, false, true, true><<<gts, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr,
+                                                                                      d_owndense, d_dcur, own_cap, d_ownoff, ablate, ts);
+            st.ms_tri_fill = ctx->timer.stop(s);
+            unsigned long long dc[4] = {0, 0, 0, 0};
+            KOMB_HIP(ctx, d2h(ctx, dc, d_dcur, sizeof(dc)));
+            n_claimed = dc[2];
+            if (getenv("KOMB_TRI_DEBUG"))
+                fprintf(stderr, "komb triangles: stream build: %llu record positions claimed of %llu, dense own-role region %llu entries claimed of %llu, %llu task ranges overflowed their record buffer\n",
+                        dc[2], rec_cap, dc[0], own_cap, dc[1]);
+            if (n_claimed > rec_cap) ok = false;                     // the stream ran out: records were dropped
+        } else (void)hipGetLastError();
+        uint32_t *d_skey = nullptr;
+        if (ok) {
+            // sort the records by destination edge
+            uint32_t *d_key2 = nullptr; unsigned long long *d_val2 = nullptr;
+            ok = bufs.alloc(&d_key2, (size_t)n_claimed + 1) == hipSuccess && bufs.alloc(&d_val2, (size_t)n_claimed + 1) == hipSuccess;
+            if (ok) {
+                // sort the records by BIN (the key bits above kBinBits): two radix passes instead of four
+                ctx->timer.start(s);
+                unsigned long long *sv = nullptr;
+                if (end_bit > kBinBits) KOMB_TRY(prim_sort_pairs_u32_u64(ctx, d_key, d_key2, (unsigned long long *)d_val, d_val2, (int64_t)n_claimed, kBinBits, end_bit, &d_skey, &sv));
+                else { d_skey = d_key; sv = (unsigned long long *)d_val; }      // a single bin: nothing to sort
+                st.ms_sort = ctx->timer.stop(s);
+                d_recval = (int2 *)sv;
+                if (d_skey == d_key) { bufs.release(d_key2); bufs.release(d_val2); } else { bufs.release(d_key); bufs.release(d_val); }
+                d_reckey = d_skey;
+                n_bins = (m + kBinEdges - 1) >> kBinBits;
+                KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)n_bins + 2));
+                ctx->timer.start(s);
+                KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
+                k_bin_offsets<<<grid_for(n_bins + 1), kBlock, 0, s>>>(d_skey, (int64_t)n_claimed, n_bins, d_toff);
+                k_bin_count<<<grid_for(n_bins, 1, 256 * 8), kBlock, 0, s>>>(d_skey, d_toff, n_bins, d_own, m, d_cnt, d_mom + 5);
+                st.ms_compact = ctx->timer.stop(s);
+                st.tri_records = (int64_t)n_claimed;
+            } else (void)hipGetLastError();
+        }
+        if (!ok) {
+            // no memory for the stream, or it ran out: exact two-pass build
+            bufs.release(d_key); bufs.release(d_val); bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
+            d_owndense = nullptr; d_ownoff = nullptr; d_dcur = nullptr;
+            KOMB_HIP(ctx, zero_counts());
+            KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
+            st.ms_tri_fill = 0.0;
+            layout = IDX_TWO_PASS;
+        }
+    }
+
+    if (layout == IDX_SLICES) {
+        // every edge gets a slice sized by the bound sup(a->b) <= d(a)-1; ~26 GB at |E|=100M, which the 288 GB of HBM afford
+        bool single = true;
         KOMB_HIP(ctx, bufs.alloc(&d_cap, (size_t)m + 1));
         KOMB_HIP(ctx, bufs.alloc(&d_offc, (size_t)m + 1));
         KOMB_HIP(ctx, hipMemsetAsync(d_cap + m, 0, sizeof(uint32_t), s));
@@ -1103,59 +1451,61 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
         if (single) {
             if (d_offc64) {
-                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate);
-                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate);
+                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream);
+                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
             } else {
                 k_back_cursors<<<ge, kBlock, 0, s>>>(d_offc, m, d_other);
-                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate);
-                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate);
+                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream);
+                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
             }
-#ifdef KOMB_TRI_PROFILE
-            {
-                std::vector<unsigned long long> pr(2 * 16384);
-                (void)hipStreamSynchronize(s);
-                (void)hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_tri_prof), pr.size() * sizeof(unsigned long long));
-                unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> dur, endt;
-                const int nwv = gt * kTriWaves < 16384 ? gt * kTriWaves : 16384;
-                for (int i = 0; i < nwv; ++i) { if (pr[2 * i] < t0) t0 = pr[2 * i]; if (pr[2 * i + 1] > t1) t1 = pr[2 * i + 1]; }
-                for (int i = 0; i < nwv; ++i) { dur.push_back((pr[2 * i + 1] - pr[2 * i]) / 100.0); endt.push_back((pr[2 * i + 1] - t0) / 100.0); }
-                std::sort(dur.begin(), dur.end()); std::sort(endt.begin(), endt.end());
-                auto q = [&](std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-                fprintf(stderr, "komb tri profile: %d waves, span %.0f us; wave busy time us: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; end time us: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f\n",
-                        nwv, (t1 - t0) / 100.0, dur.front(), q(dur, .1), q(dur, .5), q(dur, .9), q(dur, .99), dur.back(), q(endt, .1), q(endt, .5), q(endt, .9), q(endt, .99), endt.back());
-            }
-#endif
             st.ms_tri_fill = ctx->timer.stop(s);
-            st.ms_tri_count = 0.0;
+            KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
+            k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, d_offc64 ? nullptr : d_offc, m + 1, d_cnt, d_mom + 5);
         } else {
             (void)ctx->timer.stop(s);
             bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64); d_offc64 = nullptr;
             bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur); d_owndense = nullptr; d_ownoff = nullptr; d_dcur = nullptr;
+            layout = IDX_TWO_PASS;
         }
     }
-    if (!single) {
-        const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
-        ctx->timer.start(s);
-        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate);
-        st.ms_tri_count = ctx->timer.stop(s);
+#ifdef KOMB_TRI_PROFILE
+    if (layout != IDX_TWO_PASS) {
+        std::vector<unsigned long long> pr(2 * 16384);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_tri_prof), pr.size() * sizeof(unsigned long long));
+        unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> dur, endt;
+        const int nwv = gt * kTriWaves < 16384 ? gt * kTriWaves : 16384;
+        for (int i = 0; i < nwv; ++i) { if (pr[2 * i] < t0) t0 = pr[2 * i]; if (pr[2 * i + 1] > t1) t1 = pr[2 * i + 1]; }
+        for (int i = 0; i < nwv; ++i) { dur.push_back((pr[2 * i + 1] - pr[2 * i]) / 100.0); endt.push_back((pr[2 * i + 1] - t0) / 100.0); }
+        std::sort(dur.begin(), dur.end()); std::sort(endt.begin(), endt.end());
+        auto q = [&](std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        fprintf(stderr, "komb tri profile: %d waves, span %.0f us; wave busy time us: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; end time us: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f\n",
+                nwv, (t1 - t0) / 100.0, dur.front(), q(dur, .1), q(dur, .5), q(dur, .9), q(dur, .99), dur.back(), q(endt, .1), q(endt, .5), q(endt, .9), q(endt, .99), endt.back());
     }
-    k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, (single && !d_offc64) ? d_offc : nullptr, m + 1, d_cnt, d_mom + 5);
-    if (!single && world > 1) {
-        // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
-        ctx->timer.start(s);
-        KOMB_HIP(ctx, hipStreamSynchronize(s));          // the buffer is complete when the callback runs
-        if (fn(user, d_cnt, (int64_t)m + 1) != 0)
-            KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: all-reduce callback failed");
-        st.ms_allreduce = ctx->timer.stop(s);
-        KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
-        k_total_u32<<<ge, kBlock, 0, s>>>(d_cnt, m + 1, d_mom + 5);
+#endif
+    if (layout != IDX_TWO_PASS && d_cnt_ref) {
+        // sharded run: the supports summed over the ranks must be the supports the whole build has just found
+        k_count_mismatch<<<ge, kBlock, 0, s>>>(d_cnt, d_cnt_ref, m + 1, d_mom + 8);
     }
+    if (layout == IDX_TWO_PASS) {
+        if (d_cnt_ref) {
+            KOMB_HIP(ctx, hipMemcpyAsync(d_cnt, d_cnt_ref, ((size_t)m + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
+            k_total_u32<<<ge, kBlock, 0, s>>>(d_cnt, m + 1, d_mom + 5);
+        } else if (!have_counts) {
+            ctx->timer.start(s);
+            k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
+            st.ms_tri_count = ctx->timer.stop(s);
+            k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
+        }
+    }
+    st.index_layout = layout;
     // graph statistics for the roofline model (sum d^2, sum min(d,d), max d, sum d+ + d+): properties of
     // the graph, not results of the path -- computed on the first whole-graph run and on every subgraph run
     const bool want_moments = vmask_host != nullptr || !ctx->moments_valid;
     if (want_moments) k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_cnt, d_orow, d_mom);
     {
-        unsigned long long mom[6];
+        unsigned long long mom[9];
         KOMB_HIP(ctx, d2h(ctx, mom, d_mom, sizeof(mom)));
         if (want_moments) {
             st.sum_deg_sq = (int64_t)mom[0]; st.wedge_items = (int64_t)mom[1]; st.max_degree = (int32_t)mom[2];
@@ -1164,19 +1514,27 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
         st.triangles = (int64_t)(mom[5] / 3);
         bufs.release(d_mom);
+        if (mom[8] != 0)
+            KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "komb_truss_run_sharded: %llu edges whose all-reduced support differs from the support of the index build", mom[8]);
         if (mom[5] > 0xFFFFFFF0ull)
             KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %llu triangles; the incidence index is limited to 2^32-16 entries (3 per triangle)",
                       mom[5] / 3);
     }
+    bufs.release(d_cnt_ref);
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_off, m + 1));
     uint32_t total = 0;
     KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
     int2 *d_inc = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
-    st.ms_compact = 0.0;
-    if (single) {
+    const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
+    if (layout == IDX_STREAM) {
         ctx->timer.start(s);
-        const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
+        k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, n_bins, d_own, d_off, d_owndense, d_ownoff, d_inc, m);
+        st.ms_compact += ctx->timer.stop(s);
+        bufs.release(d_toff); bufs.release((void *)d_recval); bufs.release(d_reckey);
+        bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
+    } else if (layout == IDX_SLICES) {
+        ctx->timer.start(s);
         if (d_offc64) k_compact_inc<unsigned long long><<<gc, kBlock, 0, s>>>(d_offc64, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
         else k_compact_inc<uint32_t><<<gc, kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
         st.ms_compact = ctx->timer.stop(s);
@@ -1189,14 +1547,15 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64);
         bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
     } else {
-        // second enumeration, same writer as the single-pass layout but into the EXACT slices: own-role
+        // second enumeration, same writer as the single-pass layouts but into the EXACT slices: own-role
         // entries from the front and third-role entries from the back meet precisely -- no compaction
         ctx->timer.start(s);
+        KOMB_HIP(ctx, zero_counts());
         k_back_cursors<<<ge, kBlock, 0, s>>>(d_off, m, d_other);
-        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, 0ull, nullptr, ablate);
+        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
-    st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_compact;
+    st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_sort + st.ms_compact;
     bufs.release(d_cnt); bufs.release(d_own);
 
     // ---- peel

@@ -97,4 +97,23 @@ int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, ui
     return KOMB_OK;
 }
 
+// records of the k-truss index build: 32-bit keys (an edge id), 8-byte values (the other two edges of a triangle), sorted
+// by the key bits [begin_bit, end_bit).  Asynchronous on the context's stream.
+int prim_sort_pairs_u32_u64(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, unsigned long long *vals, unsigned long long *vals_alt,
+                            int64_t n, int begin_bit, int end_bit, uint32_t **sorted_keys, unsigned long long **sorted_vals)
+{
+    hipcub::DoubleBuffer<uint32_t> dk(keys, keys_alt);
+    hipcub::DoubleBuffer<unsigned long long> dv(vals, vals_alt);
+    if (n > 0) {
+        size_t bytes = 0;
+        KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (long long)n, begin_bit, end_bit, ctx->stream));
+        TempBuf t(ctx);
+        KOMB_HIP(ctx, t.get(bytes));
+        KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(t.p, bytes, dk, dv, (long long)n, begin_bit, end_bit, ctx->stream));
+    }
+    *sorted_keys = dk.Current();
+    *sorted_vals = dv.Current();
+    return KOMB_OK;
+}
+
 } // namespace komb

@@ -26,7 +26,7 @@ def _i64(x):
 
 def test_native_library_is_loaded(K):
     lib = K._lib.load()
-    assert lib.komb_abi_version() == 2
+    assert lib.komb_abi_version() == 3
     with open("/proc/self/maps") as f:
         assert "libkomb_accel.so" in f.read()
 
@@ -228,45 +228,50 @@ def test_full_size_c2_properties(K, O):
 
 
 def test_index_layouts_agree(K, O, monkeypatch):
-    """Single-pass (degree-bounded slices + compaction, 32- and 64-bit slice offsets, own-role entries in dense per-task
-    blocks or in the slices) and two-pass (exact slices) incidence builds must give the same supports and trussness."""
+    """The three index builds must give the same supports and trussness: record stream (default: dense own-role blocks +
+    sorted records; also with a dense region that runs out, with no dense region at all, and with a stream that runs out
+    and falls back), bounded slices + compaction (32- and 64-bit slice offsets, own-role entries in dense per-task blocks
+    or in the slices), exact two-pass."""
+    env = ("KOMB_TWO_PASS", "KOMB_INDEX", "KOMB_OFF64", "KOMB_OWN_DENSE_CAP", "KOMB_NO_OWN_DENSE", "KOMB_REC_CAP")
     uv = K.gen_hug_edges(40000, 110000, 2.3, 21)
     with K.KombAccel() as a:
         a.from_edges(40000, uv)
-        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
-        r1 = a.run_truss(with_support=True)
-        monkeypatch.setenv("KOMB_TWO_PASS", "1")
-        r2 = a.run_truss(with_support=True)
-        assert a.stats()["ms_tri_count"] > 0
-        for x, y in zip(r1, r2):
-            assert np.array_equal(x, y)
-        # the single-pass layout with 64-bit slice offsets (what graphs beyond 2^32 bounded entries use)
-        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
-        monkeypatch.setenv("KOMB_OFF64", "1")
-        r3 = a.run_truss(with_support=True)
-        assert a.stats()["ms_tri_count"] == 0 and a.stats()["ms_compact"] > 0
-        monkeypatch.delenv("KOMB_OFF64", raising=False)
-        for x, y in zip(r1, r3):
-            assert np.array_equal(x, y)
-        # own-role entries kept in the bounded slices instead of the dense per-task blocks (what a run without the
-        # memory for the dense region does, and what a task with more triangles than its record buffer does)
-        # a dense region that runs out half way: the tasks that find no room fall back to the slices one by one
-        monkeypatch.setenv("KOMB_OWN_DENSE_CAP", "70000")
-        r5 = a.run_truss(with_support=True)
-        monkeypatch.delenv("KOMB_OWN_DENSE_CAP", raising=False)
-        for x, y in zip(r1, r5):
-            assert np.array_equal(x, y)
-        for off64 in (False, True):
-            monkeypatch.setenv("KOMB_NO_OWN_DENSE", "1")
-            if off64:
-                monkeypatch.setenv("KOMB_OFF64", "1")
-            r4 = a.run_truss(with_support=True)
-            monkeypatch.delenv("KOMB_NO_OWN_DENSE", raising=False)
-            monkeypatch.delenv("KOMB_OFF64", raising=False)
-            for x, y in zip(r1, r4):
-                assert np.array_equal(x, y)
+
+        def run(**kv):
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in kv.items():
+                monkeypatch.setenv(k, v)
+            r = a.run_truss(with_support=True)
+            st = a.stats()
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+            return r, st
+
+        r1, st = run()
+        assert st["index_layout"] == 0 and st["ms_tri_count"] == 0 and st["ms_sort"] > 0 and st["tri_records"] >= st["triangles"]
         rowptr, col = a.get_csr()
         assert np.array_equal(r1[2], O.trussness(rowptr, col))
+        assert np.array_equal(r1[3], O.support(rowptr, col)[0])
+        variants = [
+            (dict(KOMB_TWO_PASS="1"), 2), (dict(KOMB_INDEX="two_pass"), 2),
+            # stream: a dense region that runs out half way (the tasks that find no room send their own-role entries to the
+            # stream one by one), no dense region at all (three records per triangle), a stream that runs out (-> two-pass)
+            (dict(KOMB_OWN_DENSE_CAP="70000"), 0), (dict(KOMB_NO_OWN_DENSE="1"), 0), (dict(KOMB_REC_CAP="50000"), 2),
+            # bounded slices: 32- and 64-bit offsets, with and without the dense own-role region
+            (dict(KOMB_INDEX="slices"), 1), (dict(KOMB_INDEX="slices", KOMB_OFF64="1"), 1),
+            (dict(KOMB_INDEX="slices", KOMB_OWN_DENSE_CAP="70000"), 1),
+            (dict(KOMB_INDEX="slices", KOMB_NO_OWN_DENSE="1"), 1), (dict(KOMB_INDEX="slices", KOMB_NO_OWN_DENSE="1", KOMB_OFF64="1"), 1),
+        ]
+        for kv, layout in variants:
+            r, st = run(**kv)
+            assert st["index_layout"] == layout, (kv, st["index_layout"])
+            if layout == 2:
+                assert st["ms_tri_count"] > 0
+            if kv == dict(KOMB_NO_OWN_DENSE="1"):
+                assert st["tri_records"] >= 3 * st["triangles"]
+            for x, y in zip(r1, r):
+                assert np.array_equal(x, y), kv
 
 
 def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
@@ -277,17 +282,23 @@ def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
     rng = np.random.default_rng(77)
     nv = 30000
     uv = rng.integers(0, nv, (12_600_000, 2)).astype(np.int64)
-    for k in ("KOMB_OFF64", "KOMB_TWO_PASS", "KOMB_NO_OWN_DENSE"):
+    for k in ("KOMB_OFF64", "KOMB_TWO_PASS", "KOMB_NO_OWN_DENSE", "KOMB_INDEX"):
         monkeypatch.delenv(k, raising=False)
     with K.KombAccel() as a:
         a.from_edges(nv, uv)
         del uv
         deg, core = a.run_core()
+        r0 = a.run_truss(with_support=True)                                 # the default build (record stream)
+        assert a.stats()["index_layout"] == 0
+        monkeypatch.setenv("KOMB_INDEX", "slices")
         eu, ev, tr, sup = a.run_truss(with_support=True)
+        monkeypatch.delenv("KOMB_INDEX", raising=False)
         st = a.stats()
+        for x, y in zip((eu, ev, tr, sup), r0):
+            assert np.array_equal(x, y)
         lower = np.minimum(deg[eu], deg[ev])                                # d(a) of the lower-(degree, id) endpoint a
         assert int((lower.astype(np.int64) - 1).sum()) > 2**32           # the bound the slices are sized by, beyond 32 bits
-        assert st["ms_tri_count"] == 0 and st["ms_compact"] > 0             # ... and still the single pass
+        assert st["index_layout"] == 1 and st["ms_tri_count"] == 0 and st["ms_compact"] > 0   # ... and still the single pass
         assert sup.sum(dtype=np.int64) == 3 * st["triangles"]
         assert np.all(tr >= 2) and np.all(tr <= sup + 2)
         assert np.all(np.minimum(core[eu], core[ev]) >= tr - 1)
@@ -299,14 +310,12 @@ def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("two_pass", [False, True])
-def test_cliques_and_hubs(K, O, monkeypatch, two_pass):
+@pytest.mark.parametrize("layout", ["stream", "slices", "two_pass"])
+def test_cliques_and_hubs(K, O, monkeypatch, layout):
     """Complete graphs: long oriented rows (the LDS staging falls back to global search), every
     edge a heavy unit (slices of n-2 > 64 items).  Star + clique: a hub row split into chunks."""
-    if two_pass:
-        monkeypatch.setenv("KOMB_TWO_PASS", "1")
-    else:
-        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+    monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+    monkeypatch.setenv("KOMB_INDEX", layout)
     for n in (70, 200, 320):
         iu = np.triu_indices(n, 1)
         uv = np.stack(iu, axis=1).astype(np.int64)
@@ -371,14 +380,12 @@ def test_incidence_limit_is_refused(K):
             a.truss_fetch()                      # no stale result is exposed
 
 
-@pytest.mark.parametrize("two_pass", [False, True])
-def test_kernel_threshold_boundaries(K, O, monkeypatch, two_pass):
+@pytest.mark.parametrize("layout", ["stream", "slices", "two_pass"])
+def test_kernel_threshold_boundaries(K, O, monkeypatch, layout):
     """Slice lengths around kLight=64 and kChunk=128 ("book" graphs: one spine edge with k pages), and
     16-vertex task blocks whose staged oriented rows straddle the 512-slot LDS budget (dense G(n,p))."""
-    if two_pass:
-        monkeypatch.setenv("KOMB_TWO_PASS", "1")
-    else:
-        monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+    monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
+    monkeypatch.setenv("KOMB_INDEX", layout)
 
     def check(nv, uv):
         o_rowptr, o_col = O.simplify(nv, uv)
