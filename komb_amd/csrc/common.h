@@ -296,6 +296,9 @@ int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, ui
 
 int prim_sort_pairs_u32_u64(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, unsigned long long *vals, unsigned long long *vals_alt,
                             int64_t n, int begin_bit, int end_bit, uint32_t **sorted_keys, unsigned long long **sorted_vals);
+int prim_select_reversed(komb_ctx *ctx, const int32_t *osrc, const int32_t *ocol, int64_t m, uint32_t *out, uint32_t *d_num);
+int prim_sort_pairs_u32_u32(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                            int64_t n, int end_bit, uint32_t **sorted_keys, uint32_t **sorted_vals);
 
 // ---- stages (each in its own translation unit)
 int core_run(komb_ctx *ctx);
@@ -319,7 +322,10 @@ template <typename F>
 int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *launches_out)
 {
     // launch(i) issues the launch with index i; the state says which index it expects (PeelCtrl::seq)
-    constexpr int kBatch = 24;
+#ifndef KOMB_PEEL_BATCH
+#define KOMB_PEEL_BATCH 24
+#endif
+    constexpr int kBatch = KOMB_PEEL_BATCH;
     PeelCtrl first;
     KOMB_HIP(ctx, d2h(ctx, &first, d_ctrl, sizeof(PeelCtrl)));
     int32_t next = first.seq;

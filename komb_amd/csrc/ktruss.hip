@@ -82,8 +82,11 @@ __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restric
                                                         int64_t ns, Pred pred, uint32_t *__restrict__ chunk_count,
                                                         const uint32_t *__restrict__ chunk_base,
                                                         int32_t *__restrict__ out_col, int32_t *__restrict__ out_src,
-                                                        unsigned long long *__restrict__ keep_bits)
+                                                        unsigned long long *__restrict__ keep_bits,
+                                                        unsigned long long *__restrict__ keep_upper_bits)
 {
+    // keep_upper_bits (nullable, pass 1): the kept slots whose column is above their row -- the canonical (u < v) copies
+    // that are also the oriented copies; the result gather ranks the others through them
     // keep_bits: one bit per slot (64-slot words = one wavefront ballot).  Pass 1 evaluates the predicate
     // and records it; pass 2 only replays the bits (no second gather of the predicate's operands).
     __shared__ uint32_t sh_wave[kBlock / kWave];
@@ -99,8 +102,10 @@ __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restric
             const int64_t jw = j - lane;                        // first slot of this wave's 64 (multiple of 64)
             bool keep = false;
             if (!FILL) {
-                if (j < ns) keep = pred(src[j], col[j]);
+                bool up = false;
+                if (j < ns) { const int32_t a = src[j], b = col[j]; keep = pred(a, b); up = keep && b > a; }
                 const uint64_t m = __ballot(keep);
+                if (keep_upper_bits) { const uint64_t mu = __ballot(up); if (lane == 0 && jw < ns) keep_upper_bits[jw >> 6] = mu; }
                 if (lane == 0 && jw < ns) keep_bits[jw >> 6] = m;
                 total += (uint32_t)__popcll(m);
                 continue;
@@ -1067,25 +1072,52 @@ struct TrussLocal {
 };
 
 // -------------------------------------------------------------- result gather
-// One thread per slot of the working CSR.  Upper slots (u < v) are the canonical
-// copies of the edges; they are the suffix of their (ascending) row, so the
-// canonical id is ebase[u] + (j - first upper slot of u) with no compaction.
-// The oriented slot of {u,v} -- where trussness and support live -- is found by
-// a binary search of the tiny oriented row of the lower-(degree,id) endpoint.
-__global__ __launch_bounds__(kBlock) void k_pack_results(const int32_t *__restrict__ truss, const uint32_t *__restrict__ off,
-                                                         int64_t m, int2 *__restrict__ res)
+// One thread per slot of the working CSR.  Upper slots (u < v) are the canonical copies of the edges; they are the
+// suffix of their (ascending) row, so the canonical id c of slot j is ebase[u] + (j - first upper slot of u) -- which is
+// also the number of upper slots before j.  Where trussness and support live is the ORIENTED slot of {u,v}:
+//   - u precedes v: the oriented copy is this very slot; its oriented id is its rank among the kept slots (per-word rank
+//     array of the orientation's bitmask + a popcount): no search, no gather.
+//   - v precedes u: the oriented copy is the slot (v,u) of row v.  Those edges are the "reversed" oriented slots (source
+//     id above target id).  Listed in oriented order they are sorted by (v, u); a STABLE sort by their target u puts them
+//     in (u, v) order -- exactly the order in which the not-kept upper slots follow each other in the CSR.  So the k-th
+//     not-kept upper slot is the k-th entry of that sorted list, and k = c - (kept upper slots before j): a stream on
+//     both sides.  (Until round 3 this case binary-searched u in v's oriented row: 3.5 random lines per edge, 4.7 ms of
+//     a 31 ms step; the sort of the 50 M (target, oriented id) pairs and this pass take 2.x ms.)
+__global__ __launch_bounds__(kBlock) void k_popc_words(const unsigned long long *__restrict__ bits, int64_t nwords, uint32_t *__restrict__ cnt)
 {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock)
-        res[e] = make_int2(truss[e], (int)(off[e + 1] - off[e]));
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w <= nwords; w += (int64_t)gridDim.x * kBlock)
+        cnt[w] = w < nwords ? (uint32_t)__popcll(bits[w]) : 0u;
+}
+
+// the reversed oriented slots = the kept LOWER slots of the CSR, in slot order: (key = target id, value = the edge's
+// (trussness, support)) at its rank among them = oriented id - kept upper slots before it.  Everything is a stream:
+// the oriented id of a kept slot grows with the slot index.
+__global__ __launch_bounds__(kBlock) void k_rev_emit(const int32_t *__restrict__ col, int64_t ns,
+                                                     const unsigned long long *__restrict__ obits, const uint32_t *__restrict__ wrank,
+                                                     const unsigned long long *__restrict__ kubits, const uint32_t *__restrict__ kurank,
+                                                     const int32_t *__restrict__ truss, const uint32_t *__restrict__ off,
+                                                     uint32_t *__restrict__ rkey, unsigned long long *__restrict__ rval)
+{
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long word = obits[j >> 6], ku = kubits[j >> 6];
+        if (!(((word & ~ku) >> (j & 63)) & 1ull)) continue;            // not a kept lower slot
+        const unsigned long long below = (1ull << (j & 63)) - 1ull;
+        const uint32_t o = wrank[j >> 6] + (uint32_t)__popcll(word & below);
+        const uint32_t rr = o - (kurank[j >> 6] + (uint32_t)__popcll(ku & below));
+        rkey[rr] = (uint32_t)col[j];
+        rval[rr] = (unsigned long long)(uint32_t)truss[o] | ((unsigned long long)(off[o + 1] - off[o]) << 32);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
                                                              const int32_t *__restrict__ col, int64_t ns,
                                                              const unsigned long long *__restrict__ obits,
                                                              const uint32_t *__restrict__ wrank,
+                                                             const unsigned long long *__restrict__ kubits,
+                                                             const uint32_t *__restrict__ kurank,
+                                                             const unsigned long long *__restrict__ rev_sorted,
                                                              const uint32_t *__restrict__ ebase,
-                                                             const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
-                                                             const int2 *__restrict__ res,
+                                                             const int32_t *__restrict__ truss, const uint32_t *__restrict__ off,
                                                              int32_t *__restrict__ eu, int32_t *__restrict__ ev,
                                                              int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
@@ -1094,25 +1126,20 @@ __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__r
         if (v <= u) continue;
         const uint32_t eb = ebase[u];
         const uint32_t first_upper = rowptr[u + 1] - (ebase[u + 1] - eb);
-        const uint32_t o = eb + ((uint32_t)j - first_upper);
+        const uint32_t c = eb + ((uint32_t)j - first_upper);
         const unsigned long long word = obits[j >> 6];
-        const bool u_first = (word >> (j & 63)) & 1ull;                // slot (u,v) is the oriented copy: u precedes v
-        uint32_t lo;
-        if (u_first) {
-            // the oriented slot is this slot's own position in the compaction: no search, no gather
-            lo = wrank[j >> 6] + (uint32_t)__popcll(word & ((1ull << (j & 63)) - 1ull));
+        const unsigned long long below = (1ull << (j & 63)) - 1ull;
+        int32_t t, sp;
+        if ((word >> (j & 63)) & 1ull) {                               // slot (u,v) is the oriented copy
+            const uint32_t o = wrank[j >> 6] + (uint32_t)__popcll(word & below);
+            t = truss[o]; sp = (int32_t)(off[o + 1] - off[o]);
         } else {
-            lo = orow[v];
-            uint32_t hi = orow[v + 1];
-            while (lo < hi) {                                   // u is present in v's oriented row by construction
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (ocol[mid] < u) lo = mid + 1; else hi = mid;
-            }
+            const unsigned long long r = rev_sorted[c - (kurank[j >> 6] + (uint32_t)__popcll(kubits[j >> 6] & below))];
+            t = (int32_t)(uint32_t)r; sp = (int32_t)(uint32_t)(r >> 32);
         }
-        const int2 r = res[lo];
-        eu[o] = u; ev[o] = v;
-        tr_out[o] = r.x;
-        sup_out[o] = r.y;
+        eu[c] = u; ev[c] = v;
+        tr_out[c] = t;
+        sup_out[c] = sp;
     }
 }
 
@@ -1159,7 +1186,8 @@ void truss_free(komb_ctx *ctx)
 template <class Pred>
 static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const int32_t *col, int64_t ns, int64_t nv, Pred pred,
                          uint32_t *out_rowptr, int32_t **out_col, int32_t **out_src, int64_t *n_out,
-                         unsigned long long **keep_bits_out = nullptr, uint32_t **word_rank_out = nullptr)
+                         unsigned long long **keep_bits_out = nullptr, uint32_t **word_rank_out = nullptr,
+                         unsigned long long **keep_upper_out = nullptr)
 {
     hipStream_t s = ctx->stream;
     const int64_t nchunks = (ns + kChunkSlots - 1) / kChunkSlots;
@@ -1170,13 +1198,16 @@ static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const
     KOMB_HIP(ctx, bufs.alloc(&d_bits, (size_t)(ns + 63) / 64 + 1));
     KOMB_HIP(ctx, hipMemsetAsync(d_cc, 0, ((size_t)nchunks + 1) * sizeof(uint32_t), s));
     const int g = grid_for(nchunks, 1, 256 * 32);
-    k_slot_filter<Pred, false><<<g, kBlock, 0, s>>>(src, col, ns, pred, d_cc, nullptr, nullptr, nullptr, d_bits);
+    unsigned long long *d_kub = nullptr;
+    if (keep_upper_out) KOMB_HIP(ctx, bufs.alloc(&d_kub, (size_t)(ns + 63) / 64 + 1));
+    k_slot_filter<Pred, false><<<g, kBlock, 0, s>>>(src, col, ns, pred, d_cc, nullptr, nullptr, nullptr, d_bits, d_kub);
+    if (keep_upper_out) *keep_upper_out = d_kub;
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cc, d_cb, nchunks + 1));
     uint32_t kept = 0;
     KOMB_HIP(ctx, d2h(ctx, &kept, d_cb + nchunks, sizeof(uint32_t)));
     KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept + 4));        // + 4: the triangle enumeration reads 16 bytes at a time
     KOMB_HIP(ctx, bufs.alloc(out_src, (size_t)kept));
-    k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits);
+    k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits, nullptr);
     if ((int64_t)kept * 4 < nv) k_rowptr_search<<<grid_for(nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
     else k_rowptr_from_src<<<grid_for(kept), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
     if (word_rank_out) {
@@ -1249,7 +1280,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     int64_t m = 0;
     unsigned long long *d_obits = nullptr;                           // bit j: working slot j is the oriented copy of its edge
     uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
-    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank));
+    unsigned long long *d_kubits = nullptr;                          // ... and is an upper slot (its row's id below its column's)
+    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits));
     st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
 
@@ -1730,10 +1762,30 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-    int2 *d_res = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
-    k_pack_results<<<grid_for(m), kBlock, 0, s>>>(d_truss, d_off, m, d_res);
-    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_ebase, d_orow, d_ocol, d_res,
+    // the reversed oriented slots (source id above target id), stably sorted by target: see k_gather_canonical
+    const int64_t nwords = (w_ns + 63) / 64;
+    uint32_t *d_kurank = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_kurank, (size_t)nwords + 1));
+    k_popc_words<<<grid_for(nwords + 1), kBlock, 0, s>>>(d_kubits, nwords, d_kurank);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_kurank, d_kurank, nwords + 1));
+    uint32_t kept_upper = 0;
+    KOMB_HIP(ctx, d2h(ctx, &kept_upper, d_kurank + nwords, sizeof(uint32_t)));
+    const int64_t n_rev = m - (int64_t)kept_upper;
+    uint32_t *d_rkey = nullptr, *d_rkey2 = nullptr;
+    unsigned long long *d_rval = nullptr, *d_rval2 = nullptr, *d_rev_sorted = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_rkey, (size_t)n_rev + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_rkey2, (size_t)n_rev + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_rval, (size_t)n_rev + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_rval2, (size_t)n_rev + 1));
+    d_rev_sorted = d_rval;
+    if (n_rev > 0) {
+        k_rev_emit<<<grid_for(w_ns), kBlock, 0, s>>>(w_col, w_ns, d_obits, d_wrank, d_kubits, d_kurank, d_truss, d_off, d_rkey, d_rval);
+        int vbits = 1;
+        while (vbits < 32 && (1ll << vbits) < nv) ++vbits;
+        uint32_t *sk = nullptr;
+        KOMB_TRY(prim_sort_pairs_u32_u64(ctx, d_rkey, d_rkey2, d_rval, d_rval2, n_rev, 0, vbits, &sk, &d_rev_sorted));
+    }
+    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_kubits, d_kurank, d_rev_sorted, d_ebase, d_truss, d_off,
                                                         ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
     ctx->t_ne = m;
