@@ -306,8 +306,10 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                                                       uint32_t *own, uint32_t *other_or_cursor,
                                                       const OffT *__restrict__ off, int2 *__restrict__ inc,
                                                       int2 *__restrict__ dense, unsigned long long *dense_cursor, unsigned long long dense_cap,
-                                                      unsigned long long *__restrict__ ownoff, int ablate, TriStream ts)
+                                                      unsigned long long *__restrict__ ownoff, int ablate, TriStream ts, int tv)
 {
+    // tv: consecutive source vertices per task (<= kTriV).  Fewer than kTriV when the graph has few vertices for its work
+    // (a 20 000-vertex graph with 4 M edges is 1 250 tasks of 16 vertices: not even one per SIMD)
     static_assert(!STREAM || (MODE == TRI_SINGLE && DENSE), "the record stream replaces the slices of the single pass");
     // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all,
     // 16 = no own-role stores, 32 = no third-role atomic + store
@@ -364,8 +366,8 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
     if (lane == 0 && gw < 16384) g_tri_prof[2 * gw] = wall_clock64();
 #endif
     for (int64_t task = task_lo + gw; task < task_hi; task += nw) {
-      const int64_t v0t = task * kTriV;
-      const int nvt_all = (int)min((int64_t)kTriV, nv - v0t);
+      const int64_t v0t = task * tv;
+      const int nvt_all = (int)min((int64_t)tv, nv - v0t);
       const uint32_t myrow = (lane <= nvt_all) ? orow[v0t + lane] : 0u;       // lane l holds orow[v0t + l]
       // A task whose rows exceed the LDS budget is cut into sub-ranges of consecutive vertices that fit;
       // only a single row longer than the budget runs unstaged (global binary search, global atomics).
@@ -385,6 +387,13 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
         const uint32_t E = S1 - S0;
         if (E == 0) continue;
         const bool staged = E <= (uint32_t)kTriCap;
+        // Signature width of this sub-range: its rows share the wave's kTriSigW * kTriV words -- 256 bits each when all kTriV
+        // rows are staged together, up to 4096 bits when a single long row is (a 200-slot row fills 256 bits to 54%, which
+        // rejects next to nothing: dense graphs ran the lookup for most of their probes)
+        int sig_lw = 0;                                         // (wave-uniform) log2 of the words per row
+        while ((kTriSigW << (sig_lw + 1)) * nvt <= kTriSigW * kTriV) ++sig_lw;
+        const int sig_w = kTriSigW << sig_lw;
+        const int sig_shift = kTriSigShift - sig_lw;
         if (staged) {
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { s_col[k] = ocol[S0 + k]; s_cnt[k] = 0u; }
             for (int x = lane; x < kTriSigW * kTriV; x += kWave) s_sig[x] = 0u;
@@ -393,8 +402,8 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
                 int lo = 0, hi = nvt - 1;
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_orow[mid] <= S0 + k) lo = mid; else hi = mid - 1; }
-                const uint32_t hb = ((uint32_t)s_col[k] * 0x9E3779B1u) >> kTriSigShift;
-                atomicOr(&s_sig[kTriSigW * lo + (int)(hb >> 5)], 1u << (hb & 31u));
+                const uint32_t hb = ((uint32_t)s_col[k] * 0x9E3779B1u) >> sig_shift;
+                atomicOr(&s_sig[sig_w * lo + (int)(hb >> 5)], 1u << (hb & 31u));
                 s_rid[k] = (uint8_t)lo;                                   // the edge's source row, for the batches below
             }
         }
@@ -580,8 +589,8 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                     for (int k = 0; k < kTriR; ++k) {
                         bool cand = false;
                         if ((uint32_t)k < nin && !(ablate & 2)) {
-                            const uint32_t hb = ((uint32_t)wv[k] * 0x9E3779B1u) >> kTriSigShift;
-                            cand = (s_sig[kTriSigW * r + (hb >> 5)] >> (hb & 31u)) & 1u;
+                            const uint32_t hb = ((uint32_t)wv[k] * 0x9E3779B1u) >> sig_shift;
+                            cand = (s_sig[(uint32_t)sig_w * r + (hb >> 5)] >> (hb & 31u)) & 1u;
                         }
                         const uint64_t cm = __ballot(cand);
                         if (cm) {
@@ -1287,8 +1296,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
 
     // ---- triangle support + incidence index
     const int ge = grid_for(m);
-    const int gt = grid_for((nv + kTriV - 1) / kTriV, kTriWaves);
-    const int64_t ntasks = (nv + kTriV - 1) / kTriV;
+    // vertices per enumeration task: kTriV, fewer when that leaves the chip without enough tasks (>= 4 per resident wavefront)
+    const int tri_tv = (int)std::max<int64_t>(1, std::min<int64_t>(kTriV, nv / (256 * KOMB_TRI_EU * kTriWaves * 4)));
+    const int64_t ntasks = (nv + tri_tv - 1) / tri_tv;
+    const int gt = grid_for(ntasks, kTriWaves);
     uint32_t *d_own = nullptr, *d_other = nullptr, *d_cnt = nullptr, *d_off = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_own, 2 * ((size_t)m + 1)));         // [own | other] contiguous: one all-reduce
     d_other = d_own + ((size_t)m + 1);
@@ -1342,7 +1353,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (world > 1) {
         const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
         ctx->timer.start(s);
-        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
+        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
         st.ms_tri_count = ctx->timer.stop(s);
         k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
         // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
@@ -1396,7 +1407,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel};
             ctx->timer.start(s);
             k_triangles<TRI_SINGLE, uint32_t, false, true, true><<<gts, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr,
-                                                                                      d_owndense, d_dcur, own_cap, d_ownoff, ablate, ts);
+                                                                                      d_owndense, d_dcur, own_cap, d_ownoff, ablate, ts, tri_tv);
             st.ms_tri_fill = ctx->timer.stop(s);
             unsigned long long dc[4] = {0, 0, 0, 0};
             KOMB_HIP(ctx, d2h(ctx, dc, d_dcur, sizeof(dc)));
@@ -1483,12 +1494,12 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
         if (single) {
             if (d_offc64) {
-                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream);
-                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
+                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream, tri_tv);
+                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
             } else {
                 k_back_cursors<<<ge, kBlock, 0, s>>>(d_offc, m, d_other);
-                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream);
-                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
+                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream, tri_tv);
+                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
             }
             st.ms_tri_fill = ctx->timer.stop(s);
             KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
@@ -1526,7 +1537,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             k_total_u32<<<ge, kBlock, 0, s>>>(d_cnt, m + 1, d_mom + 5);
         } else if (!have_counts) {
             ctx->timer.start(s);
-            k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
+            k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
             st.ms_tri_count = ctx->timer.stop(s);
             k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
         }
@@ -1584,7 +1595,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         ctx->timer.start(s);
         KOMB_HIP(ctx, zero_counts());
         k_back_cursors<<<ge, kBlock, 0, s>>>(d_off, m, d_other);
-        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, 0ull, nullptr, ablate, no_stream);
+        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_sort + st.ms_compact;
