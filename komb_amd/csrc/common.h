@@ -80,7 +80,7 @@ static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
 struct LocalCtrl {
     int32_t  done;           // 1 once a sweep changed nothing
     int32_t  iters;          // sweeps run (including the one that changed nothing)
-    uint32_t spare[3];       // (the per-sweep change counters live in their own array, spread over several lines)
+    uint32_t spare[3];       // [0]: the sweep that is running (progress word for the host's guard); the per-sweep change counters live in their own array
     uint32_t bad;            // consistency failures (a compact slice whose fill differs from the live key, ...)
     int32_t  max_val;        // largest final value (k_local_finish)
     uint32_t levels;         // distinct final values (k_local_levels)
@@ -154,6 +154,22 @@ struct Timer {                               // HIP-event stopwatch on one strea
     void destroy() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); a = b = nullptr; }
 };
 
+// HIP events that are destroyed on every way out of the scope that made them (error returns included)
+struct EventSet {
+    std::vector<hipEvent_t> v;
+    EventSet() = default;
+    EventSet(const EventSet &) = delete;
+    EventSet &operator=(const EventSet &) = delete;
+    hipError_t make(hipEvent_t *out, unsigned flags = 0)
+    {
+        hipEvent_t e = nullptr;
+        const hipError_t rc = flags ? hipEventCreateWithFlags(&e, flags) : hipEventCreate(&e);
+        if (rc == hipSuccess) { v.push_back(e); *out = e; }
+        return rc;
+    }
+    ~EventSet() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+};
+
 } // namespace komb
 
 // Caching device allocator: a step's scratch buffers are returned to the pool,
@@ -184,6 +200,12 @@ struct DevPool {
     {
         if (!p) return;
         for (auto &b : blocks) if (b.p == p) { b.used = false; return; }
+    }
+    size_t unused_bytes() const                      // cached blocks nobody holds: a large request gets them back (trim) before it fails
+    {
+        size_t t = 0;
+        for (const auto &b : blocks) if (!b.used) t += b.bytes;
+        return t;
     }
     void trim()                                      // free every unused block
     {
@@ -361,9 +383,10 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
         return KOMB_OK;
     }
 #endif
+    EventSet evs;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    KOMB_HIP(ctx, evs.make(&ev[0], hipEventDisableTiming));
+    KOMB_HIP(ctx, evs.make(&ev[1], hipEventDisableTiming));
     const int64_t max_batches = (4 * units + 4096) / kBatch + 16;   // > 2 launches per unit: cannot be reached
     int launches = 0, slot = 0, status = KOMB_OK;
     bool have_prev = false, finished = false, stuck = false;
@@ -383,8 +406,6 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
         slot ^= 1;
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
     if (launches_out) *launches_out = launches;
     if (status != KOMB_OK || e != hipSuccess)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "peel driver: HIP failure (%s)", hipGetErrorString(e));

@@ -107,7 +107,8 @@ struct CoreCollect {
     {
         if (!ld.live) return;
         const uint32_t id = (uint32_t)num[ld.me];
-        nbr[off[id] + local_slot(id, cur)] = (uint32_t)num[ld.u];
+        const uint32_t b0 = off[id], k = local_slot(id, cur);           // (bounded: see TrussCollect)
+        if (k < off[id + 1] - b0) nbr[b0 + k] = (uint32_t)num[ld.u];
     }
 };
 
@@ -262,8 +263,9 @@ int core_run(komb_ctx *ctx)
     auto run_local = [&]() -> int {
         const PeelCtrl hc = ctx->h_ctrl[0];
         Range r_local("core: local finish");
+        EventSet evs;
         hipEvent_t ev[2] = {nullptr, nullptr};
-        for (auto &e : ev) KOMB_HIP(ctx, hipEventCreate(&e));
+        for (auto &e : ev) KOMB_HIP(ctx, evs.make(&e));
         (void)hipEventRecord(ev[0], s);
         KOMB_HIP(ctx, hipMemsetAsync(d_livebits, 0, live_words * sizeof(unsigned long long), s));
         LocalStats ls;
@@ -282,7 +284,6 @@ int core_run(komb_ctx *ctx)
         (void)hipEventSynchronize(ev[1]);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-        for (auto &e : ev) (void)hipEventDestroy(e);
         KOMB_TRY(rc);
         if (ls.refused) { ctx->h_ctrl[0].done = 0; ctx->h_ctrl[0].tail_limit = ls.new_limit; return KOMB_OK; }
         stt.core_local_units = (int32_t)ls.units; stt.core_local_sweeps = ls.sweeps; stt.core_local_items = (int64_t)ls.items;

@@ -1055,7 +1055,10 @@ struct TrussCollect {
     {
         if (!marker_alive(ld.sx) || !marker_alive(ld.sy)) return;
         const uint32_t id = (uint32_t)num[ld.me];
-        cpair[coff[id] + local_slot(id, cur)] = make_uint2((uint32_t)num[ld.x], (uint32_t)num[ld.y]);
+        // (bounded: a unit whose live items outnumber its live key -- an inconsistent index -- is reported by k_local_check
+        // from its cursor, never written past its slice)
+        const uint32_t b0 = coff[id], k = local_slot(id, cur);
+        if (k < coff[id + 1] - b0) cpair[b0 + k] = make_uint2((uint32_t)num[ld.x], (uint32_t)num[ld.y]);
     }
 };
 
@@ -1387,9 +1390,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         unsigned long long t_bound = bound / 2;
         unsigned long long rec_cap = 3 * t_bound + (3 * t_bound) / 14 + slack;
         if (const char *rc = getenv("KOMB_REC_CAP")) rec_cap = strtoull(rc, nullptr, 10) + 1;            // (tests: a stream that runs out)
+        // (what the pool holds unused counts as free: the choice must not depend on what an earlier call left cached)
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const unsigned long long budget = (unsigned long long)(free_b * 0.7);
+        const unsigned long long budget = (unsigned long long)((free_b + ctx->pool.unused_bytes()) * 0.7);
         if (own_cap * sizeof(int2) > budget / 2) own_cap = budget / 2 / sizeof(int2);
         if (rec_cap * 12ull > budget / 2) rec_cap = budget / 2 / 12ull;
         if (rec_cap > 0xFFFFFFF0ull) rec_cap = 0xFFFFFFF0ull;        // 32-bit record positions
@@ -1683,8 +1687,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // local finish: compact the live sub-index, sweep the h-index operator to its fixed point (local_dev.h)
     auto run_local = [&]() -> int {
         const PeelCtrl hc = ctx->h_ctrl[0];
+        EventSet evs;
         hipEvent_t ev[2] = {nullptr, nullptr};
-        for (auto &e : ev) KOMB_HIP(ctx, hipEventCreate(&e));
+        for (auto &e : ev) KOMB_HIP(ctx, evs.make(&e));
         (void)hipEventRecord(ev[0], s);
         LocalStats ls;
         const int lrc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)m, d_stamp, d_sup, Q.live[hc.live_sel],
@@ -1701,7 +1706,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         (void)hipEventSynchronize(ev[1]);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-        for (auto &e : ev) (void)hipEventDestroy(e);
         KOMB_TRY(lrc);
         if (ls.refused) { ctx->h_ctrl[0].done = 0; ctx->h_ctrl[0].tail_limit = ls.new_limit; return KOMB_OK; }
         st.truss_local_units = (int32_t)ls.units; st.truss_local_sweeps = ls.sweeps; st.truss_local_items = (int64_t)ls.items;

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(kLocBlock) void k_local_step(LocalCtrl *ctrl, uint3
         return;
     }
     const bool skip_notify = sh_pick[0] & 1u, full = sh_pick[0] & 2u;
+    if (blockIdx.x == 0 && tid == 0) ctrl->spare[0] = (uint32_t)k;     // progress word: the sweep that is running (the host's guard reads it)
     __syncthreads();                                     // sh_pick and sh_m are reused below
     if (blockIdx.x == 0 && tid < (uint32_t)kCntWays) cnt[(((k + 1) & 3) * kCntWays + tid) * 32] = 0u;   // nobody reads or adds to that slot in this launch
     if (blockIdx.x == 0 && tid == 0) cnt[(5 * kCntWays + ((k + 1) % 3)) * 32] = 0u;                    // next sweep's queue of the longest units
@@ -790,16 +791,17 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
     const int grid = 512;                                 // two 512-thread workgroups per CU (<= 96 VGPRs)
     const uint32_t nlight_all = g.n - g.nh;
     const int list_grid = (int)std::min<uint32_t>(256u, (nlight_all + kListBlock - 1) / kListBlock ? (nlight_all + kListBlock - 1) / kListBlock : 1u);
+    EventSet evs;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    KOMB_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    KOMB_HIP(ctx, evs.make(&ev[0], hipEventDisableTiming));
+    KOMB_HIP(ctx, evs.make(&ev[1], hipEventDisableTiming));
     LocalCtrl *h = ctx->h_local;
     // a sweep that changes anything lowers the sum of the values (<= total_items at the start) by at least 1, so this
     // many launches cannot be reached; the loop ends on `done`
     const uint64_t max_launches = total_items + (uint64_t)g.n + 64u;
     int launches = 0, slot = 0, status = KOMB_OK;
-    bool have_prev = false, finished = false;
-    int32_t k = 0;
+    bool have_prev = false, finished = false, stuck = false;
+    int32_t k = 0, seen_iters = -1;
     // KOMB_LOCAL_DEBUG=2: an event after every launch, the per-sweep times on stderr
     // notifications are skipped (and the next sweep is full) while a sweep changes at least an eighth of the units (measured at C3: n/2 .. n/16 within 4%, never = +20%)
     uint32_t full_thr = g.n / 8u + 1u;
@@ -809,36 +811,38 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
     const char *dbg_env = getenv("KOMB_LOCAL_DEBUG");
     const bool per_sweep = dbg_env && atoi(dbg_env) >= 2;
     std::vector<hipEvent_t> sw;
-    if (per_sweep) { sw.resize(1); (void)hipEventCreate(&sw[0]); (void)hipEventRecord(sw[0], s); }
+    if (per_sweep) { sw.resize(1); if (evs.make(&sw[0]) == hipSuccess) (void)hipEventRecord(sw[0], s); }
     while (!finished && (uint64_t)launches < max_launches && k < 0x3FFFFFF0) {
         for (int i = 0; i < kLocBatch; ++i) {
             ++k;
             if (g.flags & kLocUseList) k_local_list<<<list_grid, kListBlock, 0, s>>>(d_ctrl, d_cnt, g, k);
             k_local_step<P><<<grid, kLocBlock, 0, s>>>(d_ctrl, d_cnt, g, p, k, full_thr); ++launches;
             if (g.nchunk && (g.flags & kLocDeferNotify)) k_local_giant_notify<P><<<(int)std::min<uint32_t>(g.nchunk, 1024u), kLocBlock, 0, s>>>(d_ctrl, g, p, k);
-            if (per_sweep && sw.size() < 600) { hipEvent_t e2; (void)hipEventCreate(&e2); (void)hipEventRecord(e2, s); sw.push_back(e2); }
+            if (per_sweep && sw.size() < 600) { hipEvent_t e2 = nullptr; if (evs.make(&e2) == hipSuccess) { (void)hipEventRecord(e2, s); sw.push_back(e2); } }
         }
         if (hipMemcpyAsync(&h[slot], d_ctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipEventRecord(ev[slot], s) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
         if (have_prev) {
             if (hipEventSynchronize(ev[slot ^ 1]) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
+            // a batch of sweeps that neither finished nor counted a single sweep: the kernels are not running the fixed
+            // point any more (the same guard as drive_peel's sequence check) -- fail instead of queueing launches for hours
             if (h[slot ^ 1].done) finished = true;
+            else if ((int32_t)h[slot ^ 1].spare[0] == seen_iters) { stuck = true; finished = true; }
+            seen_iters = (int32_t)h[slot ^ 1].spare[0];
         }
         have_prev = true;
         slot ^= 1;
     }
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
     if (per_sweep) {
         fprintf(stderr, "komb local sweeps (us):");
         for (size_t i = 1; i < sw.size(); ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, sw[i - 1], sw[i]); fprintf(stderr, " %.0f", ms * 1e3f); }
         fprintf(stderr, "\n");
-        for (auto &x : sw) (void)hipEventDestroy(x);
     }
     if (launches_out) *launches_out = launches;
     if (status != KOMB_OK || e != hipSuccess)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local fixed point: HIP failure (%s)", hipGetErrorString(e));
+    if (stuck) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local fixed point: the sweeps make no progress (sweep %d)", (int)seen_iters);
     return KOMB_OK;
 }
 
@@ -867,8 +871,9 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     if (n == 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "local finish: nothing left to hand over");
     // KOMB_LOCAL_DEBUG=1: one stderr line per hand-over with the phase times (HIP events)
     const bool dbg = getenv("KOMB_LOCAL_DEBUG") != nullptr;
+    EventSet evs;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (dbg) for (auto &e : ev) (void)hipEventCreate(&e);
+    if (dbg) for (auto &e : ev) (void)evs.make(&e);
     auto stamp = [&](int i) { if (dbg) (void)hipEventRecord(ev[i], s); };
     stamp(0);
     const int32_t *list = hc.live_mode ? live_list : nullptr;
@@ -944,7 +949,9 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     // takes 0.3 ms off the k-truss fixed point at both sizes and adds 0.1-0.2 ms to k-core's (its units are long: few
     // groups have a single marked unit); the notification kernel pays where hubs are many (k-core at C3: 235 of them in
     // ~600 chunks, -0.13 ms; 3 x C3: -2.4 ms) and costs 0.2-0.4 ms where they are few (C2, k-truss).
-    g.flags = (use_list ? kLocUseList : 0u) | (g.nchunk >= kLocDeferChunks ? kLocDeferNotify : 0u);
+    uint32_t defer_chunks = kLocDeferChunks;
+    if (const char *e = getenv("KOMB_LOCAL_DEFER_CHUNKS")) defer_chunks = (uint32_t)strtoul(e, nullptr, 10);     // (no result depends on it)
+    g.flags = (use_list ? kLocUseList : 0u) | (g.nchunk >= defer_chunks && g.nchunk > 0 ? kLocDeferNotify : 0u);
 #ifdef KOMB_DEBUG_SWITCHES
     if (const char *e = getenv("KOMB_LOCAL_MODE")) g.flags = (uint32_t)atoi(e);      // 1 = list, 2 = notification kernel
 #endif
@@ -996,7 +1003,6 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     if (dbg) {
         float t[4] = {0, 0, 0, 0};
         for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
-        for (auto &e : ev) (void)hipEventDestroy(e);
         fprintf(stderr, "komb local finish: %u units (%u heavy, %u of them long; bound %d), %u items; number+scan %.1f us, collect %.1f us, %d sweeps (%d launches, %u evaluations) %.1f us, scatter %.1f us\n",
                 n, g.nh, g.ng, K == 0x7FFFFFFF ? -1 : K, total, t[0] * 1e3f, t[1] * 1e3f, hl.iters, launches, hl.evals, t[2] * 1e3f, t[3] * 1e3f);
     }

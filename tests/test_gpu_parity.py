@@ -638,6 +638,13 @@ def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
                     st = a.stats()
                     assert st["truss_local_items"] <= int(items) and st["core_local_items"] <= int(items), (name, items, limit)
             monkeypatch.delenv("KOMB_LOCAL_ITEMS", raising=False)
+            # the hubs' notification kernel (k_local_giant_notify; by default only from 256 hub chunks on) with and without
+            # the list of marked units: forced on every graph that has a hub chunk at all
+            monkeypatch.setenv("KOMB_LOCAL_DEFER_CHUNKS", "1")
+            monkeypatch.setenv("KOMB_LOCAL_LIMIT", "4000000000")
+            assert np.array_equal(a.run_core()[1], want_core), (name, "defer")
+            assert np.array_equal(a.run_truss()[2], want_tr), (name, "defer")
+            monkeypatch.delenv("KOMB_LOCAL_DEFER_CHUNKS", raising=False)
             # default density rule: a remainder with more than 160 triangles per edge stays with the peel for good
             monkeypatch.delenv("KOMB_LOCAL_DENSITY", raising=False)
             monkeypatch.setenv("KOMB_LOCAL_LIMIT", "4000000000")
