@@ -310,7 +310,7 @@ def main():
             # record -- are not counted); the sort at its 4 radix passes over 12-byte records, read + write
             kernels["k_triangles<stream>"] = (phase["ms_tri_fill"], 1, ab["tri_count"])
             kernels["record sort (rocPRIM radix, by destination edge)"] = (phase["ms_sort"], 1, 4 * 2 * 12 * st["tri_records"])
-            kernels["k_key_offsets + k_merge_inc"] = (phase["ms_compact"], 2, 16 * st["ne"] + 48 * st["triangles"] + 4 * st["tri_records"])
+            kernels["k_bin_offsets + k_bin_count + k_bin_finish"] = (phase["ms_compact"], 3, 16 * st["ne"] + 48 * st["triangles"] + 4 * st["tri_records"])
         elif layout == 1:                        # ONE enumeration into bounded slices + dense compaction
             kernels["k_triangles<single>"] = (phase["ms_tri_fill"], 1, ab["tri_count"])
             kernels["k_compact_inc"] = (phase["ms_compact"], 1, 16 * st["ne"] + 48 * st["triangles"])

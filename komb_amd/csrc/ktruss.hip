@@ -53,12 +53,31 @@ struct PredMask {                       // keep slot (a,b) when both endpoints a
 };
 struct PredOrient {                     // keep slot (a,b) when a precedes b in (degree,id) order
     const int32_t *deg;
-    const uint8_t *deg8;                // min(deg, 255): a 1-byte-per-vertex table that the L2s and the Infinity Cache hold,
-                                        // so the one random gather per slot rarely goes to HBM; exact degrees only
-                                        // when both endpoints saturate
+    const uint8_t *deg8;                // min(deg, 255): a 1-byte-per-vertex table that the L2s (small graphs) or the Infinity
+                                        // Cache hold; exact degrees only when both endpoints saturate
     __device__ bool operator()(int32_t a, int32_t b) const
     {
         int32_t da = deg8[a], db = deg8[b];
+        if (da == 255 && db == 255) { da = deg[a]; db = deg[b]; }
+        return da < db || (da == db && a < b);
+    }
+};
+struct PredOrientClass {                // the same order, for graphs whose 1-byte table does not fit the L2s
+    const int32_t *deg;
+    const uint8_t *deg8;
+    const uint32_t *deg2;               // a 2-bit degree class per vertex, 16 vertices per word: |V| / 4 bytes (2.5 MB for 10 M
+                                        // vertices) stay in every XCD's L2.  The class is a monotone function of the degree
+                                        // (thresholds t1 <= t2 <= t3 at the quartiles of the slots' endpoint degrees), so two
+                                        // different classes decide the order and only equal classes -- about a third of the
+                                        // slots -- go on to the 1-byte table: the one random gather per slot mostly ends in L2.
+    int32_t t1, t2, t3;
+    __device__ bool operator()(int32_t a, int32_t b) const
+    {
+        int32_t da = deg8[a];                                    // (row-local: the wavefront's slots share a few rows)
+        const int32_t ca = (da > t1) + (da > t2) + (da > t3);
+        const int32_t cb = (int32_t)((deg2[(uint32_t)b >> 4] >> (((uint32_t)b & 15u) * 2u)) & 3u);
+        if (ca != cb) return ca < cb;
+        int32_t db = deg8[b];
         if (da == 255 && db == 255) { da = deg[a]; db = deg[b]; }
         return da < db || (da == db && a < b);
     }
@@ -202,13 +221,35 @@ __global__ __launch_bounds__(kBlock) void k_upper_count(const uint32_t *__restri
     }
 }
 
+// degrees, their 1-byte copies, and hist[d] = slots whose row has degree min(d, 255) (the distribution of the slots'
+// endpoint degrees: the orientation's class thresholds are its quartiles)
 __global__ __launch_bounds__(kBlock) void k_degree(const uint32_t *__restrict__ rowptr, int64_t nv, int32_t *__restrict__ deg,
-                                                   uint8_t *__restrict__ deg8)
+                                                   uint8_t *__restrict__ deg8, unsigned long long *__restrict__ hist)
 {
+    __shared__ uint32_t sh_h[256];
+    sh_h[threadIdx.x] = 0u;                                     // kBlock == 256
+    __syncthreads();
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
         const int32_t d = (int32_t)(rowptr[v + 1] - rowptr[v]);
         deg[v] = d;
         deg8[v] = (uint8_t)min(d, 255);
+        if (d) atomicAdd(&sh_h[min(d, 255)], (uint32_t)d);      // (a workgroup's rows hold fewer than 2^32 slots: the CSR does)
+    }
+    __syncthreads();
+    if (sh_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh_h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_degree_classes(const uint8_t *__restrict__ deg8, int64_t nv, int32_t t1, int32_t t2, int32_t t3,
+                                                           uint32_t *__restrict__ deg2)
+{
+    const int64_t nw = (nv + 15) / 16;
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < nw; w += (int64_t)gridDim.x * kBlock) {
+        uint32_t word = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int64_t v = w * 16 + k;
+            if (v < nv) { const int32_t d = deg8[v]; word |= (uint32_t)((d > t1) + (d > t2) + (d > t3)) << (2 * k); }
+        }
+        deg2[w] = word;
     }
 }
 
@@ -1287,13 +1328,36 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     ctx->timer.start(s);
     uint8_t *d_deg8 = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_deg8, (size_t)nv));
-    k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg, d_deg8);
+    // graphs whose 1-byte degree table outgrows the L2s (4 MiB per XCD) decide most slots on a 2-bit class table first
+    const bool use_classes = (nv > (4ll << 20) || getenv("KOMB_DEG_CLASSES")) && !getenv("KOMB_NO_DEG_CLASSES");   // (no result depends on it)
+    unsigned long long *d_dhist = nullptr;
+    uint32_t *d_deg2 = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_dhist, 256));
+    KOMB_HIP(ctx, hipMemsetAsync(d_dhist, 0, 256 * sizeof(unsigned long long), s));
+    k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg, d_deg8, d_dhist);
+    int32_t dth[3] = {255, 255, 255};
+    if (use_classes) {
+        // class thresholds: the quartiles of the slots' endpoint degrees (capped at 255)
+        KOMB_HIP(ctx, bufs.alloc(&d_deg2, (size_t)(nv + 15) / 16 + 1));
+        unsigned long long hh[256];
+        KOMB_HIP(ctx, d2h(ctx, hh, d_dhist, sizeof(hh)));
+        unsigned long long all = 0, run = 0;
+        for (int d = 0; d < 256; ++d) all += hh[d];
+        int q = 0;
+        for (int d = 0; d < 256 && q < 3; ++d) {
+            run += hh[d];
+            while (q < 3 && run * 4 >= all * (unsigned long long)(q + 1)) dth[q++] = d;
+        }
+        k_degree_classes<<<grid_for((nv + 15) / 16), kBlock, 0, s>>>(d_deg8, nv, dth[0], dth[1], dth[2], d_deg2);
+    }
+    bufs.release(d_dhist);
     int32_t *d_ocol = nullptr, *d_osrc = nullptr;
     int64_t m = 0;
     unsigned long long *d_obits = nullptr;                           // bit j: working slot j is the oriented copy of its edge
     uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
     unsigned long long *d_kubits = nullptr;                          // ... and is an upper slot (its row's id below its column's)
-    KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits));
+    if (use_classes) KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrientClass{d_deg, d_deg8, d_deg2, dth[0], dth[1], dth[2]}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits));
+    else KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits));
     st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
 

@@ -274,6 +274,28 @@ def test_index_layouts_agree(K, O, monkeypatch):
                 assert np.array_equal(x, y), kv
 
 
+def test_orientation_class_table(K, O, monkeypatch):
+    """Graphs above 4M vertices decide the orientation on a 2-bit degree-class table before the 1-byte one (the full-size C3
+    test runs that way); here the table is forced on small graphs -- power-law, regular (one class for everybody), dense --
+    and must change nothing."""
+    rng = np.random.default_rng(31)
+    ring = np.stack([np.arange(3000), (np.arange(3000) + 1) % 3000], axis=1)
+    cases = [(40000, K.gen_hug_edges(40000, 110000, 2.3, 21)), (3000, np.concatenate([ring, np.roll(ring, 1, axis=1)]).astype(np.int64)),
+             (600, rng.integers(0, 600, (40000, 2)).astype(np.int64)), (70000, K.gen_hug_edges(70000, 180000, 2.1, 3))]
+    for nv, uv in cases:
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            monkeypatch.delenv("KOMB_DEG_CLASSES", raising=False)
+            r0 = a.run_truss(with_support=True)
+            monkeypatch.setenv("KOMB_DEG_CLASSES", "1")
+            r1 = a.run_truss(with_support=True)
+            monkeypatch.delenv("KOMB_DEG_CLASSES", raising=False)
+            for x, y in zip(r0, r1):
+                assert np.array_equal(x, y)
+            rowptr, col = a.get_csr()
+            assert np.array_equal(r1[2], O.trussness(rowptr, col))
+
+
 def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
     """A graph whose capacity-bounded slices hold more than 2^32 entries by themselves (dense uniform random, 30 000
     vertices, ~12.5 M edges of degree ~830: sum over edges of d(lower endpoint) - 1 ~ 1e10), so the single pass runs with
