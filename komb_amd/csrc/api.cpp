@@ -51,6 +51,7 @@ komb_ctx *komb_create(const komb_opts *opts)
     e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctrl, 2 * sizeof(PeelCtrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_local, 2 * sizeof(LocalCtrl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_stage, kStageBytes, hipHostMallocDefault);
     // The library works on the device's default (legacy) stream.  A stream of its own (hipStreamNonBlocking) was tried in
     // order to run independent work beside the peel: there was nothing to gain (both sides are bound by HBM), and
     // with two processes sharing one GPU the peel's launch-to-launch hand-over of its control block became unreliable on it
@@ -75,6 +76,7 @@ void komb_destroy(komb_ctx *ctx)
         ctx->timer.destroy();
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
         if (ctx->h_local) (void)hipHostFree(ctx->h_local);
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     }
     delete ctx;
 }

@@ -249,6 +249,7 @@ struct komb_ctx {
     // ---- pinned host mirrors of the control blocks (double buffered)
     komb::PeelCtrl *h_ctrl = nullptr;        // [2]
     komb::LocalCtrl *h_local = nullptr;      // [2]
+    void *h_stage = nullptr;                 // pinned landing area of the small device-to-host reads (kStageBytes)
 
     komb_stats stats{};
 };
@@ -300,9 +301,18 @@ struct DevBufs {
         if (_s != KOMB_OK) return _s;          \
     } while (0)
 
-// small blocking device-to-host read, ordered on the context's stream
+// small blocking device-to-host read, ordered on the context's stream.  It lands in pinned memory: a copy into pageable
+// memory (a variable on the caller's stack) costs 50-100 us in the runtime alone, and a step makes a dozen of them while
+// the GPU waits for the host's next decision.
+constexpr size_t kStageBytes = 64 << 10;
 inline hipError_t d2h(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
+    if (ctx->h_stage && bytes <= kStageBytes && dst != ctx->h_stage) {
+        hipError_t e = hipMemcpyAsync(ctx->h_stage, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) memcpy(dst, ctx->h_stage, bytes);
+        return e;
+    }
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
 }

@@ -59,8 +59,7 @@ int prim_exclusive_sum_u32(komb_ctx *ctx, const uint32_t *in, uint32_t *out, int
     TempBuf t(ctx);
     KOMB_HIP(ctx, t.get(bytes));
     KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(t.p, bytes, in, out, (int)n, ctx->stream));
-    KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return KOMB_OK;
+    return KOMB_OK;                              // asynchronous on the context's stream (the scratch goes back to the pool, which the same stream uses)
 }
 
 // exclusive sum of 32-bit counts into 64-bit offsets (totals beyond 2^32)
@@ -75,7 +74,6 @@ int prim_exclusive_sum_u32_u64(komb_ctx *ctx, const uint32_t *in, unsigned long 
     TempBuf t(ctx);
     KOMB_HIP(ctx, t.get(bytes));
     KOMB_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(t.p, bytes, wide, out, (int)n, ctx->stream));
-    KOMB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KOMB_OK;
 }
 
