@@ -30,6 +30,8 @@ def short(name):
                 return f"k_peel_step<{nice}>"
     if n.startswith("k_local_step<"):
         return "k_local_step<Truss>" if "TrussLocal" in n else "k_local_step<Core>"
+    if n.startswith("k_triangles<2") and n.split("(")[0].rstrip().endswith("true, true>"):
+        return "k_triangles<stream>"
     for key, nice in (("k_triangles<0", "k_triangles<count>"), ("k_triangles<1", "k_triangles<fill>"),
                       ("k_triangles<2", "k_triangles<single>"), ("k_compact_inc<", "k_compact_inc")):
         if n.startswith(key):
@@ -37,7 +39,7 @@ def short(name):
     if n.startswith("k_slot_filter<"):
         return n.split("(")[0].replace(" ", "")
     if "rocprim" in n:
-        return "rocprim::" + ("radix_sort" if "radix_sort" in n else "scan" if "scan" in n else "partition" if "partition" in n else "other")
+        return "rocprim::" + ("radix_sort" if ("radix_sort" in n or "onesweep" in n) else "scan" if "scan" in n else "partition" if "partition" in n else "other")
     return n.split("(")[0]
 
 
