@@ -177,6 +177,7 @@ struct EventSet {
 struct DevPool {
     struct Block { void *p; size_t bytes; bool used; };
     std::vector<Block> blocks;
+    size_t n_malloc = 0, n_trim = 0;                 // statistics (KOMB_POOL_DEBUG)
     hipError_t get(void **out, size_t bytes)
     {
         if (bytes == 0) bytes = 16;
@@ -186,8 +187,10 @@ struct DevPool {
                 (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = i;
         if (best >= 0) { blocks[best].used = true; *out = blocks[best].p; return hipSuccess; }
         void *q = nullptr;
+        ++n_malloc;
         hipError_t e = hipMalloc(&q, bytes);
         if (e != hipSuccess) {                       // give cached blocks back and retry once
+            ++n_trim;
             trim();
             e = hipMalloc(&q, bytes);
             if (e != hipSuccess) return e;

@@ -875,13 +875,14 @@ __global__ __launch_bounds__(kBlock) void k_count_mismatch(const uint32_t *__res
     block_add_u64(t, bad);
 }
 
-// supports of a bin's edges: dense own-role entries + records of the bin with that key (LDS histogram); 64-bit total on the side.
-// sum[] has m + 1 entries (sum[m] = 0: the scan's total lands there).
+// supports of a bin's edges: dense own-role entries + records of the bin with that key (LDS histogram); per-bin totals
+// (their scan gives every bin its window of the index) and the 64-bit grand total on the side.
 __global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict__ key, const uint32_t *__restrict__ boff, int64_t nb,
                                                       const uint32_t *__restrict__ own, int64_t m, uint32_t *__restrict__ sum,
-                                                      unsigned long long *__restrict__ total)
+                                                      uint32_t *__restrict__ bin_total, unsigned long long *__restrict__ total)
 {
     __shared__ uint32_t sh_cnt[kBinEdges];
+    __shared__ uint32_t sh_part[kBlock / kWave];
     unsigned long long t = 0;
     for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const int64_t x0 = b << kBinBits;
@@ -891,15 +892,25 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict
         const uint32_t r0 = boff[b], r1 = boff[b + 1];
         for (uint32_t r = r0 + threadIdx.x; r < r1; r += kBlock) atomicAdd(&sh_cnt[key[r] - (uint32_t)x0], 1u);
         __syncthreads();
+        uint32_t tb = 0;
         for (uint32_t i = threadIdx.x; i < nx; i += kBlock) {
             const uint32_t c = own[x0 + i] + sh_cnt[i];
             sum[x0 + i] = c;
-            t += c;
+            tb += c;
+        }
+        tb = wave_sum(tb);
+        if (lane_id() == 0) sh_part[threadIdx.x >> 6] = tb;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t all = 0;
+            for (int i = 0; i < kBlock / kWave; ++i) all += sh_part[i];
+            bin_total[b] = all;                                  // (a bin holds 2048 edges: their supports sum to far less than 2^32 ... unless the graph is beyond the index limit, which the 64-bit total reports)
+            t += all;
         }
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) sum[m] = 0u;
-    block_add_u64(t, total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sum[m] = 0u; bin_total[nb] = 0u; }
+    if (threadIdx.x == 0 && t) atomicAdd(total, t);
 }
 
 // Dense index of a bin's edges.  An edge's slice is [its records' values | its own-role entries]; the slices of a
@@ -913,44 +924,91 @@ constexpr int kFinBlock = 512;
 constexpr uint32_t kWinCap = 7168;                 // entries of the LDS window (56 KB; with the two 8 KB tables: 2 workgroups per CU)
 constexpr int kFinE = (int)(kBinEdges / kFinBlock);          // consecutive edges per thread
 constexpr int kFinU = 4;                           // records per thread per trip
-static_assert(kFinE == 4, "a thread loads its edges' offsets and counts as one 16-byte vector each");
+static_assert(kFinE == 4, "a thread loads its edges' supports and own-role counts as one 16-byte vector each");
+// The kernel also does what followed the index build: the slice offsets off[] (a workgroup scan of the bin's supports on
+// top of the bin's base -- the 100 M-element device scan is gone) and the peel's initial state (support, alive marker or
+// "gone" for a triangle-free edge, the count of those and the smallest positive support for the first level).
 __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__restrict__ key, const int2 *__restrict__ val,
                                                          const uint32_t *__restrict__ boff, int64_t nb,
-                                                         const uint32_t *__restrict__ own, const uint32_t *__restrict__ off,
+                                                         const uint32_t *__restrict__ own, const uint32_t *__restrict__ cnt,
+                                                         const uint32_t *__restrict__ bin_base,
                                                          const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
-                                                         int2 *__restrict__ dense, int64_t m)
+                                                         int2 *__restrict__ dense, int64_t m,
+                                                         uint32_t *__restrict__ off, int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
+                                                         int32_t *__restrict__ truss, uint32_t *__restrict__ init)
 {
     __shared__ uint32_t sh_off[kBinEdges + 4];     // slice offsets relative to the window
     __shared__ uint32_t sh_cur[kBinEdges];
+    __shared__ uint32_t sh_wsum[kFinBlock / kWave];
     __shared__ int2 sh_win[kWinCap];
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    uint32_t zeros = 0;
+    int32_t lmin = 0x7FFFFFFF;
     for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const int64_t x0 = b << kBinBits;
         const uint32_t nx = (uint32_t)min((int64_t)kBinEdges, m - x0);
         const uint64_t r0 = boff[b], r1 = boff[b + 1];
-        const uint32_t base = off[x0];
-        // ---- the thread's 4 consecutive edges: offsets and own-role counts, then (for the edges that have some) where their blocks are
+        const uint32_t base = bin_base[b];
+        // ---- the thread's 4 consecutive edges: supports and own-role counts, then (for the edges that have some) where their blocks are
         const uint32_t i0 = threadIdx.x * (uint32_t)kFinE;
-        uint32_t o[kFinE + 1], ow[kFinE];
+        uint32_t c[kFinE], ow[kFinE];
         unsigned long long oo[kFinE];
         if (i0 + kFinE <= nx) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(off + x0 + i0);
-            const uint4 w = *reinterpret_cast<const uint4 *>(own + x0 + i0);
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; o[4] = off[x0 + i0 + kFinE];
-            ow[0] = w.x; ow[1] = w.y; ow[2] = w.z; ow[3] = w.w;
+            const uint4 v = *reinterpret_cast<const uint4 *>(cnt + x0 + i0);
+            const uint4 q = *reinterpret_cast<const uint4 *>(own + x0 + i0);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+            ow[0] = q.x; ow[1] = q.y; ow[2] = q.z; ow[3] = q.w;
         } else {
 #pragma unroll
-            for (int u = 0; u <= kFinE; ++u) o[u] = i0 + (uint32_t)u <= nx ? off[x0 + i0 + u] : 0u;
-#pragma unroll
-            for (int u = 0; u < kFinE; ++u) ow[u] = i0 + (uint32_t)u < nx ? own[x0 + i0 + u] : 0u;
+            for (int u = 0; u < kFinE; ++u) { const bool in = i0 + (uint32_t)u < nx; c[u] = in ? cnt[x0 + i0 + u] : 0u; ow[u] = in ? own[x0 + i0 + u] : 0u; }
         }
 #pragma unroll
         for (int u = 0; u < kFinE; ++u) oo[u] = ow[u] ? ownoff[x0 + i0 + u] : 0ull;
+        // slice offsets: exclusive scan of the supports over the workgroup
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane == kWave - 1) sh_wsum[w] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (int i = 0; i < kFinBlock / kWave; ++i) before += i < w ? sh_wsum[i] : 0u;
+        uint32_t o[kFinE + 1];                                      // relative to the window
+        o[0] = before + incl - mine;
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u) o[u + 1] = o[u] + c[u];
 #pragma unroll
         for (int u = 0; u < kFinE; ++u)
-            if (i0 + (uint32_t)u < nx) { sh_off[i0 + u] = o[u] - base; sh_cur[i0 + u] = o[u] - base; }
-        if (i0 < nx && i0 + kFinE >= nx) sh_off[nx] = o[nx - i0] - base;
+            if (i0 + (uint32_t)u < nx) { sh_off[i0 + u] = o[u]; sh_cur[i0 + u] = o[u]; }
+        if (threadIdx.x == kFinBlock - 1) sh_off[kBinEdges] = o[kFinE];      // the bin's total (edges beyond nx count 0)
+        // ... written out, with the peel's initial state
+        if (i0 + kFinE <= nx) {
+            *reinterpret_cast<uint4 *>(off + x0 + i0) = make_uint4(base + o[0], base + o[1], base + o[2], base + o[3]);
+            int4 sv, mv, tv;
+            int32_t *svp = &sv.x, *mvp = &mv.x, *tvp = &tv.x;
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) {
+                svp[u] = (int32_t)c[u];
+                mvp[u] = c[u] ? alive_marker(c[u]) : 0;              // round 0: gone before the first sub-round
+                tvp[u] = 2;
+                if (c[u]) lmin = min(lmin, (int32_t)c[u]); else ++zeros;
+            }
+            *reinterpret_cast<int4 *>(sup + x0 + i0) = sv;
+            *reinterpret_cast<int4 *>(stamp + x0 + i0) = mv;
+            *reinterpret_cast<int4 *>(truss + x0 + i0) = tv;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (i0 + (uint32_t)u < nx) {
+                const int64_t e = x0 + i0 + u;
+                off[e] = base + o[u];
+                sup[e] = (int32_t)c[u];
+                stamp[e] = c[u] ? alive_marker(c[u]) : 0;
+                truss[e] = 2;
+                if (c[u]) lmin = min(lmin, (int32_t)c[u]); else ++zeros;
+            }
+        }
         __syncthreads();
-        const uint32_t W = sh_off[nx];
+        const uint32_t W = sh_off[kBinEdges];
+        if (b == nb - 1 && threadIdx.x == 0) off[m] = base + W;
         const bool inwin = W <= kWinCap;                            // (workgroup-uniform)
         // ---- records
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += (uint64_t)kFinBlock * kFinU) {
@@ -980,7 +1038,7 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
             for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) t[u] = own_dense[oo[u] + kk];
 #pragma unroll
             for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) {
-                const uint32_t p = o[u + 1] - base - ow[u] + kk;
+                const uint32_t p = o[u + 1] - ow[u] + kk;
                 if (inwin) sh_win[p] = t[u]; else dense[base + p] = t[u];
             }
         }
@@ -989,6 +1047,7 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
         if (inwin) for (uint32_t j = threadIdx.x; j < W; j += kFinBlock) dense[base + j] = sh_win[j];
         __syncthreads();
     }
+    block_add_min(zeros, lmin, &init[0], (int32_t *)&init[1]);
 }
 
 // peel state from the slice lengths.  Triangle-free edges are peeled here (trussness 2); init[0]
@@ -1404,6 +1463,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     unsigned long long *d_ownoff = nullptr, *d_dcur = nullptr;
     uint32_t *d_cnt_ref = nullptr;             // world > 1: the all-reduced supports, kept to check the build against
     uint32_t *d_toff = nullptr;                // stream: first sorted record of every bin
+    uint32_t *d_bintot = nullptr;              // stream: supports summed per bin, then their exclusive scan (every bin's window of the index)
     uint32_t *d_reckey = nullptr;              // stream: the sorted records' keys
     int2 *d_recval = nullptr;                  // stream: ... and values
     int64_t n_bins = 0;
@@ -1502,10 +1562,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 d_reckey = d_skey;
                 n_bins = (m + kBinEdges - 1) >> kBinBits;
                 KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)n_bins + 2));
+                KOMB_HIP(ctx, bufs.alloc(&d_bintot, (size_t)n_bins + 2));
                 ctx->timer.start(s);
                 KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
                 k_bin_offsets<<<grid_for(n_bins + 1), kBlock, 0, s>>>(d_skey, (int64_t)n_claimed, n_bins, d_toff);
-                k_bin_count<<<grid_for(n_bins, 1, 256 * 8), kBlock, 0, s>>>(d_skey, d_toff, n_bins, d_own, m, d_cnt, d_mom + 5);
+                k_bin_count<<<grid_for(n_bins, 1, 256 * 8), kBlock, 0, s>>>(d_skey, d_toff, n_bins, d_own, m, d_cnt, d_bintot, d_mom + 5);
                 st.ms_compact = ctx->timer.stop(s);
                 st.tri_records = (int64_t)n_claimed;
             } else (void)hipGetLastError();
@@ -1632,19 +1693,35 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                       mom[5] / 3);
     }
     bufs.release(d_cnt_ref);
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_off, m + 1));
     uint32_t total = 0;
-    KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
     int2 *d_inc = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
+    int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
+    uint32_t *d_grp = nullptr;
+    bool peel_inited = false;                  // the stream layout's finish also writes the peel's initial state
     const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
     if (layout == IDX_STREAM) {
+        // every bin's window of the index from the scan of the per-bin totals (the slice offsets themselves are a workgroup scan inside k_bin_finish)
+        KOMB_TRY(prim_exclusive_sum_u32(ctx, d_bintot, d_bintot, n_bins + 1));
+        KOMB_HIP(ctx, d2h(ctx, &total, d_bintot + n_bins, sizeof(uint32_t)));
+        KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
+        KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
         ctx->timer.start(s);
-        k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, n_bins, d_own, d_off, d_owndense, d_ownoff, d_inc, m);
+        peel_ctrl_pre(s, d_grp);
+        k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, n_bins, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
+                                                                      d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff);
         st.ms_compact += ctx->timer.stop(s);
-        bufs.release(d_toff); bufs.release((void *)d_recval); bufs.release(d_reckey);
+        peel_inited = true;
+        bufs.release(d_toff); bufs.release(d_bintot); bufs.release((void *)d_recval); bufs.release(d_reckey);
         bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
-    } else if (layout == IDX_SLICES) {
+    } else {
+        KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_off, m + 1));
+        KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
+        KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
+    }
+    if (layout == IDX_SLICES) {
         ctx->timer.start(s);
         if (d_offc64) k_compact_inc<unsigned long long><<<gc, kBlock, 0, s>>>(d_offc64, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
         else k_compact_inc<uint32_t><<<gc, kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
@@ -1657,7 +1734,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
         bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64);
         bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
-    } else {
+    } else if (layout == IDX_TWO_PASS) {
         // second enumeration, same writer as the single-pass layouts but into the EXACT slices: own-role
         // entries from the front and third-role entries from the back meet precisely -- no compaction
         ctx->timer.start(s);
@@ -1671,13 +1748,15 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
 
     // ---- peel
     phase.next("truss: peel");
-    int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
-    PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
+    PeelCtrl *d_ctrl = nullptr;
     PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, scan_scalar_switch()};
     const size_t heavy_cap = (size_t)total / 32 + 64;             // see kcore.hip
-    KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
-    KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
-    KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
+    if (!peel_inited) {
+        KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
+    }
     for (int i = 0; i < 2; ++i) {
         KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&Q.heavy[i], heavy_cap));
@@ -1685,7 +1764,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));
-    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
     // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
     const FinishMode fin = finish_mode(FIN_LOCAL);
@@ -1782,8 +1860,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         return KOMB_OK;
     };
     ctx->timer.start(s);
-    peel_ctrl_pre(s, d_grp);
-    k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff);
+    if (!peel_inited) {
+        peel_ctrl_pre(s, d_grp);
+        k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff);
+    }
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
     int launches = 0, rc = KOMB_OK;
     st.truss_tail_runs = 0; st.ms_tail = 0.0;
@@ -1867,6 +1947,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_kubits, d_kurank, d_rev_sorted, d_ebase, d_truss, d_off,
                                                         ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
+    if (getenv("KOMB_POOL_DEBUG")) {
+        size_t held = 0;
+        for (const auto &b : ctx->pool.blocks) held += b.bytes;
+        fprintf(stderr, "komb pool: %zu blocks, %.2f GB held, %zu hipMalloc calls so far, %zu trims\n", ctx->pool.blocks.size(), held / 1e9, ctx->pool.n_malloc, ctx->pool.n_trim);
+    }
     ctx->t_ne = m;
     ctx->truss_done = true;
     return KOMB_OK;
