@@ -914,8 +914,20 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     g.n = n; g.nh = 0; g.ng = 0; g.nchunk = 0;
     int64_t gb = ((int64_t)n_in + kNumBlock - 1) / kNumBlock;
     k_local_number<<<(int)(gb < 1 ? 1 : (gb > 1024 ? 1024 : gb)), kNumBlock, 0, s>>>(list, n_in, n, marker, key, light_max, d_num, g, d_lctrl);
+    // one round trip for everything the host decides on: the numbering's counters and the histogram of the live keys
     LocalCtrl hl{};
-    KOMB_HIP(ctx, d2h(ctx, &hl, d_lctrl, sizeof(LocalCtrl)));
+    std::vector<uint32_t> kh(kKeyBins);
+    if (ctx->h_stage && sizeof(LocalCtrl) + kKeyBins * sizeof(uint32_t) <= kStageBytes) {
+        char *st8 = (char *)ctx->h_stage;
+        KOMB_HIP(ctx, hipMemcpyAsync(st8, d_lctrl, sizeof(LocalCtrl), hipMemcpyDeviceToHost, s));
+        KOMB_HIP(ctx, hipMemcpyAsync(st8 + sizeof(LocalCtrl), g.khist, kKeyBins * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        KOMB_HIP(ctx, hipStreamSynchronize(s));
+        memcpy(&hl, st8, sizeof(LocalCtrl));
+        memcpy(kh.data(), st8 + sizeof(LocalCtrl), kKeyBins * sizeof(uint32_t));
+    } else {
+        KOMB_HIP(ctx, d2h(ctx, &hl, d_lctrl, sizeof(LocalCtrl)));
+        KOMB_HIP(ctx, d2h(ctx, kh.data(), g.khist, kKeyBins * sizeof(uint32_t)));
+    }
     if (hl.bad || hl.n_heavy + hl.n_light != n)
         KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: %u live units numbered, the peel counted %u", hl.n_heavy + hl.n_light, n);
     // max_density (0 = no rule): a remainder with more items per unit than this is left to the peel for good -- it only gets
@@ -938,10 +950,9 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
         return KOMB_OK;
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, g.len, g.off, (int64_t)n + 1));
-    uint32_t total = 0;
-    KOMB_HIP(ctx, d2h(ctx, &total, g.off + n, sizeof(uint32_t)));
-    if ((uint64_t)total != hl.key_sum)
-        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "local finish: slice offsets end at %u, the live keys sum to %llu", total, (unsigned long long)hl.key_sum);
+    // (the offsets end at the sum of the live keys k_local_number has just reported -- the slice lengths ARE those keys --
+    // so the total needs no round trip of its own; k_local_check compares every slice's fill with its length afterwards)
+    const uint32_t total = (uint32_t)hl.key_sum;
     g.nh = hl.n_heavy;
     g.ng = hl.n_giant;
     g.nchunk = hl.n_chunk;
@@ -965,8 +976,6 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     // K = h-index of the live keys: no level of the remainder is above it, so no value needs to start above it
     int32_t K = 0x7FFFFFFF;
     {
-        std::vector<uint32_t> kh(kKeyBins);
-        KOMB_HIP(ctx, d2h(ctx, kh.data(), g.khist, kKeyBins * sizeof(uint32_t)));
         uint64_t ge = 0;
         for (int32_t k = (int32_t)kKeyBins - 1; k >= 0; --k) {
             ge += kh[(size_t)k];
