@@ -1,6 +1,8 @@
 """Randomised soak: many graphs of assorted shapes, k-core and k-truss (with support) against the CPU oracle,
 each under a random choice of the finish (local fixed point / LDS tails / none), its hand-over thresholds and item
-limit, and of the index layout (single / two pass, 32 / 64-bit slice offsets, dense or slice-resident own-role entries).
+limit, and of the index layout (record stream / bounded slices / two pass, 32 / 64-bit slice offsets, dense or block-less
+own-role entries, a dense region or a record stream that runs out), the orientation's class table and the fixed point's
+notification kernel.
     python tests/manual/soak.py [n_graphs] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -48,8 +50,15 @@ with komb_amd.KombAccel() as a:
         items = str(rng.choice(["", "0", "60", "5000", "200000"]))       # item limit of the local finish ("" = the default): small ones exercise the refusal
         if items: os.environ["KOMB_LOCAL_ITEMS"] = items
         else: os.environ.pop("KOMB_LOCAL_ITEMS", None)
-        for k, on in (("KOMB_TWO_PASS", rng.random() < 0.3), ("KOMB_OFF64", rng.random() < 0.3), ("KOMB_NO_OWN_DENSE", rng.random() < 0.3)):
+        for k, on in (("KOMB_TWO_PASS", rng.random() < 0.15), ("KOMB_OFF64", rng.random() < 0.3), ("KOMB_NO_OWN_DENSE", rng.random() < 0.3),
+                      ("KOMB_DEG_CLASSES", rng.random() < 0.5)):
             if on: os.environ[k] = "1"
+            else: os.environ.pop(k, None)
+        os.environ["KOMB_INDEX"] = str(rng.choice(["stream", "stream", "slices", "two_pass"]))
+        for k, choices in (("KOMB_OWN_DENSE_CAP", ["", "", "0", "200", "5000"]), ("KOMB_REC_CAP", ["", "", "", "100", "3000"]),
+                           ("KOMB_LOCAL_DEFER_CHUNKS", ["", "1"])):
+            v = str(rng.choice(choices))
+            if v: os.environ[k] = v
             else: os.environ.pop(k, None)
         a.from_edges(nv, uv)
         rowptr, col = a.get_csr()
@@ -62,7 +71,9 @@ with komb_amd.KombAccel() as a:
             np.save(f"gpurun_out/soak_fail_{g}.npy", uv)
             print(f"MISMATCH graph {g} kind {kind} nv {nv} env FINISH={os.environ['KOMB_FINISH']} LOCAL_LIMIT={os.environ['KOMB_LOCAL_LIMIT']} "
                   f"TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
-                  f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')} NO_OWN_DENSE={os.environ.get('KOMB_NO_OWN_DENSE')} LOCAL_ITEMS={os.environ.get('KOMB_LOCAL_ITEMS')}", flush=True)
+                  f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')} NO_OWN_DENSE={os.environ.get('KOMB_NO_OWN_DENSE')} LOCAL_ITEMS={os.environ.get('KOMB_LOCAL_ITEMS')} "
+                  f"INDEX={os.environ.get('KOMB_INDEX')} OWN_DENSE_CAP={os.environ.get('KOMB_OWN_DENSE_CAP')} REC_CAP={os.environ.get('KOMB_REC_CAP')} "
+                  f"DEG_CLASSES={os.environ.get('KOMB_DEG_CLASSES')} DEFER={os.environ.get('KOMB_LOCAL_DEFER_CHUNKS')}", flush=True)
         if g % 100 == 99:
             print(f"{g + 1} graphs, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {n_graphs} graphs, {bad} mismatches, {time.time() - t0:.0f} s")
