@@ -146,17 +146,19 @@ __global__ void k_collect_ctrl(PeelCtrl *c2, const PeelCtrl *from)
     }
 }
 
-// grp_done[kInitOff] = #units peeled by the init kernel, grp_done[kInitOff+1] = min live key
+// grp_done[kInitOff] = #units peeled by the init kernel, grp_done[kInitOff+1] = min live key, grp_done[kInitOff+2] = light units the
+// init kernel has already put into queue 0 as the first level's frontier (k-truss stream build; 0 = the peel starts with a SCAN)
 __global__ void k_ctrl_pre(uint32_t *grp_done)
 {
     for (int i = threadIdx.x; i < kInitOff; i += blockDim.x) grp_done[i] = 0u;
-    if (threadIdx.x == 0) { grp_done[kInitOff] = 0u; grp_done[kInitOff + 1] = 0x7FFFFFFFu; }
+    if (threadIdx.x == 0) { grp_done[kInitOff] = 0u; grp_done[kInitOff + 1] = 0x7FFFFFFFu; grp_done[kInitOff + 2] = 0u; grp_done[kInitOff + 3] = 0u; }
 }
 __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t units, uint32_t tail_limit)
 {
     if (threadIdx.x == 0) {
         const uint32_t peeled = grp_done[kInitOff];
         const int32_t first = (int32_t)grp_done[kInitOff + 1];
+        const uint32_t front = grp_done[kInitOff + 2];
         PeelCtrl c{};
         c.mode = MODE_SCAN; c.round = 1; c.seq = 1;
         c.remaining = units - peeled;
@@ -165,6 +167,12 @@ __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t u
         c.n_levels = peeled ? 1 : 0;                 // level 0 was populated by item-less units
         c.next_min = 0x7FFFFFFF;
         c.tail_limit = tail_limit;
+        if (front) {
+            // the first level's frontier is in light queue 0 already (stamped with round 1): what the first SCAN would have left
+            c.mode = MODE_PROCESS; c.cur_light = front; c.cur_heavy = 0; c.cur_sel = 0;
+            c.remaining -= front;
+            c.n_levels += 1; c.max_level = first;
+        }
         *ctrl = c;
     }
 }
@@ -217,7 +225,7 @@ int core_run(komb_ctx *ctx)
     }
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
+    KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
     // how the peel ends (common.h): local fixed point (default), LDS tail, or the general engine alone
     const FinishMode fin = finish_mode(FIN_LOCAL);
     uint32_t tail_limit = 0;

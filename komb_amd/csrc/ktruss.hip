@@ -879,11 +879,14 @@ __global__ __launch_bounds__(kBlock) void k_count_mismatch(const uint32_t *__res
 // (their scan gives every bin its window of the index) and the 64-bit grand total on the side.
 __global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict__ key, const uint32_t *__restrict__ boff, int64_t nb,
                                                       const uint32_t *__restrict__ own, int64_t m, uint32_t *__restrict__ sum,
-                                                      uint32_t *__restrict__ bin_total, unsigned long long *__restrict__ total)
+                                                      uint32_t *__restrict__ bin_total, unsigned long long *__restrict__ total,
+                                                      int32_t *__restrict__ min_pos)
 {
+    // min_pos: the smallest positive support = the peel's first level (k_bin_finish queues its frontier)
     __shared__ uint32_t sh_cnt[kBinEdges];
     __shared__ uint32_t sh_part[kBlock / kWave];
     unsigned long long t = 0;
+    int32_t lmin = 0x7FFFFFFF;
     for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const int64_t x0 = b << kBinBits;
         const uint32_t nx = (uint32_t)min((int64_t)kBinEdges, m - x0);
@@ -897,6 +900,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict
             const uint32_t c = own[x0 + i] + sh_cnt[i];
             sum[x0 + i] = c;
             tb += c;
+            if (c) lmin = min(lmin, (int32_t)c);
         }
         tb = wave_sum(tb);
         if (lane_id() == 0) sh_part[threadIdx.x >> 6] = tb;
@@ -911,6 +915,8 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { sum[m] = 0u; bin_total[nb] = 0u; }
     if (threadIdx.x == 0 && t) atomicAdd(total, t);
+    lmin = wave_min(lmin);
+    if (lane_id() == 0 && lmin != 0x7FFFFFFF) atomicMin(min_pos, lmin);
 }
 
 // Dense index of a bin's edges.  An edge's slice is [its records' values | its own-role entries]; the slices of a
@@ -935,15 +941,22 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
                                                          const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
                                                          int2 *__restrict__ dense, int64_t m,
                                                          uint32_t *__restrict__ off, int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
-                                                         int32_t *__restrict__ truss, uint32_t *__restrict__ init)
+                                                         int32_t *__restrict__ truss, uint32_t *__restrict__ init, int32_t *__restrict__ light0)
 {
+    // init[0] += triangle-free edges; init[1] = the smallest positive support (from k_bin_count) = the peel's first level L1.
+    // The edges with support L1 ARE that level's first frontier (nothing has been decremented yet): they are stamped with
+    // round 1 / trussness L1 + 2 and appended to light queue 0 here (one reservation per bin on init[2]), so the peel starts
+    // with a PROCESS step instead of a dense SCAN of every edge (0.55 ms at C3).  Only when they are light units (L1 <= kLight).
     __shared__ uint32_t sh_off[kBinEdges + 4];     // slice offsets relative to the window
     __shared__ uint32_t sh_cur[kBinEdges];
     __shared__ uint32_t sh_wsum[kFinBlock / kWave];
     __shared__ int2 sh_win[kWinCap];
+    __shared__ uint32_t sh_hsum[kFinBlock / kWave];
+    __shared__ uint32_t sh_qbase;
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     uint32_t zeros = 0;
-    int32_t lmin = 0x7FFFFFFF;
+    const int32_t L1 = (int32_t)init[1];
+    const bool queue_first = light0 != nullptr && L1 <= kLight;
     for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const int64_t x0 = b << kBinBits;
         const uint32_t nx = (uint32_t)min((int64_t)kBinEdges, m - x0);
@@ -967,11 +980,16 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
         // slice offsets: exclusive scan of the supports over the workgroup
         const uint32_t mine = c[0] + c[1] + c[2] + c[3];
         const uint32_t incl = wave_incl_scan(mine);
-        if (lane == kWave - 1) sh_wsum[w] = incl;
-        __syncthreads();
-        uint32_t before = 0;
+        uint32_t hits = 0;
 #pragma unroll
-        for (int i = 0; i < kFinBlock / kWave; ++i) before += i < w ? sh_wsum[i] : 0u;
+        for (int u = 0; u < kFinE; ++u) hits += (queue_first && (int32_t)c[u] == L1) ? 1u : 0u;
+        const uint32_t hincl = wave_incl_scan(hits);
+        if (lane == kWave - 1) { sh_wsum[w] = incl; sh_hsum[w] = hincl; }
+        __syncthreads();
+        uint32_t before = 0, hbefore = 0, hall = 0;
+#pragma unroll
+        for (int i = 0; i < kFinBlock / kWave; ++i) { before += i < w ? sh_wsum[i] : 0u; hbefore += i < w ? sh_hsum[i] : 0u; hall += sh_hsum[i]; }
+        if (threadIdx.x == 0 && hall) sh_qbase = atomicAdd(&init[2], hall);
         uint32_t o[kFinE + 1];                                      // relative to the window
         o[0] = before + incl - mine;
 #pragma unroll
@@ -987,10 +1005,11 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
             int32_t *svp = &sv.x, *mvp = &mv.x, *tvp = &tv.x;
 #pragma unroll
             for (int u = 0; u < kFinE; ++u) {
+                const bool first = queue_first && (int32_t)c[u] == L1;
                 svp[u] = (int32_t)c[u];
-                mvp[u] = c[u] ? alive_marker(c[u]) : 0;              // round 0: gone before the first sub-round
-                tvp[u] = 2;
-                if (c[u]) lmin = min(lmin, (int32_t)c[u]); else ++zeros;
+                mvp[u] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);   // round 1: the first frontier; round 0: gone before the first sub-round
+                tvp[u] = first ? L1 + 2 : 2;
+                if (!c[u]) ++zeros;
             }
             *reinterpret_cast<int4 *>(sup + x0 + i0) = sv;
             *reinterpret_cast<int4 *>(stamp + x0 + i0) = mv;
@@ -999,14 +1018,20 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
 #pragma unroll
             for (int u = 0; u < kFinE; ++u) if (i0 + (uint32_t)u < nx) {
                 const int64_t e = x0 + i0 + u;
+                const bool first = queue_first && (int32_t)c[u] == L1;
                 off[e] = base + o[u];
                 sup[e] = (int32_t)c[u];
-                stamp[e] = c[u] ? alive_marker(c[u]) : 0;
-                truss[e] = 2;
-                if (c[u]) lmin = min(lmin, (int32_t)c[u]); else ++zeros;
+                stamp[e] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);
+                truss[e] = first ? L1 + 2 : 2;
+                if (!c[u]) ++zeros;
             }
         }
         __syncthreads();
+        if (hall) {                                                 // the bin's part of the first frontier, in edge order
+            uint32_t q = sh_qbase + hbefore + hincl - hits;
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (queue_first && (int32_t)c[u] == L1 && i0 + (uint32_t)u < nx) light0[q++] = (int32_t)(x0 + i0 + u);
+        }
         const uint32_t W = sh_off[kBinEdges];
         if (b == nb - 1 && threadIdx.x == 0) off[m] = base + W;
         const bool inwin = W <= kWinCap;                            // (workgroup-uniform)
@@ -1047,7 +1072,7 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
         if (inwin) for (uint32_t j = threadIdx.x; j < W; j += kFinBlock) dense[base + j] = sh_win[j];
         __syncthreads();
     }
-    block_add_min(zeros, lmin, &init[0], (int32_t *)&init[1]);
+    block_add_min(zeros, 0x7FFFFFFF, &init[0], (int32_t *)&init[1]);
 }
 
 // peel state from the slice lengths.  Triangle-free edges are peeled here (trussness 2); init[0]
@@ -1448,6 +1473,16 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // A sharded run (world > 1) first counts the supports of its own source-vertex range and sums them over the ranks
     // (fn: the RCCL all-reduce), then builds the index whole with the layout above; the summed supports must equal the
     // supports the build finds.
+    // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
+    const FinishMode fin = finish_mode(FIN_LOCAL);
+    uint32_t tail_limit = 0;
+    if (fin == FIN_LDS) {
+        tail_limit = kTailEdges;
+        if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
+        if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
+    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 32);
+    // (a graph small enough for the finish to take the whole peel is handed over before any step: no frontier may be queued)
+    const bool whole_peel_finish = tail_limit && (uint64_t)m <= tail_limit;
     enum { IDX_STREAM = 0, IDX_SLICES = 1, IDX_TWO_PASS = 2 };
     int layout = IDX_STREAM;
     if (const char *ix = getenv("KOMB_INDEX")) {
@@ -1463,6 +1498,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     unsigned long long *d_ownoff = nullptr, *d_dcur = nullptr;
     uint32_t *d_cnt_ref = nullptr;             // world > 1: the all-reduced supports, kept to check the build against
     uint32_t *d_toff = nullptr;                // stream: first sorted record of every bin
+    uint32_t *d_grp = nullptr;                 // the peel's ticket / init words (stream: allocated before the build's last kernels, which fill them)
+    int32_t *d_light0 = nullptr;               // stream: light queue 0 of the peel, which k_bin_finish fills with the first frontier
     uint32_t *d_bintot = nullptr;              // stream: supports summed per bin, then their exclusive scan (every bin's window of the index)
     uint32_t *d_reckey = nullptr;              // stream: the sorted records' keys
     int2 *d_recval = nullptr;                  // stream: ... and values
@@ -1563,10 +1600,13 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 n_bins = (m + kBinEdges - 1) >> kBinBits;
                 KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)n_bins + 2));
                 KOMB_HIP(ctx, bufs.alloc(&d_bintot, (size_t)n_bins + 2));
+                KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
+                if (!whole_peel_finish && !getenv("KOMB_NO_FIRST_QUEUE")) KOMB_HIP(ctx, bufs.alloc(&d_light0, (size_t)m));
                 ctx->timer.start(s);
+                peel_ctrl_pre(s, d_grp);
                 KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
                 k_bin_offsets<<<grid_for(n_bins + 1), kBlock, 0, s>>>(d_skey, (int64_t)n_claimed, n_bins, d_toff);
-                k_bin_count<<<grid_for(n_bins, 1, 256 * 8), kBlock, 0, s>>>(d_skey, d_toff, n_bins, d_own, m, d_cnt, d_bintot, d_mom + 5);
+                k_bin_count<<<grid_for(n_bins, 1, 256 * 8), kBlock, 0, s>>>(d_skey, d_toff, n_bins, d_own, m, d_cnt, d_bintot, d_mom + 5, (int32_t *)(d_grp + kInitOff + 1));
                 st.ms_compact = ctx->timer.stop(s);
                 st.tri_records = (int64_t)n_claimed;
             } else (void)hipGetLastError();
@@ -1574,6 +1614,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         if (!ok) {
             // no memory for the stream, or it ran out: exact two-pass build
             bufs.release(d_key); bufs.release(d_val); bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
+            bufs.release(d_grp); bufs.release(d_light0); d_grp = nullptr; d_light0 = nullptr;
             d_owndense = nullptr; d_ownoff = nullptr; d_dcur = nullptr;
             KOMB_HIP(ctx, zero_counts());
             KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
@@ -1696,7 +1737,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     uint32_t total = 0;
     int2 *d_inc = nullptr;
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
-    uint32_t *d_grp = nullptr;
     bool peel_inited = false;                  // the stream layout's finish also writes the peel's initial state
     const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
     if (layout == IDX_STREAM) {
@@ -1707,11 +1747,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
-        KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
         ctx->timer.start(s);
-        peel_ctrl_pre(s, d_grp);
         k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, n_bins, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
-                                                                      d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff);
+                                                                      d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff, d_light0);
         st.ms_compact += ctx->timer.stop(s);
         peel_inited = true;
         bufs.release(d_toff); bufs.release(d_bintot); bufs.release((void *)d_recval); bufs.release(d_reckey);
@@ -1755,24 +1793,17 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
-        KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 2));
+        KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
     }
     for (int i = 0; i < 2; ++i) {
-        KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)m));
+        if (i == 0 && d_light0) Q.light[0] = d_light0;
+        else KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&Q.heavy[i], heavy_cap));
         KOMB_HIP(ctx, bufs.alloc(&Q.live[i], (size_t)m / 2 + 64));
     }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));
     TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
-    // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
-    const FinishMode fin = finish_mode(FIN_LOCAL);
-    uint32_t tail_limit = 0;
-    if (fin == FIN_LDS) {
-        tail_limit = kTailEdges;
-        if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
-        if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
-    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 32);
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
@@ -1868,7 +1899,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     int launches = 0, rc = KOMB_OK;
     st.truss_tail_runs = 0; st.ms_tail = 0.0;
     st.truss_local_units = 0; st.truss_local_sweeps = 0; st.truss_local_items = 0; st.ms_truss_local = 0.0;
-    if (tail_limit && (uint64_t)m <= tail_limit) {
+    if (whole_peel_finish) {
         // small graph: the finish takes the whole peel (unless it is refused, or nothing is left to peel)
         rc = d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) == hipSuccess ? KOMB_OK : KOMB_ERR_DEVICE;
         if (rc == KOMB_OK && !ctx->h_ctrl[0].done) rc = (fin == FIN_LOCAL) ? run_local() : run_tail(nullptr, (uint32_t)m);
