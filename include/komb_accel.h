@@ -157,6 +157,18 @@ int komb_corea_scores(komb_ctx *ctx, const int32_t *degree, const int32_t *coren
 int komb_corea_ranks(komb_ctx *ctx, const int32_t *degree, const int32_t *coreness,
                      int64_t nv, double *rank_degree, double *rank_key);
 
+/* Replaces CombineCoreA::runMerge over its two HashIndexedMinHeap instances (src/CombineCoreA.h:45-219,
+ * src/HashIndexedMinHeap.h:10-238; dead code in the reference -- nothing calls it): the greedy densest-block
+ * peel over a row copy and a column copy of the resident graph.  suspiciousness: host array [nv] (what
+ * getAnomalyScore returns) or NULL for plain degrees.  order[2*nv] / side[2*nv] are filled from the back, as the
+ * reference fills `order` / `modes`; the first *n_block entries are the densest block (rows: side 0, columns:
+ * side 1), *max_density its density.  Ties between equal priorities are resolved exactly as the reference's heap
+ * resolves them (the same sift operations in the same order), which makes the peel sequential: the device runs
+ * it on one lane (heaps in LDS up to 4096 nodes).  Two defects of the reference are not reproduced: removed[][]
+ * read uninitialised (:104-108) and `cols` sized by the number of rows (:191). */
+int komb_densest_block(komb_ctx *ctx, const double *suspiciousness, int32_t *order, int32_t *side,
+                       int64_t *n_block, double *max_density);
+
 /* ---- instrumentation --------------------------------------------------- */
 int komb_get_stats(komb_ctx *ctx, komb_stats *out);
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "komb_trussness": (_i32, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp, _vp]),
     "komb_corea_scores": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "komb_corea_ranks": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "komb_densest_block": (_i32, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
     "komb_get_stats": (_i32, [_vp, ctypes.POINTER(KombStats)]),
     "komb_gen_hug_edges": (_i64, [_i64, _i64, ctypes.c_double, ctypes.c_uint64, _vp]),
 }

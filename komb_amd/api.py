@@ -144,6 +144,17 @@ class KombAccel:
         self._check(self._lib.komb_corea_ranks(self._ctx, ptr(degree), ptr(coreness), len(degree), ptr(rd), ptr(rk)))
         return rd, rk
 
+    def densest_block(self, suspiciousness=None):
+        """komb_densest_block: (order int32[2*nv], side int32[2*nv], n_block, max_density) of the resident graph."""
+        n = int(self.nv)
+        order = np.zeros(max(2 * n, 1), dtype=np.int32)
+        side = np.zeros(max(2 * n, 1), dtype=np.int32)
+        nb = ctypes.c_int64(0)
+        dens = ctypes.c_double(0.0)
+        susp = None if suspiciousness is None else as_c(suspiciousness, np.float64)
+        self._check(self._lib.komb_densest_block(self._ctx, ptr(susp), ptr(order), ptr(side), ctypes.byref(nb), ctypes.byref(dens)))
+        return order[: 2 * n], side[: 2 * n], int(nb.value), float(dens.value)
+
     def stats(self):
         st = KombStats()
         self._check(self._lib.komb_get_stats(self._ctx, ctypes.byref(st)))

@@ -206,6 +206,12 @@ int komb_corea_scores(komb_ctx *ctx, const int32_t *degree, const int32_t *coren
     return KOMB_OK;
 }
 
+int komb_densest_block(komb_ctx *ctx, const double *suspiciousness, int32_t *order, int32_t *side, int64_t *n_block, double *max_density)
+{
+    KOMB_TRY(require_device(ctx));
+    return merge_run(ctx, suspiciousness, order, side, n_block, max_density);
+}
+
 int komb_get_stats(komb_ctx *ctx, komb_stats *out)
 {
     if (!ctx || !out) return KOMB_ERR_ARG;

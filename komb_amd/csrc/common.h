@@ -338,6 +338,7 @@ int prim_sort_pairs_u32_u32(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, u
 // ---- stages (each in its own translation unit)
 int core_run(komb_ctx *ctx);
 int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, komb_allreduce_fn fn, void *user);
+int merge_run(komb_ctx *ctx, const double *susp_host, int32_t *order, int32_t *side, int64_t *n_block, double *max_density);
 int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t n, double *rank_deg, double *rank_key);
 int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv);
 int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);

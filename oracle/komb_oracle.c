@@ -519,3 +519,112 @@ void orc_corea_scores(const int32_t *degree, const int32_t *coreness, int64_t n,
     for (int64_t i = 0; i < n; ++i) score[i] = fabs(log(rd[i]) - log(rc[i]));
     free(rd); free(rc);
 }
+
+/* ------------------------------------------- a12 + a13 HashIndexedMinHeap, runMerge
+ * Reference: src/HashIndexedMinHeap.h:10-238 (array-backed binary min-heap over int ids with a position index:
+ * insert = append + refreshPriority; poll = move the last id to the root + sift down; refreshPriority = sift down,
+ * and only if nothing moved, sift up while the parent's value is GREATER) and its only user,
+ * CombineCoreA::runMerge, src/CombineCoreA.h:45-219 (dead code in the reference: no caller): a greedy
+ * densest-block peel over a "row" copy and a "column" copy of the graph.  Every node starts on both sides with
+ * priority = suspiciousness + degree; each step polls the smaller of the two heap minima (the row side only when
+ * strictly smaller, or the column side is empty), subtracts its priority from the running sum, records
+ * density = sum / nodes left, and lowers by one the priority of the node's neighbours on the OTHER side that are
+ * still there.  Output: removal order and sides (filled from the back, as :137-138), the number of nodes of the
+ * densest block and its density (:140-145).  Which of several equal priorities is polled first is decided by
+ * the heap's array layout, so the heap is restated operation for operation; tests/ pin this against the
+ * reference's own class compiled in place (oracle/_ref/merge_ref).  removed[][] is zero-initialised (the
+ * reference reads it uninitialised, :104-108), and the reference's `cols` vector sized by the number of rows
+ * (:191) is not modelled: rows / cols of the block are order[i] for i < n_block with side[i] == 0 / 1. */
+struct mheap { int32_t *arr; int32_t *pos; double *val; int32_t size; };
+static int mh_down(struct mheap *h, int32_t p)                /* minHeapfy, :171-217 (iterative; same moves) */
+{
+    int moved = 0;
+    for (;;) {
+        const int32_t l = 2 * (p + 1) - 1, r = 2 * (p + 1);
+        const int32_t cur = h->arr[p];
+        int32_t sp = p, sk = cur;
+        if (l < h->size && h->val[h->arr[l]] < h->val[cur]) { sp = l; sk = h->arr[l]; }
+        if (r < h->size && h->val[h->arr[r]] < h->val[sk]) { sp = r; sk = h->arr[r]; }
+        if (sp == p) return moved;
+        h->arr[p] = sk; h->pos[sk] = p;
+        h->arr[sp] = cur; h->pos[cur] = sp;
+        p = sp; moved = 1;
+    }
+}
+static void mh_refresh(struct mheap *h, int32_t key, double v)   /* refreshPriority, :138-167 */
+{
+    h->val[key] = v;
+    int32_t p = h->pos[key];
+    if (mh_down(h, p) || p <= 0) return;
+    int32_t pp = (p + 1) / 2 - 1;
+    while (p > 0 && h->val[h->arr[pp]] > h->val[key]) {
+        const int32_t pe = h->arr[pp];
+        h->arr[pp] = key; h->pos[key] = pp;
+        h->arr[p] = pe; h->pos[pe] = p;
+        p = pp; pp = (p + 1) / 2 - 1;
+    }
+}
+static void mh_insert(struct mheap *h, int32_t key, double v)    /* insert, :83-98 */
+{
+    const int32_t p = h->size++;
+    h->arr[p] = key; h->pos[key] = p; h->val[key] = v;
+    mh_refresh(h, key, v);
+}
+static int32_t mh_poll(struct mheap *h, double *v)               /* poll, :55-81 (size > 0) */
+{
+    const int32_t top = h->arr[0];
+    *v = h->val[top];
+    h->pos[top] = -1;
+    if (h->size != 1) {
+        const int32_t last = h->arr[h->size - 1];
+        h->arr[0] = last; h->pos[last] = 0;
+        h->size--;
+        mh_down(h, 0);
+    } else h->size--;
+    h->arr[h->size] = 0;
+    return top;
+}
+int32_t orc_run_merge(int64_t nv, const int64_t *rowptr, const int32_t *col, const double *susp,
+                      int32_t *order, int32_t *side, double *max_density)
+{
+    const int32_t n = (int32_t)nv;
+    struct mheap h[2];
+    for (int s = 0; s < 2; ++s) {
+        h[s].arr = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+        h[s].pos = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+        h[s].val = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+        h[s].size = 0;
+        for (int32_t v = 0; v < n; ++v) h[s].pos[v] = -1;
+    }
+    double *p0 = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)), *p1 = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    double sum = 0;
+    if (susp) for (int32_t v = 0; v < n; ++v) { p0[v] = susp[v]; p1[v] = susp[v]; sum += 2 * susp[v]; }   /* :58-67 */
+    long slots = 0;
+    for (int32_t v = 0; v < n; ++v)                                                                       /* :71-85 */
+        for (int64_t j = rowptr[v]; j < rowptr[v + 1]; ++j) { p0[v] += 1; p1[col[j]] += 1; ++slots; }
+    sum += (double)slots;                                                                                   /* :87 */
+    for (int32_t v = 0; v < n; ++v) mh_insert(&h[0], v, p0[v]);                                            /* :89-93 */
+    for (int32_t v = 0; v < n; ++v) mh_insert(&h[1], v, p1[v]);                                            /* :95-99 */
+    uint8_t *gone = (uint8_t *)calloc((size_t)2 * (size_t)(n > 0 ? n : 1), 1);
+    double best = 0;
+    int32_t best_left = 0;
+    for (int32_t left = 2 * n; left >= 1;) {                                                                /* :114-174 */
+        const int s = (h[0].size > 0 && (h[1].size == 0 || h[0].val[h[0].arr[0]] < h[1].val[h[1].arr[0]])) ? 0 : 1;
+        double pv;
+        const int32_t node = mh_poll(&h[s], &pv);
+        sum -= pv;
+        --left;
+        order[left] = node; side[left] = s;
+        if (left >= 1) { const double d = sum / left; if (d > best) { best = d; best_left = left; } }
+        gone[(size_t)s * (size_t)(n > 0 ? n : 1) + node] = 1;
+        struct mheap *o = &h[s ^ 1];
+        for (int64_t j = rowptr[node]; j < rowptr[node + 1]; ++j) {
+            const int32_t w = col[j];
+            if (!gone[(size_t)(s ^ 1) * (size_t)(n > 0 ? n : 1) + w]) mh_refresh(o, w, o->val[w] - 1);
+        }
+    }
+    for (int s = 0; s < 2; ++s) { free(h[s].arr); free(h[s].pos); free(h[s].val); }
+    free(p0); free(p1); free(gone);
+    if (max_density) *max_density = best;
+    return best_left;
+}

@@ -10,6 +10,9 @@
  *     own std-only header src/CoreA.h is compiled in place by oracle/Makefile
  *     into oracle/_ref/corea_ref and orc_corea_* is checked against it (and
  *     against the SURVEY App. D known-answer test) in tests/.
+ *   - heap + runMerge (rows a12, a13): PINNED since round 3.  src/HashIndexedMinHeap.h is std-only and is
+ *     compiled in place into oracle/_ref/merge_ref under a restatement of runMerge's loop (the loop itself needs
+ *     <igraph.h>); orc_run_merge is checked against it on random graphs and through tests/golden/.
  *   - igraph half (rows a1-a3, a5-a6): PARITY UNPINNED by the reference.  The
  *     arithmetic lives in igraph >= 0.10 (komb.yml:7, not vendored, absent
  *     from the image) and the reference holds no tests or golden vectors for
@@ -87,8 +90,14 @@ void orc_fractional_rank_fast(const int64_t *keys, int64_t n, double *rank_out);
 void orc_corea_scores(const int32_t *degree, const int32_t *coreness, int64_t n,
                       int faithful, double *score);
 
-/* a12  HashIndexedMinHeap -- src/HashIndexedMinHeap.h:10-238 is exercised only
- * by the dead CombineCoreA::runMerge; no oracle entry point. */
+/* a12 + a13  HashIndexedMinHeap (src/HashIndexedMinHeap.h:10-238) and its only user, the dead
+ * CombineCoreA::runMerge (src/CombineCoreA.h:45-219): greedy densest-block peel over a row copy and a column
+ * copy of the graph.  susp: per-node suspiciousness or NULL (then priorities are plain degrees).  order[2*nv] /
+ * side[2*nv] are filled from the back as the reference fills `order` / `modes`; the first n_block (the return
+ * value) entries are the densest block: its rows are the order[i] with side[i] == 0, its columns those with
+ * side[i] == 1.  PINNED against the reference's own heap class compiled in place (oracle/_ref/merge_ref). */
+int32_t orc_run_merge(int64_t nv, const int64_t *rowptr, const int32_t *col, const double *susp,
+                      int32_t *order, int32_t *side, double *max_density);
 
 /* a6 with every host core (OpenMP builds only: oracle/Makefile target `native`): a level-synchronous parallel peel;
  * the same values as orc_trussness.  nthreads <= 0: OpenMP's default. */

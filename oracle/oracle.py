@@ -53,6 +53,8 @@ def lib():
         L.orc_fractional_rank_fast.argtypes = [_i64p, _i64, _f64p]
         L.orc_corea_scores.restype = None
         L.orc_corea_scores.argtypes = [_i32p, _i32p, _i64, ctypes.c_int, _f64p]
+        L.orc_run_merge.restype = ctypes.c_int32
+        L.orc_run_merge.argtypes = [_i64, _i64p, _i32p, ctypes.c_void_p, _i32p, _i32p, ctypes.POINTER(ctypes.c_double)]
         _LIB = L
     return _LIB
 
@@ -206,3 +208,44 @@ def ref_corea_scores(deg, core):
     text = "%d\n" % len(deg) + "".join("%d %d\n" % (int(d), int(c)) for d, c in zip(deg, core))
     out = subprocess.run([exe, "arrays"], input=text, capture_output=True, text=True, check=True).stdout
     return np.array([float(x) for x in out.split()], dtype=np.float64)
+
+
+def run_merge(rowptr, col, susp=None):
+    """a12 + a13: the greedy densest-block peel of CombineCoreA::runMerge over its indexed min-heaps.
+    Returns (order int32[2*nv], side int32[2*nv], n_block, max_density)."""
+    nv = len(rowptr) - 1
+    order = np.zeros(max(2 * nv, 1), dtype=np.int32)
+    side = np.zeros(max(2 * nv, 1), dtype=np.int32)
+    dens = ctypes.c_double(0.0)
+    sp = None
+    if susp is not None:
+        susp = np.ascontiguousarray(susp, dtype=np.float64)
+        sp = susp.ctypes.data_as(ctypes.c_void_p)
+    nb = lib().orc_run_merge(nv, rowptr, _colbuf(col), sp, order, side, ctypes.byref(dens))
+    return order[: 2 * nv], side[: 2 * nv], int(nb), float(dens.value)
+
+
+def ref_merge_path():
+    p = os.path.join(_HERE, "_ref", "merge_ref")
+    return p if os.path.exists(p) else None
+
+
+def ref_run_merge(rowptr, col, susp=None):
+    """The same from the REFERENCE's own HashIndexedMinHeap.h (oracle/_ref/merge_ref: its class under a restatement of the loop)."""
+    import tempfile
+    exe = ref_merge_path()
+    if exe is None:
+        raise FileNotFoundError("oracle/_ref/merge_ref not built")
+    nv = len(rowptr) - 1
+    with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+        np.array([nv, len(col)], dtype=np.int64).tofile(f)
+        np.asarray(rowptr, dtype=np.int64).tofile(f)
+        np.asarray(col, dtype=np.int32).tofile(f)
+        np.array([0 if susp is None else 1], dtype=np.int64).tofile(f)
+        if susp is not None:
+            np.asarray(susp, dtype=np.float64).tofile(f)
+        f.flush()
+        out = subprocess.run([exe, f.name], capture_output=True, text=True, check=True).stdout.split()
+    nb, dens = int(out[0]), float(out[1])
+    rest = np.array(out[2:], dtype=np.int64).reshape(-1, 2)
+    return rest[:, 0].astype(np.int32), rest[:, 1].astype(np.int32), nb, dens

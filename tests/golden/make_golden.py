@@ -1,7 +1,7 @@
 """Generates tests/golden/graphs.json -- committed golden vectors for the path.
 
 Run in the build container (needs networkx and, for the `ref_corea` column,
-oracle/_ref/corea_ref built from the reference's own src/CoreA.h):
+oracle/_ref/corea_ref and oracle/_ref/merge_ref built from the reference's own src/CoreA.h and src/HashIndexedMinHeap.h):
 
     python tests/golden/make_golden.py
 
@@ -124,6 +124,18 @@ def main():
         if nv:
             ref = O.ref_corea_scores(degree, core)      # the REFERENCE's CoreA.h
             rec["ref_corea_hex"] = [float(x).hex() for x in ref]
+        # a12 + a13: the REFERENCE's HashIndexedMinHeap.h under the restated runMerge loop (oracle/_ref/merge_ref),
+        # unweighted and weighted with the reference's own CoreA scores
+        import numpy as np
+        rp, cl = np.asarray(rowptr, np.int64), np.asarray(col, np.int32)
+        for tag, susp in (("", None), ("w_", ref if nv else None)):
+            if tag and susp is None:
+                continue
+            order, side, nb, dens = O.ref_run_merge(rp, cl, susp)
+            rec["merge_" + tag + "order"] = order.tolist()
+            rec["merge_" + tag + "side"] = side.tolist()
+            rec["merge_" + tag + "n_block"] = nb
+            rec["merge_" + tag + "density_hex"] = float(dens).hex()
         out.append(rec)
         print(f"{name}: nv={nv} ne={len(edges)} T={rec['triangles']} kmax={kmax} tmax={max(truss) if truss else 0}")
     with open(os.path.join(HERE, "graphs.json"), "w") as f:

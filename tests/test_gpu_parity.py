@@ -677,3 +677,33 @@ def test_local_finish_agrees_with_general_engine(K, O, monkeypatch):
     monkeypatch.delenv("KOMB_LOCAL_ITEMS", raising=False)
     monkeypatch.delenv("KOMB_LOCAL_DENSITY", raising=False)
     monkeypatch.delenv("KOMB_FINISH", raising=False)
+
+
+def test_densest_block_vs_reference_heap(K, O, golden):
+    """a12 + a13 (dead code in the reference): komb_densest_block -- CombineCoreA::runMerge over the indexed min-heaps, on
+    the device -- against the committed answers of the REFERENCE's own HashIndexedMinHeap.h (tests/golden, `merge_*`) and
+    against the oracle on larger graphs: removal order, sides, block size and density bit for bit.  Heaps in LDS (<= 4096
+    nodes) and in global memory (above); unweighted and weighted with CoreA scores."""
+    n = 0
+    for g in golden:
+        with K.KombAccel() as a:
+            a.from_csr(_i64(g["rowptr"]), np.asarray(g["col"], dtype=np.int32))
+            for tag, susp in (("", None), ("w_", np.array([float.fromhex(h) for h in g["ref_corea_hex"]]) if g["nv"] else None)):
+                if tag and susp is None:
+                    continue
+                order, side, nb, dens = a.densest_block(susp)
+                assert order.tolist() == g["merge_" + tag + "order"] and side.tolist() == g["merge_" + tag + "side"], g["name"]
+                assert nb == g["merge_" + tag + "n_block"] and dens == float.fromhex(g["merge_" + tag + "density_hex"]), g["name"]
+                n += 1
+    assert n >= 30
+    rng = np.random.default_rng(41)
+    cases = [(4096, rng.integers(0, 4096, (30000, 2)).astype(np.int64)), (4097, rng.integers(0, 4097, (20000, 2)).astype(np.int64)),
+             (9000, rng.integers(0, 9000, (40000, 2)).astype(np.int64)), (20000, K.gen_hug_edges(20000, 50000, 2.6, 7))]
+    for nv, uv in cases:
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            rowptr, col = a.get_csr()
+            deg, core = a.run_core()
+            for susp in (None, a.get_anomaly_score(deg, core)):
+                got, want = a.densest_block(susp), O.run_merge(rowptr, col, susp)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2:] == want[2:], nv

@@ -176,3 +176,44 @@ def test_all_cores_variant_matches(built):
         want = O.trussness(rowptr, col)
         for threads in (1, 3, 8):
             assert np.array_equal(O.trussness_native(rowptr, col, threads), want)
+
+
+def _merge_cases():
+    rng = np.random.default_rng(77)
+    cases = [(1, np.zeros((0, 2), np.int64)), (5, np.zeros((0, 2), np.int64)), (2, np.array([[0, 1]], np.int64)),
+             (6, np.stack(np.triu_indices(6, 1), axis=1).astype(np.int64))]
+    for _ in range(25):
+        nv = int(rng.integers(2, 250))
+        cases.append((nv, rng.integers(0, nv, (int(rng.integers(0, 8 * nv)), 2)).astype(np.int64)))
+    return cases
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "merge_ref")),
+                    reason="oracle/_ref/merge_ref not built (reference absent)")
+def test_run_merge_matches_reference_heap(O):
+    """a12 + a13: the oracle's restated indexed min-heap + runMerge loop against the REFERENCE's own HashIndexedMinHeap.h
+    compiled in place (oracle/_ref/merge_ref), unweighted and weighted with CoreA scores: removal order, sides, block size
+    and density bit for bit -- ties between equal priorities are decided by the heap's layout on both sides."""
+    for nv, uv in _merge_cases():
+        rowptr, col = O.simplify(nv, uv)
+        deg = O.degree(rowptr)
+        for susp in (None, O.corea_scores(deg, O.coreness(rowptr, col))):
+            a, b = O.run_merge(rowptr, col, susp), O.ref_run_merge(rowptr, col, susp)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3], nv
+
+
+def test_golden_run_merge(O, golden):
+    """The committed fixtures hold the reference heap's answers (tests/golden/make_golden.py, `merge_*` columns)."""
+    n = 0
+    for g in golden:
+        if "merge_order" not in g:
+            continue
+        rowptr, col = np.asarray(g["rowptr"], np.int64), np.asarray(g["col"], np.int32)
+        for tag, susp in (("", None), ("w_", np.array([float.fromhex(h) for h in g["ref_corea_hex"]]) if g["nv"] else None)):
+            if tag and susp is None:
+                continue
+            order, side, nb, dens = O.run_merge(rowptr, col, susp)
+            assert order.tolist() == g["merge_" + tag + "order"] and side.tolist() == g["merge_" + tag + "side"], g["name"]
+            assert nb == g["merge_" + tag + "n_block"] and dens == float.fromhex(g["merge_" + tag + "density_hex"]), g["name"]
+            n += 1
+    assert n >= 10
