@@ -846,6 +846,18 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
     return KOMB_OK;
 }
 
+// one launch instead of five memsets at the hand-over (each is ~15 us of host time while the GPU waits)
+static __global__ __launch_bounds__(kBlock) void k_local_zero(uint32_t *a, uint32_t na, uint32_t *b, uint32_t nb, uint32_t *c, uint32_t nc,
+                                                       uint32_t *d, uint32_t nd, uint32_t *e, uint32_t ne)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x, step = gridDim.x * kBlock;
+    for (uint32_t i = t; i < na; i += step) a[i] = 0u;
+    for (uint32_t i = t; i < nb; i += step) b[i] = 0u;
+    for (uint32_t i = t; i < nc; i += step) c[i] = 0u;
+    for (uint32_t i = t; i < nd; i += step) d[i] = 0u;
+    for (uint32_t i = t; i < ne; i += step) e[i] = 0u;
+}
+
 struct LocalStats {
     uint32_t units = 0, heavy = 0, levels = 0;
     int32_t max_val = 0;
@@ -895,16 +907,15 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     KOMB_HIP(ctx, bufs.alloc(&g.list, (size_t)n));
     KOMB_HIP(ctx, bufs.alloc(&g.giant, (size_t)n));                // at most n entries of 16 bytes; the pool hands out what is asked for
     KOMB_HIP(ctx, bufs.alloc(&g.khist, (size_t)kKeyBins));
-    KOMB_HIP(ctx, hipMemsetAsync(g.khist, 0, kKeyBins * sizeof(uint32_t), s));
     KOMB_HIP(ctx, bufs.alloc(&d_lctrl, 1));
     uint32_t *d_cnt = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)kCntWords + kCntTimerWords));
-    KOMB_HIP(ctx, hipMemsetAsync(d_cnt, 0, (kCntWords + kCntTimerWords) * sizeof(uint32_t), s));
     KOMB_HIP(ctx, bufs.alloc(&d_cctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&d_present, present_words));
-    KOMB_HIP(ctx, hipMemsetAsync(d_lctrl, 0, sizeof(LocalCtrl), s));
-    KOMB_HIP(ctx, hipMemsetAsync(g.len + n, 0, sizeof(uint32_t), s));
-    KOMB_HIP(ctx, hipMemsetAsync(d_present, 0, present_words * sizeof(uint32_t), s));
+    static_assert(sizeof(LocalCtrl) % sizeof(uint32_t) == 0, "LocalCtrl is zeroed word by word");
+    if (present_words > 0xFFFFFFFFull) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "local finish: %zu presence words", present_words);
+    k_local_zero<<<64, kBlock, 0, s>>>(g.khist, kKeyBins, d_cnt, (uint32_t)(kCntWords + kCntTimerWords), (uint32_t *)d_lctrl, (uint32_t)(sizeof(LocalCtrl) / sizeof(uint32_t)),
+                                       g.len + n, 1u, d_present, (uint32_t)present_words);
     void *d_items = nullptr;
     auto release_all = [&]() {
         bufs.release(d_items); bufs.release(d_num); bufs.release(g.off); bufs.release(g.len); bufs.release(g.val);
