@@ -1,3 +1,5 @@
+"""Quick check of the three index layouts (and the first-frontier queue) against the oracle on one 40k-vertex graph; prints the
+layout that ran, parity, and the peel's statistics.  usage: python scripts/dbg_layouts.py   (GPU box)"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, komb_amd
