@@ -102,8 +102,11 @@ __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restric
                                                         const uint32_t *__restrict__ chunk_base,
                                                         int32_t *__restrict__ out_col, int32_t *__restrict__ out_src,
                                                         unsigned long long *__restrict__ keep_bits,
-                                                        unsigned long long *__restrict__ keep_upper_bits)
+                                                        unsigned long long *__restrict__ keep_upper_bits,
+                                                        uint32_t *__restrict__ upper_cnt)
 {
+    // upper_cnt (nullable, pass 1, with keep_upper_bits): upper slots (column above row) per 64-slot word, kept or not: their
+    // prefix sum is the canonical edge id of a word's first upper slot
     // keep_upper_bits (nullable, pass 1): the kept slots whose column is above their row -- the canonical (u < v) copies
     // that are also the oriented copies; the result gather ranks the others through them
     // keep_bits: one bit per slot (64-slot words = one wavefront ballot).  Pass 1 evaluates the predicate
@@ -122,9 +125,13 @@ __global__ __launch_bounds__(kBlock) void k_slot_filter(const int32_t *__restric
             bool keep = false;
             if (!FILL) {
                 bool up = false;
-                if (j < ns) { const int32_t a = src[j], b = col[j]; keep = pred(a, b); up = keep && b > a; }
+                bool upper = false;
+                if (j < ns) { const int32_t a = src[j], b = col[j]; keep = pred(a, b); upper = b > a; up = keep && upper; }
                 const uint64_t m = __ballot(keep);
-                if (keep_upper_bits) { const uint64_t mu = __ballot(up); if (lane == 0 && jw < ns) keep_upper_bits[jw >> 6] = mu; }
+                if (keep_upper_bits) {
+                    const uint64_t mu = __ballot(up), ma = __ballot(upper);
+                    if (lane == 0 && jw < ns) { keep_upper_bits[jw >> 6] = mu; upper_cnt[jw >> 6] = (uint32_t)__popcll(ma); }
+                }
                 if (lane == 0 && jw < ns) keep_bits[jw >> 6] = m;
                 total += (uint32_t)__popcll(m);
                 continue;
@@ -202,22 +209,6 @@ __global__ __launch_bounds__(kBlock) void k_rowptr_search(const int32_t *__restr
             if ((int64_t)src[mid] < v) lo = mid + 1; else hi = mid;
         }
         rowptr[v] = (uint32_t)lo;
-    }
-}
-
-// number of upper slots (col > row id) of every row: rows are ascending, so it is a suffix
-__global__ __launch_bounds__(kBlock) void k_upper_count(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                        int64_t nv, uint32_t *__restrict__ ucnt)
-{
-    for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < nv; u += (int64_t)gridDim.x * kBlock) {
-        uint32_t lo = rowptr[u];
-        const uint32_t end = rowptr[u + 1];
-        uint32_t hi = end;
-        while (lo < hi) {                                       // first slot with col > u
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (col[mid] > (int32_t)u) hi = mid; else lo = mid + 1;
-        }
-        ucnt[u] = end - lo;
     }
 }
 
@@ -1246,32 +1237,38 @@ __global__ __launch_bounds__(kBlock) void k_rev_emit(const int32_t *__restrict__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
+__global__ __launch_bounds__(kBlock) void k_gather_canonical(const int32_t *__restrict__ src,
                                                              const int32_t *__restrict__ col, int64_t ns,
                                                              const unsigned long long *__restrict__ obits,
                                                              const uint32_t *__restrict__ wrank,
                                                              const unsigned long long *__restrict__ kubits,
                                                              const uint32_t *__restrict__ kurank,
                                                              const unsigned long long *__restrict__ rev_sorted,
-                                                             const uint32_t *__restrict__ ebase,
+                                                             const uint32_t *__restrict__ urank,
                                                              const int32_t *__restrict__ truss, const uint32_t *__restrict__ off,
                                                              int32_t *__restrict__ eu, int32_t *__restrict__ ev,
                                                              int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
-        const int32_t u = src[j], v = col[j];
-        if (v <= u) continue;
-        const uint32_t eb = ebase[u];
-        const uint32_t first_upper = rowptr[u + 1] - (ebase[u + 1] - eb);
-        const uint32_t c = eb + ((uint32_t)j - first_upper);
-        const unsigned long long word = obits[j >> 6];
-        const unsigned long long below = (1ull << (j & 63)) - 1ull;
+    // a wavefront's 64 lanes hold the 64 slots of one word of the bitmasks: the canonical id of an upper slot is the number of
+    // upper slots before it = urank[word] (a prefix sum the orientation's predicate pass prepared) + a popcount of the ballot
+    const int64_t nwords = (ns + 63) >> 6;
+    const int lane = lane_id();
+    for (int64_t w = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; w < nwords; w += ((int64_t)gridDim.x * kBlock) >> 6) {
+        const int64_t j = (w << 6) + lane;
+        int32_t u = 0, v = 0;
+        if (j < ns) { u = src[j]; v = col[j]; }
+        const bool up = j < ns && v > u;
+        const unsigned long long um = __ballot(up);
+        if (!up) continue;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t c = urank[w] + (uint32_t)__popcll(um & below);
+        const unsigned long long word = obits[w];
         int32_t t, sp;
-        if ((word >> (j & 63)) & 1ull) {                               // slot (u,v) is the oriented copy
-            const uint32_t o = wrank[j >> 6] + (uint32_t)__popcll(word & below);
+        if ((word >> lane) & 1ull) {                                   // slot (u,v) is the oriented copy
+            const uint32_t o = wrank[w] + (uint32_t)__popcll(word & below);
             t = truss[o]; sp = (int32_t)(off[o + 1] - off[o]);
         } else {
-            const unsigned long long r = rev_sorted[c - (kurank[j >> 6] + (uint32_t)__popcll(kubits[j >> 6] & below))];
+            const unsigned long long r = rev_sorted[c - (kurank[w] + (uint32_t)__popcll(kubits[w] & below))];
             t = (int32_t)(uint32_t)r; sp = (int32_t)(uint32_t)(r >> 32);
         }
         eu[c] = u; ev[c] = v;
@@ -1324,7 +1321,7 @@ template <class Pred>
 static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const int32_t *col, int64_t ns, int64_t nv, Pred pred,
                          uint32_t *out_rowptr, int32_t **out_col, int32_t **out_src, int64_t *n_out,
                          unsigned long long **keep_bits_out = nullptr, uint32_t **word_rank_out = nullptr,
-                         unsigned long long **keep_upper_out = nullptr)
+                         unsigned long long **keep_upper_out = nullptr, uint32_t **upper_cnt_out = nullptr)
 {
     hipStream_t s = ctx->stream;
     const int64_t nchunks = (ns + kChunkSlots - 1) / kChunkSlots;
@@ -1336,15 +1333,20 @@ static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const
     KOMB_HIP(ctx, hipMemsetAsync(d_cc, 0, ((size_t)nchunks + 1) * sizeof(uint32_t), s));
     const int g = grid_for(nchunks, 1, 256 * 32);
     unsigned long long *d_kub = nullptr;
-    if (keep_upper_out) KOMB_HIP(ctx, bufs.alloc(&d_kub, (size_t)(ns + 63) / 64 + 1));
-    k_slot_filter<Pred, false><<<g, kBlock, 0, s>>>(src, col, ns, pred, d_cc, nullptr, nullptr, nullptr, d_bits, d_kub);
-    if (keep_upper_out) *keep_upper_out = d_kub;
+    uint32_t *d_ucw = nullptr;
+    if (keep_upper_out) {
+        KOMB_HIP(ctx, bufs.alloc(&d_kub, (size_t)(ns + 63) / 64 + 1));
+        KOMB_HIP(ctx, bufs.alloc(&d_ucw, (size_t)(ns + 63) / 64 + 2));
+        KOMB_HIP(ctx, hipMemsetAsync(d_ucw + (ns + 63) / 64, 0, 2 * sizeof(uint32_t), s));
+    }
+    k_slot_filter<Pred, false><<<g, kBlock, 0, s>>>(src, col, ns, pred, d_cc, nullptr, nullptr, nullptr, d_bits, d_kub, d_ucw);
+    if (keep_upper_out) { *keep_upper_out = d_kub; *upper_cnt_out = d_ucw; }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cc, d_cb, nchunks + 1));
     uint32_t kept = 0;
     KOMB_HIP(ctx, d2h(ctx, &kept, d_cb + nchunks, sizeof(uint32_t)));
     KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept + 4));        // + 4: the triangle enumeration reads 16 bytes at a time
     KOMB_HIP(ctx, bufs.alloc(out_src, (size_t)kept));
-    k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits, nullptr);
+    k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits, nullptr, nullptr);
     if ((int64_t)kept * 4 < nv) k_rowptr_search<<<grid_for(nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
     else k_rowptr_from_src<<<grid_for(kept), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);
     if (word_rank_out) {
@@ -1440,8 +1442,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     unsigned long long *d_obits = nullptr;                           // bit j: working slot j is the oriented copy of its edge
     uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
     unsigned long long *d_kubits = nullptr;                          // ... and is an upper slot (its row's id below its column's)
-    if (use_classes) KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrientClass{d_deg, d_deg8, d_deg2, dth[0], dth[1], dth[2]}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits));
-    else KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits));
+    uint32_t *d_urank = nullptr;                                     // upper slots per 64-slot word (the gather turns it into their prefix sum)
+    if (use_classes) KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrientClass{d_deg, d_deg8, d_deg2, dth[0], dth[1], dth[2]}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank));
+    else KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank));
     st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
 
@@ -1941,19 +1944,14 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
 
     // ---- canonical-order results with original vertex ids
     phase.next("truss: canonical gather");
-    uint32_t *d_ucnt = nullptr, *d_ebase = nullptr;
     ctx->timer.start(s);
-    KOMB_HIP(ctx, bufs.alloc(&d_ucnt, (size_t)nv + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
-    KOMB_HIP(ctx, hipMemsetAsync(d_ucnt, 0, ((size_t)nv + 1) * sizeof(uint32_t), s));
-    k_upper_count<<<gv, kBlock, 0, s>>>(w_rowptr, w_col, nv, d_ucnt);
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_ucnt, d_ebase, nv + 1));
+    const int64_t nwords = (w_ns + 63) / 64;
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_urank, d_urank, nwords + 1));     // upper slots before every word = canonical id of its first upper slot
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
     // the reversed oriented slots (source id above target id), stably sorted by target: see k_gather_canonical
-    const int64_t nwords = (w_ns + 63) / 64;
     uint32_t *d_kurank = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_kurank, (size_t)nwords + 1));
     k_popc_words<<<grid_for(nwords + 1), kBlock, 0, s>>>(d_kubits, nwords, d_kurank);
@@ -1975,7 +1973,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         uint32_t *sk = nullptr;
         KOMB_TRY(prim_sort_pairs_u32_u64(ctx, d_rkey, d_rkey2, d_rval, d_rval2, n_rev, 0, vbits, &sk, &d_rev_sorted));
     }
-    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_rowptr, w_src, w_col, w_ns, d_obits, d_wrank, d_kubits, d_kurank, d_rev_sorted, d_ebase, d_truss, d_off,
+    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_src, w_col, w_ns, d_obits, d_wrank, d_kubits, d_kurank, d_rev_sorted, d_urank, d_truss, d_off,
                                                         ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
     if (getenv("KOMB_POOL_DEBUG")) {
