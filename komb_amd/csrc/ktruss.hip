@@ -13,10 +13,15 @@
 //   2. enumerate every triangle once (k_triangles: edge a->b, every element of
 //      N+(b) looked up in the LDS-staged N+(a)) and build the incidence index:
 //      for every edge, the pairs of the other two edges of its triangles
-//      (24 bytes per triangle).  Default: ONE enumeration into slices sized by
-//      the bound sup(a->b) <= d(a)-1 (~26 GB at |E|=100M -- the 288 GB of HBM
-//      buy it) followed by a streaming compaction into the dense index; the
-//      exact count-scan-fill two-pass layout serves sharded runs and fallback.
+//      (24 bytes per triangle).  Default (round 3): ONE enumeration; the entries
+//      of a task's own edges leave it as a dense block, every other entry as a
+//      12-byte record of one stream -- no atomic, no scattered store per
+//      triangle; the records are radix-sorted by BIN (2048 consecutive edges)
+//      and one workgroup per bin assembles its window of the index in LDS
+//      (k_bin_count, k_bin_finish), which also writes the slice offsets, the
+//      peel's initial state and the first level's frontier.  Round 2's bounded
+//      slices (KOMB_INDEX=slices) and the exact count-scan-fill two-pass layout
+//      (KOMB_INDEX=two_pass, the fallback) are kept and tested.
 //   3. peel: level-synchronous sub-rounds driven by the device control block
 //      (peel_dev.h).  A frontier edge walks its incidence slice; a triangle
 //      whose other two edges are both still present loses one support on each
@@ -25,7 +30,9 @@
 //      exactly on the level enqueues it for the next sub-round.  The peel
 //      never touches the adjacency again.
 //   4. gather results into canonical (min,max)-lexicographic edge order with
-//      ORIGINAL vertex ids -- the identity the C ABI promises.
+//      ORIGINAL vertex ids -- the identity the C ABI promises.  No search: the
+//      oriented copies that sit in the other endpoint's row travel through a
+//      stable radix sort by target id, after which every access is a stream.
 #include "peel_dev.h"
 #include "truss_tail.h"
 #include "local_dev.h"
