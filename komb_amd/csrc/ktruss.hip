@@ -295,7 +295,10 @@ constexpr int kTriR = 4;                       // consecutive elements of one ro
 struct __attribute__((packed, aligned(4))) Int4U { int32_t x, y, z, w; };      // 16 bytes at a 4-byte aligned address
 struct __attribute__((packed, aligned(4))) UInt2U { uint32_t x, y; };
 constexpr int kTriBuf = 128;                   // parked triangles per wave on the unstaged path (handled once >= 64 are waiting)
-constexpr int kTriRec = 384;                   // triangle records a staged task keeps until it is done (own-role entries, 8 bytes each)
+#ifndef KOMB_TRI_REC
+#define KOMB_TRI_REC 384
+#endif
+constexpr int kTriRec = KOMB_TRI_REC;           // triangle records a staged task keeps until it is done (own-role entries, 8 bytes each)
 constexpr int kTriCand = KOMB_TRI_CAND;        // parked lookup candidates per wave (searched once >= 64 are waiting)
 constexpr int kTriWaves = kBlock / kWave;
 #ifndef KOMB_TRI_SIGW
