@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KOMB_ACCEL_ABI_VERSION 3
+#define KOMB_ACCEL_ABI_VERSION 4
 
 typedef enum komb_status {
     KOMB_OK          =  0,
@@ -79,7 +79,10 @@ typedef struct komb_stats {
     double  ms_sort;                /* truss: sort of the incidence records by destination edge */
     int64_t tri_records;            /* truss: record positions of the stream (incl. unused claim tails) */
     int32_t index_layout;           /* truss: 0 = record stream, 1 = bounded slices, 2 = exact two-pass */
-    int32_t reserved0;
+    /* sharded peel (ABI version 4): the last komb_core_run_sharded / komb_truss_run_sharded with komb_set_shard_peel */
+    int32_t shard_exchanges;        /* all-reduce callbacks made by the peel (two per sub-round + level changes) */
+    double  ms_exchange;            /* host time inside them (stream drain + callback); part of ms_core / ms_peel */
+    int64_t exchange_words;         /* 32-bit words they carried                                                 */
 } komb_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -113,6 +116,14 @@ int komb_graph_get_csr(komb_ctx *ctx, int64_t *rowptr, int32_t *col);
  * degree/coreness in HBM (this is the timed region of bench.py);
  * komb_core_fetch copies them out; komb_degree_coreness = run + fetch. */
 int komb_core_run(komb_ctx *ctx);
+/* One process per GPU, every rank holding the same graph: rank r owns the vertices
+ * [nv*r/world, nv*(r+1)/world) -- their live degrees and the decrements on them; every sub-round the ranks exchange
+ * their parts of the frontier through `allreduce` (komb_allreduce_fn below: each rank fills its own segment of a zeroed
+ * buffer, so the SUM is the concatenation), stamp the whole frontier and walk all of its rows, each applying the
+ * decrements it owns.  All ranks end with identical, complete results, bit-equal to komb_core_run's.  world == 1 is
+ * the same engine without a collective. */
+typedef int (*komb_allreduce_fn)(void *user, void *device_u32, int64_t count);
+int komb_core_run_sharded(komb_ctx *ctx, int32_t rank, int32_t world, komb_allreduce_fn allreduce, void *user);
 int komb_core_fetch(komb_ctx *ctx, int32_t *degree /*[nv]*/, int32_t *coreness /*[nv]*/);
 int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness);
 
@@ -132,10 +143,14 @@ int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
  * library has drained its stream when it calls, the reduction must be complete when the
  * callback returns; 32-bit two's-complement sums, so an int32 view of the words is fine;
  * return 0 on success).  Incidence index, peel and gather then run on every rank; all
- * ranks end with identical results.  world == 1 is komb_truss_run. */
-typedef int (*komb_allreduce_fn)(void *user, void *device_u32, int64_t count);
+ * ranks end with identical results.  world == 1 is komb_truss_run.
+ * komb_set_shard_peel(ctx, 1) makes the following sharded runs split the PEEL as well: rank r owns the internal edge ids
+ * [m*r/world, m*(r+1)/world) -- their live supports and the decrements on them -- and the ranks exchange their parts of
+ * the frontier every sub-round through the same callback (as komb_core_run_sharded does for vertices).  Same results;
+ * slower than the replicated peel on one node (DESIGN.md section 6 has the measurements), hence opt-in. */
 int komb_truss_run_sharded(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world,
                            komb_allreduce_fn allreduce, void *user);
+int komb_set_shard_peel(komb_ctx *ctx, int32_t on);
 int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub);
 int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss);
 /* per-edge triangle counts the peel started from (canonical order) */

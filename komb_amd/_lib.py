@@ -41,7 +41,8 @@ class KombStats(ctypes.Structure):
         ("truss_local_units", ctypes.c_int32), ("truss_local_sweeps", ctypes.c_int32),
         ("ms_core_local", ctypes.c_double), ("ms_truss_local", ctypes.c_double),
         ("ms_sort", ctypes.c_double), ("tri_records", ctypes.c_int64),
-        ("index_layout", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("index_layout", ctypes.c_int32), ("shard_exchanges", ctypes.c_int32),
+        ("ms_exchange", ctypes.c_double), ("exchange_words", ctypes.c_int64),
     ]
 
 
@@ -57,6 +58,8 @@ SIGNATURES = {
     "komb_graph_info": (_i32, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "komb_graph_get_csr": (_i32, [_vp, _vp, _vp]),
     "komb_core_run": (_i32, [_vp]),
+    "komb_core_run_sharded": (_i32, [_vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp]),
+    "komb_set_shard_peel": (_i32, [_vp, ctypes.c_int32]),
     "komb_core_fetch": (_i32, [_vp, _vp, _vp]),
     "komb_degree_coreness": (_i32, [_vp, _vp, _vp]),
     "komb_truss_run": (_i32, [_vp, _vp]),

@@ -91,6 +91,10 @@ class KombAccel:
     def core_run(self):
         self._check(self._lib.komb_core_run(self._ctx))
 
+    def set_shard_peel(self, on=True):
+        """komb_set_shard_peel: sharded k-truss runs split the peel by edge range as well (opt-in; shard_dev.h)."""
+        self._check(self._lib.komb_set_shard_peel(self._ctx, 1 if on else 0))
+
     def core_fetch(self):
         deg = np.zeros(self.nv, dtype=np.int32)
         core = np.zeros(self.nv, dtype=np.int32)

@@ -123,6 +123,21 @@ int komb_core_run(komb_ctx *ctx)
     return core_run(ctx);
 }
 
+int komb_core_run_sharded(komb_ctx *ctx, int32_t rank, int32_t world, komb_allreduce_fn allreduce, void *user)
+{
+    KOMB_TRY(require_device(ctx));
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce))
+        KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_core_run_sharded: bad rank %d / world %d / callback", rank, world);
+    return core_run(ctx, rank, world, allreduce, user, true);
+}
+
+int komb_set_shard_peel(komb_ctx *ctx, int32_t on)
+{
+    if (!ctx) return KOMB_ERR_ARG;
+    ctx->shard_peel = on != 0;
+    return KOMB_OK;
+}
+
 int komb_core_fetch(komb_ctx *ctx, int32_t *degree, int32_t *coreness)
 {
     KOMB_TRY(require_device(ctx));

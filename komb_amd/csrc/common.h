@@ -248,6 +248,7 @@ struct komb_ctx {
     int64_t t_ne = -1;                       // edges of the (sub)graph last run
     int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr; // canonical order
     bool truss_done = false;
+    bool shard_peel = false;                 // komb_set_shard_peel: sharded runs split the peel too (shard_dev.h)
 
     // ---- pinned host mirrors of the control blocks (double buffered)
     komb::PeelCtrl *h_ctrl = nullptr;        // [2]
@@ -336,7 +337,7 @@ int prim_sort_pairs_u32_u32(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, u
                             int64_t n, int end_bit, uint32_t **sorted_keys, uint32_t **sorted_vals);
 
 // ---- stages (each in its own translation unit)
-int core_run(komb_ctx *ctx);
+int core_run(komb_ctx *ctx, int rank = 0, int world = 1, komb_allreduce_fn fn = nullptr, void *user = nullptr, bool sharded = false);
 int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, komb_allreduce_fn fn, void *user);
 int merge_run(komb_ctx *ctx, const double *susp_host, int32_t *order, int32_t *side, int64_t *n_block, double *max_density);
 int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t n, double *rank_deg, double *rank_key);

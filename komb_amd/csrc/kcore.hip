@@ -14,6 +14,7 @@
 #include "peel_dev.h"
 #include "core_tail.h"
 #include "local_dev.h"
+#include "shard_dev.h"
 
 #include <cstdlib>
 
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(kBlock) void k_core_init(const uint32_t *__restrict
 
 struct CoreProblem {
     static constexpr bool kChain = true;
+    static constexpr bool kSingleStep = false;
     uint32_t units;
     const uint32_t *rowptr;
     const int32_t *col;
@@ -70,12 +72,50 @@ struct CoreProblem {
     }
 };
 
+// The same peel with the live degrees owned by vertex range (shard_dev.h): every rank walks every frontier vertex's row;
+// a decrement is applied -- and can trigger -- only on the rank that owns the neighbour.  No in-launch chaining: a
+// triggered vertex has to reach the other ranks before its row is walked.
+struct ShardCore {
+    static constexpr bool kChain = false;
+    static constexpr bool kSingleStep = true;
+    uint32_t units;
+    const uint32_t *rowptr;
+    const int32_t *col;
+    int32_t *degw;
+    int32_t *core;
+    uint32_t lo, hi;                     // vertices this rank owns
+
+    __device__ __forceinline__ const int32_t *scan_marker() const { return core; }
+    __device__ __forceinline__ const int32_t *scan_key() const { return degw; }
+    __device__ __forceinline__ void mark_scanned(uint32_t v, const CtrlView &cv) const { core[v] = cv.level; }
+    __device__ __forceinline__ void slice(uint32_t v, uint32_t &b, uint32_t &len) const
+    {
+        b = rowptr[v];
+        len = rowptr[v + 1] - b;
+    }
+    struct Loaded { int32_t u, c; };
+    __device__ __forceinline__ Loaded item_load(int32_t, uint32_t pos, const CtrlView &) const
+    {
+        Loaded ld;
+        ld.u = col[pos];
+        ld.c = ((uint32_t)ld.u - lo < hi - lo) ? core[ld.u] : 0;      // 0: not this rank's to decrement
+        return ld;
+    }
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &, uint32_t &, uint32_t &) const
+    {
+        if (marker_alive(ld.c)) {
+            if (atomicSub(&degw[ld.u], 1) == cv.level + 1) { core[ld.u] = cv.level; t0 = ld.u; }
+        }
+    }
+};
+
 // ---- hand-over to the local finish (local_dev.h)
 // Collect pass: the peel engine run once over all live vertices; a live neighbour of a live vertex becomes an
 // entry of the compact row (ids of the remainder).  Liveness of the neighbour comes from a bitmap (nv / 8 bytes,
 // L2-resident) instead of a gather into core[].
 struct CoreCollect {
     static constexpr bool kChain = false;
+    static constexpr bool kSingleStep = false;
     uint32_t units;
     const uint32_t *rowptr;
     const int32_t *col;
@@ -195,7 +235,7 @@ int peel_grid(int64_t units)
     return (int)g;
 }
 
-int core_run(komb_ctx *ctx)
+int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *user, bool sharded)
 {
     if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_core_run: no graph loaded");
     const int64_t nv = ctx->nv;
@@ -209,6 +249,8 @@ int core_run(komb_ctx *ctx)
     stt.core_levels = stt.core_subrounds = stt.core_launches = 0;
     stt.max_coreness = 0; stt.ms_core = 0.0;
     stt.core_local_units = 0; stt.core_local_sweeps = 0; stt.core_local_items = 0; stt.ms_core_local = 0.0;
+    if (getenv("KOMB_SHARD_PEEL")) sharded = true;               // (one rank: the sharded engine without a collective -- a test of its logic)
+    if (sharded) { stt.shard_exchanges = 0; stt.ms_exchange = 0.0; stt.exchange_words = 0; }
     if (nv == 0) { ctx->core_done = true; return KOMB_OK; }
 
     Range r_all("komb_core_run");
@@ -304,7 +346,21 @@ int core_run(komb_ctx *ctx)
         return KOMB_OK;
     };
     int launches = 0, st = KOMB_OK;
-    if (tail_limit && (uint64_t)nv <= tail_limit) {
+    if (sharded) {
+        // live degrees owned by vertex range, the frontier exchanged every sub-round, no finish (shard_dev.h)
+        uint32_t iw[2] = {0u, 0u};
+        KOMB_HIP(ctx, d2h(ctx, iw, d_grp + kInitOff, sizeof(iw)));     // isolated vertices; the smallest positive degree
+        ShardCore SP{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, d_degw, ctx->d_core, 0u, 0u};
+        shard_bounds((uint64_t)nv, rank, world, &SP.lo, &SP.hi);
+        ShardStats ss;
+        st = shard_peel(ctx, bufs, SP, (uint32_t)nv, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
+                        [&](int32_t launch) { k_peel_step<ShardCore><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, SP, launch); }, &ss);
+        stt.shard_exchanges = (int32_t)ss.exchanges; stt.ms_exchange = ss.ms_exchange; stt.exchange_words = ss.words;
+        launches = ss.launches;
+        PeelCtrl fc{};
+        fc.done = 1; fc.n_levels = ss.levels; fc.n_rounds = ss.rounds; fc.n_scans = ss.scans; fc.max_level = ss.max_level;
+        ctx->h_ctrl[0] = fc;
+    } else if (tail_limit && (uint64_t)nv <= tail_limit) {
         // small graph: the finish takes the whole peel (unless nothing is left to peel)
         st = d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) == hipSuccess ? KOMB_OK : KOMB_ERR_DEVICE;
         if (st == KOMB_OK && !ctx->h_ctrl[0].done) st = (fin == FIN_LOCAL) ? run_local() : run_tail(nullptr, (uint32_t)nv);

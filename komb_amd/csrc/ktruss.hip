@@ -36,6 +36,7 @@
 #include "peel_dev.h"
 #include "truss_tail.h"
 #include "local_dev.h"
+#include "shard_dev.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1106,6 +1107,7 @@ __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t 
 // A decrement that returns level+1 triggers the edge (trussness level+2).
 struct TrussProblem {
     static constexpr bool kChain = false;
+    static constexpr bool kSingleStep = false;
     uint32_t units;
     const uint32_t *off;
     const int2 *inc;
@@ -1146,11 +1148,62 @@ struct TrussProblem {
     }
 };
 
+// The same peel with the supports owned by edge range (shard_dev.h): every rank walks every frontier edge's triangles and
+// makes the same decisions from the replicated stamps; a decrement is applied -- and can trigger -- only on the rank that
+// owns its target.  (The owner stamps a triggered edge at once, the other ranks when the next frontier arrives: both
+// values are "later than this sub-round" to everything that reads them in between.)
+struct ShardTruss {
+    static constexpr bool kChain = false;
+    static constexpr bool kSingleStep = true;
+    uint32_t units;
+    const uint32_t *off;
+    const int2 *inc;
+    int32_t *sup;
+    int32_t *stamp;
+    int32_t *truss;
+    uint32_t lo, hi;                     // internal edge ids this rank owns
+
+    __device__ __forceinline__ const int32_t *scan_marker() const { return stamp; }
+    __device__ __forceinline__ const int32_t *scan_key() const { return sup; }
+    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const
+    {
+        stamp[e] = cv.round;
+        truss[e] = cv.level + 2;
+    }
+    __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
+    {
+        b = off[e];
+        len = off[e + 1] - b;
+    }
+    __device__ __forceinline__ bool mine(int32_t e) const { return (uint32_t)e - lo < hi - lo; }
+    struct Loaded { int32_t me, x, y, sx, sy; };
+    __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
+    {
+        Loaded ld;
+        const int2 p = inc[pos];
+        ld.me = me; ld.x = p.x; ld.y = p.y;
+        ld.sx = stamp[p.x]; ld.sy = stamp[p.y];
+        return ld;
+    }
+    __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &t1, uint32_t &, uint32_t &) const
+    {
+        const int32_t r = cv.round, L = cv.level;
+        if (ld.sx < r || ld.sy < r) return;             // an edge of the triangle is already gone
+        const bool xin = (ld.sx == r), yin = (ld.sy == r);
+        const bool decx = !xin && (!yin || ld.me < ld.y) && mine(ld.x);
+        const bool decy = !yin && (!xin || ld.me < ld.x) && mine(ld.y);
+        // (triggered edges are reported as light units: the next frontier is re-classified after the exchange)
+        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; truss[ld.x] = L + 2; t0 = ld.x; }
+        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; truss[ld.y] = L + 2; t1 = ld.y; }
+    }
+};
+
 // ---- hand-over to the local finish (local_dev.h)
 // Collect pass: the peel engine run once over all live edges; a triangle whose other two edges are both live
 // becomes an entry of the compact slice (ids of the remainder).
 struct TrussCollect {
     static constexpr bool kChain = false;
+    static constexpr bool kSingleStep = false;
     uint32_t units;
     const uint32_t *off;                 // the peel's incidence index
     const int2 *inc;
@@ -1496,6 +1549,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 32);
     // (a graph small enough for the finish to take the whole peel is handed over before any step: no frontier may be queued)
     const bool whole_peel_finish = tail_limit && (uint64_t)m <= tail_limit;
+    // the peel sharded by edge range, one exchange per sub-round (shard_dev.h): komb_set_shard_peel, or KOMB_SHARD_PEEL=1 (with
+    // one rank: the same engine without a collective -- a test of its logic)
+    const bool shard_peel_on = (ctx->shard_peel && world > 1) || getenv("KOMB_SHARD_PEEL") != nullptr;
     enum { IDX_STREAM = 0, IDX_SLICES = 1, IDX_TWO_PASS = 2 };
     int layout = IDX_STREAM;
     if (const char *ix = getenv("KOMB_INDEX")) {
@@ -1614,7 +1670,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)n_bins + 2));
                 KOMB_HIP(ctx, bufs.alloc(&d_bintot, (size_t)n_bins + 2));
                 KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
-                if (!whole_peel_finish && !getenv("KOMB_NO_FIRST_QUEUE")) KOMB_HIP(ctx, bufs.alloc(&d_light0, (size_t)m));
+                if (!whole_peel_finish && !shard_peel_on && !getenv("KOMB_NO_FIRST_QUEUE")) KOMB_HIP(ctx, bufs.alloc(&d_light0, (size_t)m));
                 ctx->timer.start(s);
                 peel_ctrl_pre(s, d_grp);
                 KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
@@ -1912,7 +1968,22 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     int launches = 0, rc = KOMB_OK;
     st.truss_tail_runs = 0; st.ms_tail = 0.0;
     st.truss_local_units = 0; st.truss_local_sweeps = 0; st.truss_local_items = 0; st.ms_truss_local = 0.0;
-    if (whole_peel_finish) {
+    st.shard_exchanges = 0; st.ms_exchange = 0.0; st.exchange_words = 0;
+    if (shard_peel_on) {
+        // supports owned by edge range, the frontier exchanged every sub-round, no finish (shard_dev.h)
+        uint32_t iw[2] = {0u, 0u};
+        KOMB_HIP(ctx, d2h(ctx, iw, d_grp + kInitOff, sizeof(iw)));     // triangle-free edges; the smallest positive support
+        ShardTruss SP{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss, 0u, 0u};
+        shard_bounds((uint64_t)m, rank, world, &SP.lo, &SP.hi);
+        ShardStats ss;
+        rc = shard_peel(ctx, bufs, SP, (uint32_t)m, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
+                        [&](int32_t launch) { k_peel_step<ShardTruss><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, SP, launch); }, &ss);
+        st.shard_exchanges = (int32_t)ss.exchanges; st.ms_exchange = ss.ms_exchange; st.exchange_words = ss.words;
+        launches = ss.launches;
+        PeelCtrl fc{};
+        fc.done = 1; fc.n_levels = ss.levels; fc.n_rounds = ss.rounds; fc.n_scans = ss.scans; fc.max_level = ss.max_level;
+        ctx->h_ctrl[0] = fc;
+    } else if (whole_peel_finish) {
         // small graph: the finish takes the whole peel (unless it is refused, or nothing is left to peel)
         rc = d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)) == hipSuccess ? KOMB_OK : KOMB_ERR_DEVICE;
         if (rc == KOMB_OK && !ctx->h_ctrl[0].done) rc = (fin == FIN_LOCAL) ? run_local() : run_tail(nullptr, (uint32_t)m);

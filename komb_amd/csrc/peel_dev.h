@@ -290,6 +290,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 // ------------------------------------------------------------ the step kernel
 // Problem concept (all __device__):
 //   static constexpr bool kChain;        triggered light units may be peeled in the same launch
+//   static constexpr bool kSingleStep;   a launch never chains a second step (the sharded peel of shard_dev.h)
 //   uint32_t units;
 //   const int32_t *scan_marker();        [units] alive marker (common.h: it carries the unit's class) or round / level number
 //   const int32_t *scan_key();           [units] live keys, or null when every live unit is a hit (collect passes)
@@ -673,6 +674,7 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
     }
     // one workgroup did the whole step: finalise locally, chain the next step if it is small too
     if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc, launch);
+    if (P::kSingleStep) return;                        // (shard_dev.h: the next frontier has to be exchanged first)
     __syncthreads();
     cv = sh_cv;
     if (cv.done || chained >= kMaxInKernelSteps) return;

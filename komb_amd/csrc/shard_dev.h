@@ -1,0 +1,228 @@
+// shard_dev.h -- the peel of peel_dev.h split over the ranks of one node ("sparse path"):
+// every rank holds the whole read-only structure (CSR / incidence index) and the whole liveness state, and OWNS a
+// contiguous range of the units (vertices for k-core, internal edge ids for k-truss): only the owner keeps a unit's
+// live key (degree / support) and only the owner decrements it.
+//
+// One sub-round, on every rank:
+//   1. the rank's own part of the frontier is a plain id list (the SCAN of its own range at a level's start, afterwards
+//      the units its own decrements triggered);
+//   2. EXCHANGE: the lists of all ranks are concatenated on every rank.  The C ABI gives the library one collective, an
+//      in-place SUM all-reduce of 32-bit words (komb_allreduce_fn); a concatenation is that all-reduce over a buffer in
+//      which every rank has filled its own segment and zeroed the others.  Two calls per sub-round: the ranks' counts
+//      (and, after a SCAN, each rank's smallest live key above the level, for level skipping), then the ids;
+//   3. every rank stamps ALL frontier units (so liveness -- and, for the truss peel, the sub-round stamps its tie-break
+//      reads -- stay replicated), sorts them into the engine's light / heavy queues, and runs ONE PROCESS step of
+//      k_peel_step over the WHOLE frontier with a problem type that applies a decrement only when the target is in the
+//      rank's own range: every rank recomputes the same decisions and keeps the share it owns.  No atomics cross ranks.
+// The control flow on every rank follows the exchanged totals only, so the ranks stay in lock step without any other
+// message, and integer decrements are order independent: results are bit-identical to the single-GPU peel.
+//
+// What this costs is in DESIGN.md section 6: every rank still reads every frontier unit's items (only the atomics are
+// divided), and a sub-round pays two collectives and two host round trips.  It is the partition the survey prescribes,
+// built and tested; it is not the faster way to use N GPUs for one graph, and it is opt-in (komb_set_shard_peel).
+#pragma once
+
+#include "peel_dev.h"
+
+#include <chrono>
+
+namespace komb {
+
+// SCAN of the rank's own range [lo, hi) at level L: live units with key <= L -> out[], words[0] = how many;
+// words[1] = the smallest live key above L in the range (0x7FFFFFFF: none)
+template <class P>
+__global__ __launch_bounds__(kBlock) void k_shard_scan(P p, uint32_t lo, uint32_t hi, int32_t L, int32_t *__restrict__ out, uint32_t *words)
+{
+    const int32_t *mk = p.scan_marker(), *ky = p.scan_key();
+    const int lane = lane_id();
+    int32_t lmin = 0x7FFFFFFF;
+    for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * kBlock; base < hi; base += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t u = base + threadIdx.x;
+        bool hit = false;
+        if (u < hi && marker_alive(mk[u])) {
+            const int32_t k = ky[u];
+            if (k <= L) hit = true; else lmin = min(lmin, k);
+        }
+        const uint64_t m = __ballot(hit);
+        if (m) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&words[0], (uint32_t)__popcll(m));
+            b = (uint32_t)__shfl((int)b, 0);
+            if (hit) out[b + (uint32_t)__popcll(m & lanemask_lt())] = (int32_t)u;
+        }
+    }
+    lmin = wave_min(lmin);
+    if (lane == 0 && lmin != 0x7FFFFFFF) atomicMin(reinterpret_cast<int32_t *>(&words[1]), lmin);
+}
+
+static __global__ void k_shard_scan_reset(uint32_t *words)
+{
+    if (threadIdx.x == 0) { words[0] = 0u; words[1] = 0x7FFFFFFFu; }
+}
+
+// the rank's line of the header exchange: hdr[rank] = its count, hdr[world + rank] = its smallest live key above the level
+static __global__ void k_shard_header(uint32_t *hdr, int world, int rank, const uint32_t *cnt, const uint32_t *mn)
+{
+    for (int i = (int)threadIdx.x; i < 2 * world; i += (int)blockDim.x) hdr[i] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) { hdr[rank] = *cnt; hdr[world + rank] = mn ? *mn : 0x7FFFFFFFu; }
+}
+
+// every rank, over the whole exchanged frontier: stamp the units (mark_scanned: liveness / sub-round / result) and sort
+// them into the engine's queues -- light ids, heavy units as one (unit, chunk) entry per kChunk items.
+// words[2] / words[3]: the queues' fills.
+template <class P>
+__global__ __launch_bounds__(kBlock) void k_shard_mark(P p, const uint32_t *__restrict__ list, uint32_t n, CtrlView cv,
+                                                      int32_t *__restrict__ ql, int2 *__restrict__ qh, uint32_t *words)
+{
+    const int lane = lane_id();
+    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < n; base += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        uint32_t unit = 0, b = 0, len = 0;
+        if (valid) { unit = list[i]; p.slice(unit, b, len); p.mark_scanned(unit, cv); }
+        const bool light = valid && len <= (uint32_t)kLight, heavy = valid && len > (uint32_t)kLight;
+        const uint64_t ml = __ballot(light);
+        if (ml) {
+            uint32_t o = 0;
+            if (lane == 0) o = atomicAdd(&words[2], (uint32_t)__popcll(ml));
+            o = (uint32_t)__shfl((int)o, 0);
+            if (light) ql[o + (uint32_t)__popcll(ml & lanemask_lt())] = (int32_t)unit;
+        }
+        uint64_t mh = __ballot(heavy);
+        while (mh) {                                        // a heavy unit's entries are written by the whole wavefront
+            const int src = __ffsll((long long)mh) - 1;
+            mh &= mh - 1;
+            const int32_t u = __shfl((int)unit, src);
+            const uint32_t nch = ((uint32_t)__shfl((int)len, src) + kChunk - 1) / kChunk;
+            uint32_t o = 0;
+            if (lane == 0) o = atomicAdd(&words[3], nch);
+            o = (uint32_t)__shfl((int)o, 0);
+            for (uint32_t c = (uint32_t)lane; c < nch; c += kWave) qh[o + c] = make_int2(u, (int)c);
+        }
+    }
+}
+
+// control block of the one PROCESS step that follows (the engine reads it at entry; its finaliser leaves the number of
+// units this rank's decrements triggered in cur_light, their ids in the other light queue)
+static __global__ void k_shard_setup(PeelCtrl *ctrl, const uint32_t *words, int32_t level, int32_t round, int32_t sel, int32_t launch)
+{
+    if (threadIdx.x == 0) {
+        PeelCtrl c{};
+        c.mode = MODE_PROCESS; c.level = level; c.round = round; c.done = 0;
+        c.cur_light = words[2]; c.cur_heavy = words[3]; c.cur_sel = sel;
+        c.remaining = 0x7FFFFFFFu;                          // the host keeps the count; the device must never decide "done"
+        c.next_min = 0x7FFFFFFF;
+        c.seq = launch;
+        *ctrl = c;
+    }
+}
+
+// the rank's own unit range: contiguous, by count
+inline void shard_bounds(uint64_t units, int rank, int world, uint32_t *lo, uint32_t *hi)
+{
+    *lo = (uint32_t)(units * (uint64_t)rank / (uint64_t)world);
+    *hi = (uint32_t)(units * (uint64_t)(rank + 1) / (uint64_t)world);
+}
+
+struct ShardStats {
+    int32_t levels = 0, rounds = 0, scans = 0, launches = 0, max_level = 0;
+    int64_t exchanges = 0, words = 0;                        // collective calls; 32-bit words they carried
+    double ms_exchange = 0.0;                                // host time inside (drain + callback), all calls
+};
+
+// The host loop.  `zeros` units were peeled by the init kernel (level 0), `first_level` is the smallest live key;
+// launch_step(i) issues k_peel_step<sharded problem> with launch index i.  Q.light[0..1] hold `units` ids each,
+// Q.heavy[0..1] the chunk entries of any frontier; d_xbuf holds `units` words.
+template <class P, class LaunchStep>
+int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, uint32_t units, uint32_t zeros, int32_t first_level, int rank, int world,
+               komb_allreduce_fn fn, void *user, PeelQueues &Q, PeelCtrl *d_ctrl, LaunchStep &&launch_step, ShardStats *out)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t lo = p.lo, hi = p.hi;                     // the rank's own units (shard_bounds)
+    uint32_t *d_words = nullptr, *d_hdr = nullptr, *d_xbuf = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_words, 8));
+    KOMB_HIP(ctx, bufs.alloc(&d_hdr, (size_t)2 * world));
+    KOMB_HIP(ctx, bufs.alloc(&d_xbuf, (size_t)units));
+    std::vector<uint32_t> hdr((size_t)2 * world);
+    ShardStats ss;
+    if (zeros) ss.levels = 1;
+    auto exchange = [&](uint32_t *buf, int64_t count) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        KOMB_HIP(ctx, hipStreamSynchronize(s));             // the buffer is complete when the callback runs
+        if (world > 1 && fn(user, buf, count) != 0) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: all-reduce callback failed");
+        ss.ms_exchange += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ++ss.exchanges; ss.words += count;
+        return KOMB_OK;
+    };
+    const int scan_grid = (int)std::min<uint64_t>(((uint64_t)(hi - lo) + kBlock - 1) / kBlock + 1, 2048);
+    const uint32_t *cur_light_word = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(d_ctrl) + offsetof(PeelCtrl, cur_light));
+    uint64_t remaining = (uint64_t)units - zeros;
+    int32_t L = first_level, round = 1, launch = 0;
+    int own_q = 0;                                           // Q.light[own_q] holds this rank's part of the next frontier
+    bool after_scan = false, level_counted = false;
+    auto scan = [&]() -> int {
+        k_shard_scan_reset<<<1, 64, 0, s>>>(d_words);
+        k_shard_scan<P><<<scan_grid, kBlock, 0, s>>>(p, lo, hi, L, Q.light[own_q], d_words);
+        ++ss.scans;
+        after_scan = true; level_counted = false;
+        return KOMB_OK;
+    };
+    if (remaining) KOMB_TRY(scan());
+    const uint64_t max_iter = 4ull * units + 4096;
+    for (uint64_t it = 0; remaining > 0; ++it) {
+        if (it > max_iter) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: no progress");
+        // ---- exchange 1: counts (and the ranks' minima after a SCAN)
+        k_shard_header<<<1, 64, 0, s>>>(d_hdr, world, rank, after_scan ? d_words : cur_light_word, after_scan ? d_words + 1 : nullptr);
+        KOMB_TRY(exchange(d_hdr, (int64_t)2 * world));
+        KOMB_HIP(ctx, d2h(ctx, hdr.data(), d_hdr, hdr.size() * sizeof(uint32_t)));
+        uint64_t total = 0, my_off = 0;
+        int32_t gmin = 0x7FFFFFFF;
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) my_off = total;
+            total += hdr[(size_t)r];
+            gmin = std::min(gmin, (int32_t)hdr[(size_t)world + r]);
+        }
+        if (total > remaining) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: %llu frontier units of %llu left", (unsigned long long)total, (unsigned long long)remaining);
+        if (total == 0) {
+            // the level is exhausted on every rank: the next one, or -- straight after a SCAN that found nothing -- the
+            // smallest live key anywhere
+            if (after_scan) {
+                if (gmin == 0x7FFFFFFF) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: %llu units left but none is live", (unsigned long long)remaining);
+                L = gmin;
+            } else L += 1;
+            KOMB_TRY(scan());
+            continue;
+        }
+        if (!level_counted) { ++ss.levels; ss.max_level = L; level_counted = true; }
+        // ---- exchange 2: the ids, each rank's list in its own segment of a zeroed buffer
+        const uint32_t mine = hdr[(size_t)rank];
+        if (world > 1) {
+            KOMB_HIP(ctx, hipMemsetAsync(d_xbuf, 0, (size_t)total * sizeof(uint32_t), s));
+            if (mine) KOMB_HIP(ctx, hipMemcpyAsync(d_xbuf + my_off, Q.light[own_q], (size_t)mine * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            KOMB_TRY(exchange(d_xbuf, (int64_t)total));
+        } else if (mine) {
+            KOMB_HIP(ctx, hipMemcpyAsync(d_xbuf, Q.light[own_q], (size_t)mine * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        }
+        // ---- every rank: stamp + classify the whole frontier, then one PROCESS step that keeps the rank's own decrements
+        KOMB_HIP(ctx, hipMemsetAsync(d_words + 2, 0, 2 * sizeof(uint32_t), s));
+        CtrlView cv{};
+        cv.mode = MODE_PROCESS; cv.level = L; cv.round = round; cv.cur_sel = own_q;
+        const int mark_grid = (int)std::min<uint64_t>((total + kBlock - 1) / kBlock, 2048);
+        k_shard_mark<P><<<mark_grid, kBlock, 0, s>>>(p, d_xbuf, (uint32_t)total, cv, Q.light[own_q], Q.heavy[own_q], d_words);
+        ++launch;
+        k_shard_setup<<<1, 64, 0, s>>>(d_ctrl, d_words, L, round, own_q, launch);
+        launch_step(launch);
+        ++ss.launches; ++ss.rounds;
+        own_q ^= 1;                                          // the units this rank's decrements triggered are in the other light queue
+        after_scan = false;
+        ++round;
+        remaining -= total;
+    }
+    KOMB_HIP(ctx, hipStreamSynchronize(s));
+    bufs.release(d_words); bufs.release(d_hdr); bufs.release(d_xbuf);
+    *out = ss;
+    return KOMB_OK;
+}
+
+} // namespace komb

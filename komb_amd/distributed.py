@@ -79,9 +79,23 @@ def make_allreduce_callback(device_index, group=None):
     return _lib.ALLREDUCE_FN(_cb)
 
 
-def truss_run_sharded(acc, vmask=None, group=None):
-    """komb_truss_run_sharded on this rank's KombAccel; every rank must call it."""
+def core_run_sharded(acc, group=None):
+    """komb_core_run_sharded on this rank's KombAccel (live degrees owned by vertex range, the frontier exchanged every
+    sub-round through the all-reduce callback); every rank must call it."""
     import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    cb = make_allreduce_callback(acc.device, group)
+    acc._keepalive = cb
+    rc = acc._lib.komb_core_run_sharded(acc._ctx, rank, world, ctypes.cast(cb, ctypes.c_void_p), None)
+    acc._check(rc)
+
+
+def truss_run_sharded(acc, vmask=None, group=None, shard_peel=None):
+    """komb_truss_run_sharded on this rank's KombAccel; every rank must call it.  shard_peel=True/False switches the
+    sharded peel (komb_set_shard_peel) for this and the following runs; None leaves the context as it is."""
+    import torch.distributed as dist
+    if shard_peel is not None:
+        acc.set_shard_peel(shard_peel)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if vmask is not None:
         vmask = np.ascontiguousarray(vmask, dtype=np.uint8)

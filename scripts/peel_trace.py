@@ -5,7 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import komb_amd
 import bench
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
-nv, ncl, alpha, seed = bench.CONFIGS[name][:4]
+if len(sys.argv) > 3:                  # a shape instead of a configuration: nv n_cliques alpha
+    nv, ncl, alpha, seed = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), 42
+    name = f"{nv}_{ncl}_{alpha}"
+else:
+    nv, ncl, alpha, seed = bench.CONFIGS[name][:4]
 out = f"gpurun_out/peel_trace_{name}.txt"
 os.makedirs("gpurun_out", exist_ok=True)
 if os.path.exists(out): os.remove(out)

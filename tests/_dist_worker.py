@@ -105,12 +105,79 @@ def c3_main():
     dist.destroy_process_group()
 
 
+def _peel_graphs():
+    """(name, nv, raw pairs): shapes whose frontiers hold light and heavy units, long cascades and empty levels."""
+    rng = np.random.default_rng(5)
+    out = []
+    nv = 60000
+    out.append(("hug60k", nv, np.asarray(komb_amd.gen_hug_edges(nv, int(2.6 * nv), 2.6, 11)).reshape(-1, 2)))
+    nv = 20000
+    out.append(("hug20k_a2.1", nv, np.asarray(komb_amd.gen_hug_edges(nv, int(2.7 * nv), 2.1, 3)).reshape(-1, 2)))
+    # a clique on 120 vertices (every edge has 118 triangles: heavy units; one populated level far above the others),
+    # a star over everything (a hub row of nv - 1 slots) and a long path (a cascade: one unit per sub-round)
+    nv = 5000
+    iu = np.triu_indices(120, 1)
+    clique = np.stack(iu, axis=1) + 100
+    star = np.stack([np.zeros(nv - 1, np.int64), np.arange(1, nv)], axis=1)
+    path = np.stack([np.arange(2000, 4999), np.arange(2001, 5000)], axis=1)
+    out.append(("clique+star+path", nv, np.concatenate([clique, star, path, rng.integers(0, nv, (3000, 2))])))
+    out.append(("empty", 10, np.zeros((0, 2), np.int64)))
+    out.append(("triangle-free", 1000, np.stack([np.arange(0, 999), np.arange(1, 1000)], axis=1)))
+    return out
+
+
+def peel_main():
+    """SURVEY 8(e)'s sharded peel (komb_amd/csrc/shard_dev.h) on the GPU box: the ranks (sharing GPU 0, gloo) own vertex /
+    edge ranges and exchange their parts of the frontier every sub-round; coreness, supports and trussness must equal the
+    oracle's on every rank."""
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    for name, nv, uv in _peel_graphs():
+        uv = np.ascontiguousarray(uv, dtype=np.int64)
+        rowptr, col = O.simplify(nv, uv)
+        with komb_amd.KombAccel(device=0) as a:
+            a.from_edges(nv, uv)
+            kd.core_run_sharded(a)
+            deg, core = a.core_fetch()
+            assert np.array_equal(core, O.coreness(rowptr, col)), f"{name}: sharded coreness mismatch on rank {rank}"
+            st = a.stats()
+            if a.ne:
+                assert st["shard_exchanges"] > 0 and st["exchange_words"] >= 2 * world, (name, st["shard_exchanges"])
+            kd.truss_run_sharded(a, shard_peel=True)
+            st = a.stats()
+            tr_levels = st["truss_levels"]
+            eu, ev, tr, sup = a.truss_fetch(with_support=True)
+            osup, otri = O.support(rowptr, col)
+            assert np.array_equal(sup, osup), f"{name}: support mismatch on rank {rank}"
+            assert np.array_equal(tr, O.trussness(rowptr, col)), f"{name}: sharded-peel trussness mismatch on rank {rank}"
+            if otri:
+                assert st["shard_exchanges"] > 0 and st["ms_exchange"] > 0
+            # the replicated peel of the same context, after the sharded one
+            kd.truss_run_sharded(a, shard_peel=False)
+            st2 = a.stats()
+            assert st2["shard_exchanges"] == 0
+            assert np.array_equal(a.truss_fetch()[2], tr)
+            assert st2["max_trussness"] == st["max_trussness"] and (tr_levels >= 1 or a.ne == 0), (name, st2["truss_levels"], tr_levels)
+            if name == "hug60k":
+                mask = (O.coreness(rowptr, col) >= 5).astype(np.uint8)
+                kd.truss_run_sharded(a, mask, shard_peel=True)
+                seu, sev, stra = a.truss_fetch()
+                weu, wev, wtr = O.trussness_induced(rowptr, col, mask)
+                assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+        dist.barrier()
+    if rank == 0:
+        print("DIST_OK peel", world)
+    dist.destroy_process_group()
+
+
 def main():
     mode = sys.argv[1]
     if mode == "rccl":
         return rccl_main()
     if mode == "c3":
         return c3_main()
+    if mode == "peel":
+        return peel_main()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     nv = 3000 if mode == "cpu" else 60000

@@ -47,6 +47,15 @@ def test_world2_sharded_c3_size(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_peel_on_gpu(built, world):
+    """SURVEY 8(e)'s partition: komb_core_run_sharded and komb_truss_run_sharded with komb_set_shard_peel -- vertex / edge
+    ranges owned by the ranks, the frontier exchanged every sub-round -- against the oracle, 2 and 3 ranks (uneven ranges)."""
+    r = _launch("peel", world, 29615 + world)
+    assert r.returncode == 0 and f"DIST_OK peel {world}" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_rccl_inplace_branch_single_rank(built):
     """backend "nccl" on the GPU box: the in-place RCCL branch of komb_amd.distributed's callback runs (one rank)."""
     r = _launch("rccl", 1, 29613)

@@ -26,7 +26,7 @@ def _i64(x):
 
 def test_native_library_is_loaded(K):
     lib = K._lib.load()
-    assert lib.komb_abi_version() == 3
+    assert lib.komb_abi_version() == 4
     with open("/proc/self/maps") as f:
         assert "libkomb_accel.so" in f.read()
 
@@ -272,6 +272,41 @@ def test_index_layouts_agree(K, O, monkeypatch):
                 assert st["tri_records"] >= 3 * st["triangles"]
             for x, y in zip(r1, r):
                 assert np.array_equal(x, y), kv
+
+
+def test_sharded_peel_engine_single_rank(K, O, monkeypatch):
+    """The sharded peel of shard_dev.h with ONE rank: the same host loop, kernels and range-filtered problem
+    types as with N ranks, the exchange being the identity -- k-core and k-truss against the oracle on graphs with hub rows
+    / hub edges (heavy units), cliques (one far level), cascades and the three index layouts.  (N ranks: tests/test_distributed.py.)"""
+    rng = np.random.default_rng(17)
+    iu = np.triu_indices(90, 1)
+    clique = np.stack(iu, axis=1) + 50
+    nvc = 4000
+    star = np.stack([np.zeros(nvc - 1, np.int64), np.arange(1, nvc)], axis=1)
+    path = np.stack([np.arange(1000, 3999), np.arange(1001, 4000)], axis=1)
+    cases = [(40000, K.gen_hug_edges(40000, 110000, 2.3, 21)), (30000, K.gen_hug_edges(30000, 80000, 2.1, 9)),
+             (nvc, np.concatenate([clique, star, path, rng.integers(0, nvc, (2500, 2))]).astype(np.int64)),
+             (500, rng.integers(0, 500, (30000, 2)).astype(np.int64))]
+    for i, (nv, uv) in enumerate(cases):
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            rowptr, col = a.get_csr()
+            monkeypatch.setenv("KOMB_SHARD_PEEL", "1")
+            deg, core = a.run_core()
+            st = a.stats()
+            assert np.array_equal(core, O.coreness(rowptr, col)), i
+            assert st["shard_exchanges"] > 0 and st["core_subrounds"] > 0
+            for layout in ("stream", "slices", "two_pass"):
+                monkeypatch.setenv("KOMB_INDEX", layout)
+                eu, ev, tr, sup = a.run_truss(with_support=True)
+                st = a.stats()
+                assert st["shard_exchanges"] > 0 and st["truss_local_units"] == 0
+                assert np.array_equal(sup, O.support(rowptr, col)[0]), (i, layout)
+                assert np.array_equal(tr, O.trussness(rowptr, col)), (i, layout)
+            monkeypatch.delenv("KOMB_INDEX", raising=False)
+            monkeypatch.delenv("KOMB_SHARD_PEEL", raising=False)
+            a.truss_run()
+            assert a.stats()["shard_exchanges"] == 0
 
 
 def test_orientation_class_table(K, O, monkeypatch):
