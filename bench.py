@@ -131,6 +131,11 @@ def main():
                     help="N > 1, opt-in: the same graph on every rank, every rank runs the whole single-GPU path, no exchange")
     ap.add_argument("--same-graph", action="store_true", help="(the default for N > 1; accepted for older command lines)")
     ap.add_argument("--shard", action="store_true", help="(the default for N > 1; accepted for older command lines)")
+    ap.add_argument("--shard-peel", action="store_true",
+                    help="N > 1, opt-in, on top of the default: the peel sharded by edge range too, the ranks' parts of the frontier "
+                         "exchanged every sub-round (SURVEY 8(e)'s partition, komb_set_shard_peel); slower than the replicated peel "
+                         "on one node (DESIGN.md section 6), so never what the plain command runs.  The k-core reported alongside "
+                         "then runs komb_core_run_sharded")
     ap.add_argument("--no-build", action="store_true",
                     help="load the prebuilt libkomb_accel.so, spawn no compiler (use under rocprofv3)")
     ap.add_argument("--faithful", action="store_true",
@@ -141,6 +146,8 @@ def main():
         raise SystemExit("--batch runs one graph per rank: it cannot be combined with --replicas / --same-graph / --shard")
     if args.replicas and args.shard:
         raise SystemExit("--replicas runs the unsharded path on every rank: it cannot be combined with --shard")
+    if args.shard_peel and (args.batch or args.replicas or args.gpus < 2):
+        raise SystemExit("--shard-peel shards one graph over N > 1 ranks: it cannot be combined with --batch / --replicas / --gpus 1")
     args.batch = args.gpus > 1 and args.batch
     # N > 1 default = BASELINE configs[3]: same graph, support counting sharded + one all-reduce
     args.shard = args.gpus > 1 and not args.batch and not args.replicas
@@ -242,7 +249,8 @@ def main():
 
     def step():
         if shard:
-            kd.truss_run_sharded(acc, group=data_group)   # support phase sharded by vertex range + all-reduce
+            # support phase sharded by vertex range + all-reduce; with --shard-peel the peel by edge range + one exchange per sub-round
+            kd.truss_run_sharded(acc, group=data_group, shard_peel=args.shard_peel)
         else:
             acc.truss_run()
 
@@ -251,7 +259,7 @@ def main():
     barrier_sync()
     t0 = time.perf_counter()
     phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_sort", "ms_compact", "ms_peel", "ms_tail",
-                              "ms_truss_local", "ms_gather")}
+                              "ms_truss_local", "ms_gather", "ms_exchange")}
     for _ in range(args.steps):
         step()
         s = acc.stats()
@@ -273,7 +281,10 @@ def main():
         phase[k] /= args.steps
 
     # k-core of the same graph, reported alongside (BASELINE config C2's op)
-    acc.core_run()
+    if shard and args.shard_peel:
+        kd.core_run_sharded(acc, group=data_group)
+    else:
+        acc.core_run()
     core_ms = acc.stats()["ms_core"]
     core_stats = acc.stats()
 
@@ -347,7 +358,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.batch else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": desc if world == 1 else
-                       (f"C4: the same graph as [{desc}] on {world} GPUs, k-truss with the triangle support sharded + all-reduce" if shard else
+                       (f"C4: the same graph as [{desc}] on {world} GPUs, k-truss with the triangle support sharded + all-reduce"
+                        + (", the peel sharded by edge range + one frontier exchange per sub-round" if args.shard_peel else "") if shard else
                         f"{world} x [{desc}] ({'one graph per rank' if args.batch else 'replicas of one graph'})"),
                        "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
                        "max_degree": st["max_degree"], "max_trussness": st["max_trussness"],
@@ -356,16 +368,21 @@ def main():
                        "truss_scans": st["truss_scans"], "truss_launches": st["truss_launches"],
                        "index_layout": ["record stream", "bounded slices", "exact two-pass"][st["index_layout"]],
                        "tri_records": st["tri_records"],
+                       **({"shard_peel": {"exchanges": st["shard_exchanges"], "exchange_words": st["exchange_words"]}} if args.shard_peel else {}),
                        "truss_local": {"edges": st["truss_local_units"], "index_entries": st["truss_local_items"],
                                        "sweeps": st["truss_local_sweeps"]},
                        "parallelism": "single" if world == 1 else
                        (f"batch: {world} independent graphs (seed + rank), one per GPU, no exchange on the data path" if args.batch else
                         (f"same graph on {world} ranks: triangle-support counting sharded by source-vertex range + one all-reduce of the "
-                         f"per-edge support vector ({exchange}); incidence fill, peel and gather replicated on every rank") if shard else
+                         f"per-edge support vector ({exchange}); incidence fill"
+                         + (", gather replicated; peel: supports owned by edge range, every rank walks the whole exchanged frontier and applies "
+                            f"its own decrements, {st['shard_exchanges']} exchanges per step" if args.shard_peel else ", peel and gather replicated on every rank")) if shard else
                         f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange")},
             "phases_ms": phase,
             "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
                       "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],
+                      **({"sharded": {"exchanges": core_stats["shard_exchanges"], "ms_exchange": core_stats["ms_exchange"],
+                                      "exchange_words": core_stats["exchange_words"]}} if shard and args.shard_peel else {}),
                       "local": {"vertices": core_stats["core_local_units"], "index_entries": core_stats["core_local_items"],
                                 "sweeps": core_stats["core_local_sweeps"], "ms": core_stats["ms_core_local"]},
                       "alg_bytes": 16 * nv + 24 * ne,

@@ -347,18 +347,20 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
     };
     int launches = 0, st = KOMB_OK;
     if (sharded) {
-        // live degrees owned by vertex range, the frontier exchanged every sub-round, no finish (shard_dev.h)
+        // live degrees owned by vertex range, the frontier exchanged every sub-round; the remainder goes to the replicated
+        // local finish under the replicated peel's rule, after one exchange of the live degrees (shard_dev.h)
         uint32_t iw[2] = {0u, 0u};
         KOMB_HIP(ctx, d2h(ctx, iw, d_grp + kInitOff, sizeof(iw)));     // isolated vertices; the smallest positive degree
         ShardCore SP{(uint32_t)nv, ctx->d_rowptr, ctx->d_col, d_degw, ctx->d_core, 0u, 0u};
         shard_bounds((uint64_t)nv, rank, world, &SP.lo, &SP.hi);
         ShardStats ss;
-        st = shard_peel(ctx, bufs, SP, (uint32_t)nv, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
-                        [&](int32_t launch) { k_peel_step<ShardCore><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, SP, launch); }, &ss);
+        st = shard_peel(ctx, bufs, SP, d_degw, (uint32_t)nv, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
+                        [&](int32_t launch) { k_peel_step<ShardCore><<<grid, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, SP, launch); },
+                        fin == FIN_LOCAL ? tail_limit : 0u, [&]() -> int { return run_local(); }, &ss);
         stt.shard_exchanges = (int32_t)ss.exchanges; stt.ms_exchange = ss.ms_exchange; stt.exchange_words = ss.words;
         launches = ss.launches;
         PeelCtrl fc{};
-        fc.done = 1; fc.n_levels = ss.levels; fc.n_rounds = ss.rounds; fc.n_scans = ss.scans; fc.max_level = ss.max_level;
+        fc.done = st == KOMB_OK ? 1 : 2; fc.n_levels = ss.levels; fc.n_rounds = ss.rounds; fc.n_scans = ss.scans; fc.max_level = ss.max_level;
         ctx->h_ctrl[0] = fc;
     } else if (tail_limit && (uint64_t)nv <= tail_limit) {
         // small graph: the finish takes the whole peel (unless nothing is left to peel)

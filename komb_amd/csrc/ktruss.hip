@@ -1970,18 +1970,20 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.truss_local_units = 0; st.truss_local_sweeps = 0; st.truss_local_items = 0; st.ms_truss_local = 0.0;
     st.shard_exchanges = 0; st.ms_exchange = 0.0; st.exchange_words = 0;
     if (shard_peel_on) {
-        // supports owned by edge range, the frontier exchanged every sub-round, no finish (shard_dev.h)
+        // supports owned by edge range, the frontier exchanged every sub-round; the remainder goes to the replicated local
+        // finish under the same rule as in the replicated peel, after one exchange of the live supports (shard_dev.h)
         uint32_t iw[2] = {0u, 0u};
         KOMB_HIP(ctx, d2h(ctx, iw, d_grp + kInitOff, sizeof(iw)));     // triangle-free edges; the smallest positive support
         ShardTruss SP{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss, 0u, 0u};
         shard_bounds((uint64_t)m, rank, world, &SP.lo, &SP.hi);
         ShardStats ss;
-        rc = shard_peel(ctx, bufs, SP, (uint32_t)m, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
-                        [&](int32_t launch) { k_peel_step<ShardTruss><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, SP, launch); }, &ss);
+        rc = shard_peel(ctx, bufs, SP, d_sup, (uint32_t)m, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
+                        [&](int32_t launch) { k_peel_step<ShardTruss><<<gp, kPeelBlock, 0, s>>>(d_ctrl, d_grp, Q, SP, launch); },
+                        fin == FIN_LOCAL ? tail_limit : 0u, [&]() -> int { return run_local(); }, &ss);
         st.shard_exchanges = (int32_t)ss.exchanges; st.ms_exchange = ss.ms_exchange; st.exchange_words = ss.words;
         launches = ss.launches;
         PeelCtrl fc{};
-        fc.done = 1; fc.n_levels = ss.levels; fc.n_rounds = ss.rounds; fc.n_scans = ss.scans; fc.max_level = ss.max_level;
+        fc.done = rc == KOMB_OK ? 1 : 2; fc.n_levels = ss.levels; fc.n_rounds = ss.rounds; fc.n_scans = ss.scans; fc.max_level = ss.max_level;
         ctx->h_ctrl[0] = fc;
     } else if (whole_peel_finish) {
         // small graph: the finish takes the whole peel (unless it is refused, or nothing is left to peel)

@@ -61,11 +61,12 @@ static __global__ void k_shard_scan_reset(uint32_t *words)
 }
 
 // the rank's line of the header exchange: hdr[rank] = its count, hdr[world + rank] = its smallest live key above the level
-static __global__ void k_shard_header(uint32_t *hdr, int world, int rank, const uint32_t *cnt, const uint32_t *mn)
+static __global__ void k_shard_header(uint32_t *hdr, int world, int rank, const uint32_t *cnt, const uint32_t *mn, uint32_t *words)
 {
     for (int i = (int)threadIdx.x; i < 2 * world; i += (int)blockDim.x) hdr[i] = 0u;
     __syncthreads();
     if (threadIdx.x == 0) { hdr[rank] = *cnt; hdr[world + rank] = mn ? *mn : 0x7FFFFFFFu; }
+    if (threadIdx.x == 1 && words) { words[2] = 0u; words[3] = 0u; }     // the fills of the queues the next k_shard_mark writes
 }
 
 // every rank, over the whole exchanged frontier: stamp the units (mark_scanned: liveness / sub-round / result) and sort
@@ -125,25 +126,81 @@ inline void shard_bounds(uint64_t units, int rank, int world, uint32_t *lo, uint
     *hi = (uint32_t)(units * (uint64_t)(rank + 1) / (uint64_t)world);
 }
 
+// exchange buffer of a sub-round: zeros, except the rank's own segment [off, off + mine) = its list
+static __global__ __launch_bounds__(kBlock) void k_shard_fill(uint32_t *__restrict__ x, uint64_t total, uint64_t off, uint32_t mine, const int32_t *__restrict__ own)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock)
+        x[i] = (i - off < (uint64_t)mine) ? (uint32_t)own[i - off] : 0u;
+}
+
+// hand-over to a replicated finish: the live keys are owned by range, so every rank first publishes (id, key) of its own
+// live units; after the exchange every rank writes all of them into its copy of the key array
+template <class P>
+__global__ __launch_bounds__(kBlock) void k_shard_live(P p, uint32_t lo, uint32_t hi, uint2 *__restrict__ out, uint32_t *words)
+{
+    const int32_t *mk = p.scan_marker(), *ky = p.scan_key();
+    const int lane = lane_id();
+    for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * kBlock; base < hi; base += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t u = base + threadIdx.x;
+        const bool live = u < hi && marker_alive(mk[u]);
+        const uint64_t m = __ballot(live);
+        if (m) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&words[0], (uint32_t)__popcll(m));
+            b = (uint32_t)__shfl((int)b, 0);
+            if (live) out[b + (uint32_t)__popcll(m & lanemask_lt())] = make_uint2((uint32_t)u, (uint32_t)ky[u]);
+        }
+    }
+}
+static __global__ __launch_bounds__(kBlock) void k_shard_fill2(uint2 *__restrict__ x, uint64_t total, uint64_t off, uint32_t mine, const uint2 *__restrict__ own)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock)
+        x[i] = (i - off < (uint64_t)mine) ? own[i - off] : make_uint2(0u, 0u);
+}
+static __global__ __launch_bounds__(kBlock) void k_shard_put(const uint2 *__restrict__ x, uint64_t total, int32_t *__restrict__ key)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const uint2 e = x[i];
+        key[e.x] = (int32_t)e.y;
+    }
+}
+// the control block a finish expects from a peel that hands over: `remaining` live units, no live list, the level that starts
+static __global__ void k_shard_handover(PeelCtrl *ctrl, uint32_t remaining, int32_t level, int32_t round, int32_t levels, int32_t max_level, uint32_t tail_limit)
+{
+    if (threadIdx.x == 0) {
+        PeelCtrl c{};
+        c.mode = MODE_SCAN; c.level = level; c.round = round; c.done = 3; c.remaining = remaining;
+        c.n_levels = levels; c.max_level = max_level; c.next_min = 0x7FFFFFFF; c.tail_limit = tail_limit; c.seq = 1;
+        *ctrl = c;
+    }
+}
+
 struct ShardStats {
     int32_t levels = 0, rounds = 0, scans = 0, launches = 0, max_level = 0;
     int64_t exchanges = 0, words = 0;                        // collective calls; 32-bit words they carried
+    uint32_t handed_over = 0;                                // units the replicated finish took (0: the sharded peel ran to the end)
     double ms_exchange = 0.0;                                // host time inside (drain + callback), all calls
 };
 
-// The host loop.  `zeros` units were peeled by the init kernel (level 0), `first_level` is the smallest live key;
+// The host loop.  key = the live keys (what p.scan_key() reads); `zeros` units were peeled by the init kernel (level 0), `first_level` is the smallest live key;
 // launch_step(i) issues k_peel_step<sharded problem> with launch index i.  Q.light[0..1] hold `units` ids each,
-// Q.heavy[0..1] the chunk entries of any frontier; d_xbuf holds `units` words.
-template <class P, class LaunchStep>
-int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, uint32_t units, uint32_t zeros, int32_t first_level, int rank, int world,
-               komb_allreduce_fn fn, void *user, PeelQueues &Q, PeelCtrl *d_ctrl, LaunchStep &&launch_step, ShardStats *out)
+// Q.heavy[0..1] the chunk entries of any frontier.
+// tail_limit / finish: the hand-over to the replicated local finish (local_dev.h), with the replicated peel's own rule -- a
+// level that starts with at most tail_limit units left (0: never).  The live keys are made whole on every rank first (one
+// exchange of the ranks' (id, key) lists); finish() then runs the caller's hand-over on ctx->h_ctrl[0] and leaves done = 1
+// there, or done = 0 and a smaller tail_limit when it declines.
+template <class P, class LaunchStep, class Finish>
+int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t units, uint32_t zeros, int32_t first_level, int rank, int world,
+               komb_allreduce_fn fn, void *user, PeelQueues &Q, PeelCtrl *d_ctrl, LaunchStep &&launch_step,
+               uint32_t tail_limit, Finish &&finish, ShardStats *out)
 {
     hipStream_t s = ctx->stream;
     const uint32_t lo = p.lo, hi = p.hi;                     // the rank's own units (shard_bounds)
     uint32_t *d_words = nullptr, *d_hdr = nullptr, *d_xbuf = nullptr;
+    const size_t xwords = std::max<size_t>((size_t)units, 2 * (size_t)std::min<uint32_t>(tail_limit, units)) + 2;
     KOMB_HIP(ctx, bufs.alloc(&d_words, 8));
     KOMB_HIP(ctx, bufs.alloc(&d_hdr, (size_t)2 * world));
-    KOMB_HIP(ctx, bufs.alloc(&d_xbuf, (size_t)units));
+    KOMB_HIP(ctx, bufs.alloc(&d_xbuf, xwords));
     std::vector<uint32_t> hdr((size_t)2 * world);
     ShardStats ss;
     if (zeros) ss.levels = 1;
@@ -155,7 +212,21 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, uint32_t units, uint32_
         ++ss.exchanges; ss.words += count;
         return KOMB_OK;
     };
-    const int scan_grid = (int)std::min<uint64_t>(((uint64_t)(hi - lo) + kBlock - 1) / kBlock + 1, 2048);
+    // counts (and minima) of all ranks -> hdr[]; returns the total and this rank's offset in the concatenation
+    auto exchange_counts = [&](const uint32_t *cnt, const uint32_t *mn, uint64_t *total, uint64_t *my_off, int32_t *gmin) -> int {
+        k_shard_header<<<1, 64, 0, s>>>(d_hdr, world, rank, cnt, mn, d_words);
+        KOMB_TRY(exchange(d_hdr, (int64_t)2 * world));
+        KOMB_HIP(ctx, d2h(ctx, hdr.data(), d_hdr, hdr.size() * sizeof(uint32_t)));
+        *total = 0; *my_off = 0; *gmin = 0x7FFFFFFF;
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) *my_off = *total;
+            *total += hdr[(size_t)r];
+            *gmin = std::min(*gmin, (int32_t)hdr[(size_t)world + r]);
+        }
+        return KOMB_OK;
+    };
+    auto grid_of = [](uint64_t n) { return (int)std::min<uint64_t>((n + kBlock - 1) / kBlock + 1, 2048); };
+    const int scan_grid = grid_of((uint64_t)(hi - lo));
     const uint32_t *cur_light_word = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(d_ctrl) + offsetof(PeelCtrl, cur_light));
     uint64_t remaining = (uint64_t)units - zeros;
     int32_t L = first_level, round = 1, launch = 0;
@@ -168,21 +239,48 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, uint32_t units, uint32_
         after_scan = true; level_counted = false;
         return KOMB_OK;
     };
+    // a level starts with `remaining` <= tail_limit units: make the live keys whole everywhere, then the caller's finish
+    auto hand_over = [&](bool *finished, bool publish_keys) -> int {
+        uint64_t total = 0, my_off = 0;
+        int32_t gmin = 0;
+        if (world > 1 && publish_keys) {
+            uint2 *own = reinterpret_cast<uint2 *>(Q.light[own_q]);          // (`units` words = units / 2 pairs >= tail_limit >= the live units)
+            k_shard_scan_reset<<<1, 64, 0, s>>>(d_words);
+            k_shard_live<P><<<scan_grid, kBlock, 0, s>>>(p, lo, hi, own, d_words);
+            KOMB_TRY(exchange_counts(d_words, nullptr, &total, &my_off, &gmin));
+            if (total != remaining) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: %llu live units found at the hand-over, %llu expected", (unsigned long long)total, (unsigned long long)remaining);
+            k_shard_fill2<<<grid_of(total), kBlock, 0, s>>>(reinterpret_cast<uint2 *>(d_xbuf), total, my_off, hdr[(size_t)rank], own);
+            KOMB_TRY(exchange(d_xbuf, (int64_t)(2 * total)));
+            k_shard_put<<<grid_of(total), kBlock, 0, s>>>(reinterpret_cast<const uint2 *>(d_xbuf), total, key);
+        }
+        k_shard_handover<<<1, 64, 0, s>>>(d_ctrl, (uint32_t)remaining, L, round, ss.levels, ss.max_level, tail_limit);
+        KOMB_HIP(ctx, d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)));
+        KOMB_TRY(finish());
+        const PeelCtrl &hc = ctx->h_ctrl[0];
+        if (hc.done == 1) {
+            ss.handed_over = (uint32_t)remaining;
+            ss.levels = hc.n_levels; ss.max_level = hc.max_level;
+            remaining = 0;
+            *finished = true;
+        } else {
+            tail_limit = hc.tail_limit < tail_limit ? hc.tail_limit : 0u;     // declined: offered again at the smaller size it named (or never)
+            *finished = false;
+        }
+        return KOMB_OK;
+    };
+    bool finished = false;
+    // a small input goes to the finish whole: nothing has been decremented yet, every rank's keys are whole
+    if (remaining && tail_limit && (uint64_t)units <= tail_limit) KOMB_TRY(hand_over(&finished, false));
+    // (later hand-overs: the ranks' (id, key) pairs live in a light queue of `units` words and in d_xbuf)
+    if (tail_limit > units / 2) tail_limit = units / 2;
     if (remaining) KOMB_TRY(scan());
     const uint64_t max_iter = 4ull * units + 4096;
     for (uint64_t it = 0; remaining > 0; ++it) {
         if (it > max_iter) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: no progress");
         // ---- exchange 1: counts (and the ranks' minima after a SCAN)
-        k_shard_header<<<1, 64, 0, s>>>(d_hdr, world, rank, after_scan ? d_words : cur_light_word, after_scan ? d_words + 1 : nullptr);
-        KOMB_TRY(exchange(d_hdr, (int64_t)2 * world));
-        KOMB_HIP(ctx, d2h(ctx, hdr.data(), d_hdr, hdr.size() * sizeof(uint32_t)));
         uint64_t total = 0, my_off = 0;
         int32_t gmin = 0x7FFFFFFF;
-        for (int r = 0; r < world; ++r) {
-            if (r == rank) my_off = total;
-            total += hdr[(size_t)r];
-            gmin = std::min(gmin, (int32_t)hdr[(size_t)world + r]);
-        }
+        KOMB_TRY(exchange_counts(after_scan ? d_words : cur_light_word, after_scan ? d_words + 1 : nullptr, &total, &my_off, &gmin));
         if (total > remaining) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: %llu frontier units of %llu left", (unsigned long long)total, (unsigned long long)remaining);
         if (total == 0) {
             // the level is exhausted on every rank: the next one, or -- straight after a SCAN that found nothing -- the
@@ -190,26 +288,24 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, uint32_t units, uint32_
             if (after_scan) {
                 if (gmin == 0x7FFFFFFF) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: %llu units left but none is live", (unsigned long long)remaining);
                 L = gmin;
-            } else L += 1;
+            } else {
+                L += 1;
+                if (tail_limit && remaining <= tail_limit) {
+                    KOMB_TRY(hand_over(&finished, true));
+                    if (finished) break;
+                }
+            }
             KOMB_TRY(scan());
             continue;
         }
         if (!level_counted) { ++ss.levels; ss.max_level = L; level_counted = true; }
         // ---- exchange 2: the ids, each rank's list in its own segment of a zeroed buffer
-        const uint32_t mine = hdr[(size_t)rank];
-        if (world > 1) {
-            KOMB_HIP(ctx, hipMemsetAsync(d_xbuf, 0, (size_t)total * sizeof(uint32_t), s));
-            if (mine) KOMB_HIP(ctx, hipMemcpyAsync(d_xbuf + my_off, Q.light[own_q], (size_t)mine * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-            KOMB_TRY(exchange(d_xbuf, (int64_t)total));
-        } else if (mine) {
-            KOMB_HIP(ctx, hipMemcpyAsync(d_xbuf, Q.light[own_q], (size_t)mine * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        }
+        k_shard_fill<<<grid_of(total), kBlock, 0, s>>>(d_xbuf, total, my_off, hdr[(size_t)rank], Q.light[own_q]);
+        if (world > 1) KOMB_TRY(exchange(d_xbuf, (int64_t)total));
         // ---- every rank: stamp + classify the whole frontier, then one PROCESS step that keeps the rank's own decrements
-        KOMB_HIP(ctx, hipMemsetAsync(d_words + 2, 0, 2 * sizeof(uint32_t), s));
         CtrlView cv{};
         cv.mode = MODE_PROCESS; cv.level = L; cv.round = round; cv.cur_sel = own_q;
-        const int mark_grid = (int)std::min<uint64_t>((total + kBlock - 1) / kBlock, 2048);
-        k_shard_mark<P><<<mark_grid, kBlock, 0, s>>>(p, d_xbuf, (uint32_t)total, cv, Q.light[own_q], Q.heavy[own_q], d_words);
+        k_shard_mark<P><<<grid_of(total), kBlock, 0, s>>>(p, d_xbuf, (uint32_t)total, cv, Q.light[own_q], Q.heavy[own_q], d_words);
         ++launch;
         k_shard_setup<<<1, 64, 0, s>>>(d_ctrl, d_words, L, round, own_q, launch);
         launch_step(launch);

@@ -137,21 +137,30 @@ def peel_main():
         rowptr, col = O.simplify(nv, uv)
         with komb_amd.KombAccel(device=0) as a:
             a.from_edges(nv, uv)
-            kd.core_run_sharded(a)
-            deg, core = a.core_fetch()
-            assert np.array_equal(core, O.coreness(rowptr, col)), f"{name}: sharded coreness mismatch on rank {rank}"
-            st = a.stats()
-            if a.ne:
-                assert st["shard_exchanges"] > 0 and st["exchange_words"] >= 2 * world, (name, st["shard_exchanges"])
-            kd.truss_run_sharded(a, shard_peel=True)
-            st = a.stats()
-            tr_levels = st["truss_levels"]
-            eu, ev, tr, sup = a.truss_fetch(with_support=True)
-            osup, otri = O.support(rowptr, col)
-            assert np.array_equal(sup, osup), f"{name}: support mismatch on rank {rank}"
-            assert np.array_equal(tr, O.trussness(rowptr, col)), f"{name}: sharded-peel trussness mismatch on rank {rank}"
-            if otri:
-                assert st["shard_exchanges"] > 0 and st["ms_exchange"] > 0
+            ocore, (osup, otri), otr = O.coreness(rowptr, col), O.support(rowptr, col), O.trussness(rowptr, col)
+            # "none": sharded sub-rounds to the end; "local": the remainder handed to the replicated local finish after one
+            # exchange of the live keys (a limit of 500 units: offered late, and on a dense remainder declined)
+            for finish, limit in (("none", None), ("local", None), ("local", "500")):
+                os.environ["KOMB_FINISH"] = finish
+                if limit: os.environ["KOMB_LOCAL_LIMIT"] = limit
+                else: os.environ.pop("KOMB_LOCAL_LIMIT", None)
+                kd.core_run_sharded(a)
+                deg, core = a.core_fetch()
+                assert np.array_equal(core, ocore), f"{name}/{finish}: sharded coreness mismatch on rank {rank}"
+                st = a.stats()
+                if a.ne and finish == "none":            # (with the local finish a small graph is handed over whole, before any exchange)
+                    assert st["shard_exchanges"] > 0 and st["exchange_words"] >= 2 * world, (name, st["shard_exchanges"])
+                kd.truss_run_sharded(a, shard_peel=True)
+                st = a.stats()
+                tr_levels = st["truss_levels"]
+                eu, ev, tr, sup = a.truss_fetch(with_support=True)
+                assert np.array_equal(sup, osup), f"{name}/{finish}: support mismatch on rank {rank}"
+                assert np.array_equal(tr, otr), f"{name}/{finish}: sharded-peel trussness mismatch on rank {rank}"
+                if otri and finish == "none":
+                    assert st["shard_exchanges"] > 0 and st["ms_exchange"] > 0
+                if finish == "none":
+                    assert st["truss_local_units"] == 0
+            os.environ.pop("KOMB_FINISH", None); os.environ.pop("KOMB_LOCAL_LIMIT", None)
             # the replicated peel of the same context, after the sharded one
             kd.truss_run_sharded(a, shard_peel=False)
             st2 = a.stats()

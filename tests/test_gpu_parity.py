@@ -292,18 +292,27 @@ def test_sharded_peel_engine_single_rank(K, O, monkeypatch):
             a.from_edges(nv, uv)
             rowptr, col = a.get_csr()
             monkeypatch.setenv("KOMB_SHARD_PEEL", "1")
-            deg, core = a.run_core()
-            st = a.stats()
-            assert np.array_equal(core, O.coreness(rowptr, col)), i
-            assert st["shard_exchanges"] > 0 and st["core_subrounds"] > 0
-            for layout in ("stream", "slices", "two_pass"):
-                monkeypatch.setenv("KOMB_INDEX", layout)
-                eu, ev, tr, sup = a.run_truss(with_support=True)
+            ocore, osup, otr = O.coreness(rowptr, col), O.support(rowptr, col)[0], O.trussness(rowptr, col)
+            # "none": the sharded sub-rounds to the very end; "local" (the default): the remainder is handed to the local
+            # finish under the replicated peel's rule (tiny limits: many offers, some declined)
+            for finish, limit in (("none", None), ("local", None), ("local", "300")):
+                monkeypatch.setenv("KOMB_FINISH", finish)
+                if limit: monkeypatch.setenv("KOMB_LOCAL_LIMIT", limit)
+                deg, core = a.run_core()
                 st = a.stats()
-                assert st["shard_exchanges"] > 0 and st["truss_local_units"] == 0
-                assert np.array_equal(sup, O.support(rowptr, col)[0]), (i, layout)
-                assert np.array_equal(tr, O.trussness(rowptr, col)), (i, layout)
-            monkeypatch.delenv("KOMB_INDEX", raising=False)
+                assert np.array_equal(core, ocore), (i, finish)
+                if finish == "none":                 # (with the local finish a small graph is handed over whole, before any exchange)
+                    assert st["shard_exchanges"] > 0 and st["core_subrounds"] > 0 and st["core_local_units"] == 0
+                for layout in ("stream", "slices", "two_pass"):
+                    monkeypatch.setenv("KOMB_INDEX", layout)
+                    eu, ev, tr, sup = a.run_truss(with_support=True)
+                    st = a.stats()
+                    if finish == "none": assert st["shard_exchanges"] > 0 and st["truss_local_units"] == 0
+                    assert np.array_equal(sup, osup), (i, finish, layout)
+                    assert np.array_equal(tr, otr), (i, finish, layout)
+                monkeypatch.delenv("KOMB_INDEX", raising=False)
+                monkeypatch.delenv("KOMB_LOCAL_LIMIT", raising=False)
+            monkeypatch.delenv("KOMB_FINISH", raising=False)
             monkeypatch.delenv("KOMB_SHARD_PEEL", raising=False)
             a.truss_run()
             assert a.stats()["shard_exchanges"] == 0
