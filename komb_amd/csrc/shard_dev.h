@@ -28,31 +28,63 @@
 
 namespace komb {
 
+// Ordered-by-nobody append of a workgroup's hits to a global list: ONE atomic on the list's fill per workgroup and trip
+// (U units per thread) -- a word takes ~88 atomics per microsecond, so a wavefront-level add per 64 units would spend
+// 17 ms on the fill alone when 100 M units are swept.  All threads of the workgroup must call it.
+template <int U, class T>
+__device__ __forceinline__ void block_append(const bool (&hit)[U], const T (&val)[U], uint32_t *fill, T *__restrict__ out)
+{
+    __shared__ uint32_t sh_cnt[kBlock / kWave];
+    __shared__ uint32_t sh_at;
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    uint64_t m[U];
+    uint32_t wave_total = 0;
+#pragma unroll
+    for (int k = 0; k < U; ++k) { m[k] = __ballot(hit[k]); wave_total += (uint32_t)__popcll(m[k]); }
+    __syncthreads();                                         // (the previous trip's readers of sh_cnt / sh_at are done)
+    if (lane == 0) sh_cnt[w] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int i = 0; i < kBlock / kWave; ++i) t += sh_cnt[i];
+        sh_at = t ? atomicAdd(fill, t) : 0u;
+    }
+    __syncthreads();
+    uint32_t o = sh_at;
+    for (int i = 0; i < w; ++i) o += sh_cnt[i];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        if (hit[k]) out[o + (uint32_t)__popcll(m[k] & lanemask_lt())] = val[k];
+        o += (uint32_t)__popcll(m[k]);
+    }
+}
+
+constexpr int kShardU = 8;                                   // units per thread and trip of the sweeps below
+
 // SCAN of the rank's own range [lo, hi) at level L: live units with key <= L -> out[], words[0] = how many;
 // words[1] = the smallest live key above L in the range (0x7FFFFFFF: none)
 template <class P>
 __global__ __launch_bounds__(kBlock) void k_shard_scan(P p, uint32_t lo, uint32_t hi, int32_t L, int32_t *__restrict__ out, uint32_t *words)
 {
     const int32_t *mk = p.scan_marker(), *ky = p.scan_key();
-    const int lane = lane_id();
     int32_t lmin = 0x7FFFFFFF;
-    for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * kBlock; base < hi; base += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t u = base + threadIdx.x;
-        bool hit = false;
-        if (u < hi && marker_alive(mk[u])) {
-            const int32_t k = ky[u];
-            if (k <= L) hit = true; else lmin = min(lmin, k);
+    const uint64_t tile = (uint64_t)kBlock * kShardU;
+    for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * tile; base < hi; base += (uint64_t)gridDim.x * tile) {
+        bool hit[kShardU];
+        int32_t id[kShardU];
+#pragma unroll
+        for (int k = 0; k < kShardU; ++k) {
+            const uint64_t u = base + (uint64_t)k * kBlock + threadIdx.x;
+            hit[k] = false; id[k] = (int32_t)u;
+            if (u < hi && marker_alive(mk[u])) {
+                const int32_t key = ky[u];
+                if (key <= L) hit[k] = true; else lmin = min(lmin, key);
+            }
         }
-        const uint64_t m = __ballot(hit);
-        if (m) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&words[0], (uint32_t)__popcll(m));
-            b = (uint32_t)__shfl((int)b, 0);
-            if (hit) out[b + (uint32_t)__popcll(m & lanemask_lt())] = (int32_t)u;
-        }
+        block_append<kShardU>(hit, id, &words[0], out);
     }
     lmin = wave_min(lmin);
-    if (lane == 0 && lmin != 0x7FFFFFFF) atomicMin(reinterpret_cast<int32_t *>(&words[1]), lmin);
+    if (lane_id() == 0 && lmin != 0x7FFFFFFF) atomicMin(reinterpret_cast<int32_t *>(&words[1]), lmin);
 }
 
 static __global__ void k_shard_scan_reset(uint32_t *words)
@@ -76,30 +108,37 @@ template <class P>
 __global__ __launch_bounds__(kBlock) void k_shard_mark(P p, const uint32_t *__restrict__ list, uint32_t n, CtrlView cv,
                                                       int32_t *__restrict__ ql, int2 *__restrict__ qh, uint32_t *words)
 {
+    constexpr int U = 4;
     const int lane = lane_id();
-    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < n; base += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t i = base + threadIdx.x;
-        const bool valid = i < n;
-        uint32_t unit = 0, b = 0, len = 0;
-        if (valid) { unit = list[i]; p.slice(unit, b, len); p.mark_scanned(unit, cv); }
-        const bool light = valid && len <= (uint32_t)kLight, heavy = valid && len > (uint32_t)kLight;
-        const uint64_t ml = __ballot(light);
-        if (ml) {
-            uint32_t o = 0;
-            if (lane == 0) o = atomicAdd(&words[2], (uint32_t)__popcll(ml));
-            o = (uint32_t)__shfl((int)o, 0);
-            if (light) ql[o + (uint32_t)__popcll(ml & lanemask_lt())] = (int32_t)unit;
+    const uint64_t tile = (uint64_t)kBlock * U;
+    for (uint64_t base = (uint64_t)blockIdx.x * tile; base < n; base += (uint64_t)gridDim.x * tile) {
+        bool light[U], heavy[U];
+        int32_t unit[U];
+        uint32_t len[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
+            const bool valid = i < n;
+            uint32_t b = 0;
+            unit[k] = 0; len[k] = 0;
+            if (valid) { unit[k] = (int32_t)list[i]; p.slice((uint32_t)unit[k], b, len[k]); p.mark_scanned((uint32_t)unit[k], cv); }
+            light[k] = valid && len[k] <= (uint32_t)kLight;
+            heavy[k] = valid && len[k] > (uint32_t)kLight;
         }
-        uint64_t mh = __ballot(heavy);
-        while (mh) {                                        // a heavy unit's entries are written by the whole wavefront
-            const int src = __ffsll((long long)mh) - 1;
-            mh &= mh - 1;
-            const int32_t u = __shfl((int)unit, src);
-            const uint32_t nch = ((uint32_t)__shfl((int)len, src) + kChunk - 1) / kChunk;
-            uint32_t o = 0;
-            if (lane == 0) o = atomicAdd(&words[3], nch);
-            o = (uint32_t)__shfl((int)o, 0);
-            for (uint32_t c = (uint32_t)lane; c < nch; c += kWave) qh[o + c] = make_int2(u, (int)c);
+        block_append<U>(light, unit, &words[2], ql);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            uint64_t mh = __ballot(heavy[k]);
+            while (mh) {                                    // a heavy unit's entries are written by the whole wavefront
+                const int src = __ffsll((long long)mh) - 1;
+                mh &= mh - 1;
+                const int32_t u = __shfl(unit[k], src);
+                const uint32_t nch = ((uint32_t)__shfl((int)len[k], src) + kChunk - 1) / kChunk;
+                uint32_t o = 0;
+                if (lane == 0) o = atomicAdd(&words[3], nch);
+                o = (uint32_t)__shfl((int)o, 0);
+                for (uint32_t c = (uint32_t)lane; c < nch; c += kWave) qh[o + c] = make_int2(u, (int)c);
+            }
         }
     }
 }
@@ -139,17 +178,17 @@ template <class P>
 __global__ __launch_bounds__(kBlock) void k_shard_live(P p, uint32_t lo, uint32_t hi, uint2 *__restrict__ out, uint32_t *words)
 {
     const int32_t *mk = p.scan_marker(), *ky = p.scan_key();
-    const int lane = lane_id();
-    for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * kBlock; base < hi; base += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t u = base + threadIdx.x;
-        const bool live = u < hi && marker_alive(mk[u]);
-        const uint64_t m = __ballot(live);
-        if (m) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&words[0], (uint32_t)__popcll(m));
-            b = (uint32_t)__shfl((int)b, 0);
-            if (live) out[b + (uint32_t)__popcll(m & lanemask_lt())] = make_uint2((uint32_t)u, (uint32_t)ky[u]);
+    const uint64_t tile = (uint64_t)kBlock * kShardU;
+    for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * tile; base < hi; base += (uint64_t)gridDim.x * tile) {
+        bool live[kShardU];
+        uint2 e[kShardU];
+#pragma unroll
+        for (int k = 0; k < kShardU; ++k) {
+            const uint64_t u = base + (uint64_t)k * kBlock + threadIdx.x;
+            live[k] = u < hi && marker_alive(mk[u]);
+            e[k] = make_uint2((uint32_t)u, live[k] ? (uint32_t)ky[u] : 0u);
         }
+        block_append<kShardU>(live, e, &words[0], out);
     }
 }
 static __global__ __launch_bounds__(kBlock) void k_shard_fill2(uint2 *__restrict__ x, uint64_t total, uint64_t off, uint32_t mine, const uint2 *__restrict__ own)
@@ -226,7 +265,8 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t 
         return KOMB_OK;
     };
     auto grid_of = [](uint64_t n) { return (int)std::min<uint64_t>((n + kBlock - 1) / kBlock + 1, 2048); };
-    const int scan_grid = grid_of((uint64_t)(hi - lo));
+    auto sweep_grid = [](uint64_t n, int per_thread) { const uint64_t t = (uint64_t)kBlock * per_thread; return (int)std::min<uint64_t>((n + t - 1) / t + 1, 2048); };
+    const int scan_grid = sweep_grid((uint64_t)(hi - lo), kShardU);
     const uint32_t *cur_light_word = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(d_ctrl) + offsetof(PeelCtrl, cur_light));
     uint64_t remaining = (uint64_t)units - zeros;
     int32_t L = first_level, round = 1, launch = 0;
@@ -305,7 +345,7 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t 
         // ---- every rank: stamp + classify the whole frontier, then one PROCESS step that keeps the rank's own decrements
         CtrlView cv{};
         cv.mode = MODE_PROCESS; cv.level = L; cv.round = round; cv.cur_sel = own_q;
-        k_shard_mark<P><<<grid_of(total), kBlock, 0, s>>>(p, d_xbuf, (uint32_t)total, cv, Q.light[own_q], Q.heavy[own_q], d_words);
+        k_shard_mark<P><<<sweep_grid(total, 4), kBlock, 0, s>>>(p, d_xbuf, (uint32_t)total, cv, Q.light[own_q], Q.heavy[own_q], d_words);
         ++launch;
         k_shard_setup<<<1, 64, 0, s>>>(d_ctrl, d_words, L, round, own_q, launch);
         launch_step(launch);

@@ -94,11 +94,25 @@ def c3_main():
         eu, ev, tr, sup = a.truss_fetch(with_support=True)
         assert int(sup.sum(dtype=np.int64)) == 3 * 88_336_441
         assert hashlib.sha256(tr.tobytes()).hexdigest()[:16] == "5970a467914854ea", "sharded C3 trussness differs from the known answer"
+        # SURVEY 8(e)'s partition at the same size: supports owned by edge range, the frontier exchanged every sub-round
+        # (komb_set_shard_peel), and the k-core with live degrees owned by vertex range -- every value, on every rank
+        kd.truss_run_sharded(a, shard_peel=True)
+        st = a.stats()
+        assert st["shard_exchanges"] > 0 and st["exchange_words"] > a.ne // 2, st["shard_exchanges"]
+        eu2, ev2, tr2, sup2 = a.truss_fetch(with_support=True)
+        assert np.array_equal(eu, eu2) and np.array_equal(ev, ev2) and np.array_equal(tr, tr2) and np.array_equal(sup, sup2), "sharded-peel C3 trussness differs"
+        a.set_shard_peel(False)
+        kd.core_run_sharded(a)
+        assert a.stats()["shard_exchanges"] > 0
+        deg_s, core_s = a.core_fetch()
+        assert hashlib.sha256(core_s.tobytes()).hexdigest()[:16] == "120d47bf172d8b8f", "sharded C3 coreness differs from the known answer"
         dist.barrier()
         if rank == 0:
             a.truss_run()
             eu1, ev1, tr1, sup1 = a.truss_fetch(with_support=True)
             assert np.array_equal(eu, eu1) and np.array_equal(ev, ev1) and np.array_equal(tr, tr1) and np.array_equal(sup, sup1)
+            deg1, core1 = a.run_core()
+            assert np.array_equal(core1, core_s) and np.array_equal(deg1, deg_s)
     dist.barrier()
     if rank == 0:
         print("DIST_OK c3", world)
