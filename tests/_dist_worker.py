@@ -3,9 +3,15 @@
 mode "cpu": gloo on CPU tensors -- each rank counts the triangle supports of its
 own source-vertex shard with a pure-Python restatement of the sharded kernel's
 role counting, the partial vectors are summed with komb_amd.distributed's
-all-reduce, and the sum must equal the single-rank count and the oracle.
+all-reduce, and the sum must equal the single-rank count and the oracle; then the
+sharded PEELS' protocol (komb_amd/csrc/shard_dev.h: live keys owned by range,
+owner-computes decrements, the frontier concatenated every sub-round by an
+all-reduce over disjoint segments) restated in Python for k-core and k-truss,
+against the oracle on every rank.
 mode "gpu": the real komb_truss_run_sharded on the GPU box (ranks share GPU 0,
 gloo backend, all-reduce staged through the host), checked against the oracle.
+mode "peel": komb_core_run_sharded and komb_truss_run_sharded + komb_set_shard_peel
+on the GPU box, 2 or 3 ranks.  mode "c3": all of it at full C3 size.
 """
 import os
 import sys
@@ -50,6 +56,102 @@ def partial_support(orow, rows, v_lo, v_hi):
                     own[orow[a] + pos_a[w]] += 1
                     other[orow[b] + jw] += 1
     return own + other                                   # what the library sums before the exchange
+
+
+def concat_by_allreduce(own, world, rank):
+    """The exchange of komb_amd/csrc/shard_dev.h, restated on CPU tensors: first the ranks' counts (each rank fills its own
+    slot of a zeroed header), then the ids (each rank fills its own segment of a zeroed buffer); a SUM all-reduce of
+    disjoint segments is the concatenation.  Returns the concatenated list (rank order)."""
+    hdr = torch.zeros(world, dtype=torch.int32)
+    hdr[rank] = len(own)
+    kd.allreduce_sum_(hdr)
+    counts = hdr.tolist()
+    total, off = sum(counts), sum(counts[:rank])
+    buf = torch.zeros(total, dtype=torch.int32)
+    if len(own):
+        buf[off:off + len(own)] = torch.tensor(own, dtype=torch.int32)
+    if total:
+        kd.allreduce_sum_(buf)
+    return buf.tolist()
+
+
+def sharded_core_python(rowptr, col, rank, world):
+    """k-core with the live degrees owned by vertex range: every rank walks every frontier vertex's row and applies the
+    decrements on the vertices it owns (ShardCore in kcore.hip), the frontier concatenated every sub-round."""
+    nv = len(rowptr) - 1
+    lo, hi = nv * rank // world, nv * (rank + 1) // world
+    deg = np.diff(rowptr).astype(np.int64)
+    core = np.full(nv, -1, dtype=np.int64)
+    core[deg == 0] = 0
+    remaining = int((deg > 0).sum())
+    level = 0
+    while remaining:
+        own = [v for v in range(lo, hi) if core[v] < 0 and deg[v] <= level]
+        while True:
+            front = concat_by_allreduce(own, world, rank)
+            if not front:
+                break
+            for v in front:
+                core[v] = level                               # every rank stamps the whole frontier
+            own = []
+            for v in front:
+                for u in col[rowptr[v]:rowptr[v + 1]]:
+                    if lo <= u < hi and core[u] < 0:          # the owner's decrement
+                        deg[u] -= 1
+                        if deg[u] == level:
+                            core[u] = level; own.append(int(u))
+            remaining -= len(front)
+        level += 1
+    return core
+
+
+def sharded_truss_python(orow, rows, rank, world):
+    """k-truss peel with the supports owned by edge range (ShardTruss in ktruss.hip): internal edge id = oriented slot;
+    every rank walks every frontier edge's triangles, decides from the replicated stamps (an edge of the triangle gone
+    in an earlier sub-round: skip; one in the same sub-round: the smaller id keeps the triangle) and applies the
+    decrements on the edges it owns.  Returns (support, trussness) by internal id."""
+    nv = len(rows)
+    m = int(orow[-1])
+    inc = [[] for _ in range(m)]
+    for a in range(nv):
+        pos_a = {w: i for i, w in enumerate(rows[a])}
+        for ib, b in enumerate(rows[a]):
+            for jw, w in enumerate(rows[b]):
+                if w in pos_a:
+                    e, i, j = int(orow[a]) + ib, int(orow[a]) + pos_a[w], int(orow[b]) + jw
+                    inc[e].append((i, j)); inc[i].append((e, j)); inc[j].append((e, i))
+    sup0 = np.array([len(x) for x in inc], dtype=np.int64)
+    sup = sup0.copy()
+    lo, hi = m * rank // world, m * (rank + 1) // world
+    ALIVE = 1 << 40
+    stamp = np.full(m, ALIVE, dtype=np.int64)
+    truss = np.full(m, 2, dtype=np.int64)
+    stamp[sup == 0] = 0
+    remaining = int((sup > 0).sum())
+    level, rnd = 1, 1
+    while remaining:
+        own = [e for e in range(lo, hi) if stamp[e] == ALIVE and sup[e] <= level]
+        while True:
+            front = concat_by_allreduce(own, world, rank)
+            if not front:
+                break
+            for e in front:
+                stamp[e] = rnd; truss[e] = level + 2
+            own = []
+            for e in front:
+                for x, y in inc[e]:
+                    if stamp[x] < rnd or stamp[y] < rnd:
+                        continue
+                    xin, yin = stamp[x] == rnd, stamp[y] == rnd
+                    for t, tin, oin, other in ((x, xin, yin, y), (y, yin, xin, x)):
+                        if not tin and (not oin or e < other) and lo <= t < hi:
+                            sup[t] -= 1
+                            if sup[t] == level:
+                                stamp[t] = rnd + 1; truss[t] = level + 2; own.append(t)
+            remaining -= len(front)
+            rnd += 1
+        level += 1
+    return sup0, truss
 
 
 def rccl_main():
@@ -223,6 +325,15 @@ def main():
         # shards tile the task range exactly
         spans = [kd.shard_range(n_tasks, r, world) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == n_tasks and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        # the sharded PEELS' protocol (shard_dev.h), restated: owner-computes decrements + the frontier concatenated through
+        # the all-reduce helper every sub-round; coreness and trussness must equal the oracle's on every rank
+        assert np.array_equal(sharded_core_python(rowptr, col, rank, world), O.coreness(rowptr, col)), "sharded k-core protocol"
+        psup, ptr_ = sharded_truss_python(orow, rows, rank, world)
+        # internal ids -> canonical order: edge (a, b) with a < b, sorted by (a, b)
+        ends = [(min(a, b), max(a, b)) for a in range(nv) for b in rows[a]]
+        order = sorted(range(m), key=lambda e: ends[e])
+        assert np.array_equal(psup[order], osup), "sharded k-truss protocol: supports"
+        assert np.array_equal(ptr_[order], O.trussness(rowptr, col)), "sharded k-truss protocol: trussness"
     else:
         with komb_amd.KombAccel(device=0) as a:
             a.from_edges(nv, uv)

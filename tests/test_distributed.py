@@ -1,5 +1,7 @@
 """N>1 path: world_size-2 runs (gloo).  CPU: shard arithmetic + all-reduce of the
-support vectors against a Python restatement of the sharded role counting.
+support vectors against a Python restatement of the sharded role counting, and the sharded
+peels' exchange protocol (owner-computes decrements, frontier concatenated by all-reduce)
+restated in Python against the oracle.
 GPU box: the real komb_truss_run_sharded with two ranks sharing GPU 0."""
 import os
 import subprocess
