@@ -1,0 +1,275 @@
+// truss_index.h -- step 2b of the k-truss path (ktruss.hip): the incidence index built from the enumeration's record stream
+// (DESIGN.md section 4.2a): records sorted by bin, one workgroup per bin counts (k_bin_count) and finishes (k_bin_finish)
+// its 2048 consecutive edges out of LDS -- supports, slice offsets, the index window, the peel's initial state and the
+// first level's frontier.  Included by ktruss.hip only, after truss_tri.h.
+#pragma once
+
+#include "peel_dev.h"
+
+namespace komb {
+
+namespace {
+
+// ---- the record stream of the single pass (k_triangles, STREAM): destination-binned build of the index
+// The records are radix-sorted by the key bits above kBinBits only: records of one BIN -- 2^kBinBits consecutive edge
+// ids -- become contiguous, in no particular order inside the bin.  One workgroup then finishes a bin out of LDS: a
+// histogram of the bin's keys gives every edge its record count (k_bin_count); after the scan of the supports, per-edge
+// write cursors in LDS place every record value in its edge's slice (k_bin_fill) -- LDS atomics and stores inside one
+// ~100 KB window of the index, instead of one global atomic and one scattered HBM line per triangle.
+constexpr int kBinBits = 11;
+constexpr uint32_t kBinEdges = 1u << kBinBits;
+
+// boff[b] = first sorted record whose bin is >= b, for b = 0 .. nb (the sentinel keys lie above every bin).  One thread
+// per bin, binary search: 25 k threads x 27 probes, no pass over the keys.
+__global__ __launch_bounds__(kBlock) void k_bin_offsets(const uint32_t *__restrict__ key, int64_t n, int64_t nb, uint32_t *__restrict__ boff)
+{
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b <= nb; b += (int64_t)gridDim.x * kBlock) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)(key[mid] >> kBinBits) < b) lo = mid + 1; else hi = mid;
+        }
+        boff[b] = (uint32_t)lo;
+    }
+}
+
+// sum over the vertices of d+(a) (d+(a) - 1): bound on the own-role entries (every edge a->x closes at most d+(a) - 1
+// triangles with the other out-neighbours of a); half of it bounds the triangles
+__global__ __launch_bounds__(kBlock) void k_own_bound(const uint32_t *__restrict__ orow, int64_t nv, unsigned long long *__restrict__ total)
+{
+    unsigned long long t = 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long d = orow[v + 1] - orow[v];
+        t += d ? d * (d - 1ull) : 0ull;
+    }
+    block_add_u64(t, total);
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_mismatch(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int64_t n,
+                                                           unsigned long long *__restrict__ bad)
+{
+    unsigned long long t = 0;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) t += a[e] != b[e] ? 1ull : 0ull;
+    block_add_u64(t, bad);
+}
+
+// supports of a bin's edges: dense own-role entries + records of the bin with that key (LDS histogram); per-bin totals
+// (their scan gives every bin its window of the index) and the 64-bit grand total on the side.
+__global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict__ key, const uint32_t *__restrict__ boff, int64_t nb,
+                                                      const uint32_t *__restrict__ own, int64_t m, uint32_t *__restrict__ sum,
+                                                      uint32_t *__restrict__ bin_total, unsigned long long *__restrict__ total,
+                                                      int32_t *__restrict__ min_pos)
+{
+    // min_pos: the smallest positive support = the peel's first level (k_bin_finish queues its frontier)
+    __shared__ uint32_t sh_cnt[kBinEdges];
+    __shared__ uint32_t sh_part[kBlock / kWave];
+    unsigned long long t = 0;
+    int32_t lmin = 0x7FFFFFFF;
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int64_t x0 = b << kBinBits;
+        const uint32_t nx = (uint32_t)min((int64_t)kBinEdges, m - x0);
+        for (uint32_t i = threadIdx.x; i < kBinEdges; i += kBlock) sh_cnt[i] = 0u;
+        __syncthreads();
+        const uint32_t r0 = boff[b], r1 = boff[b + 1];
+        for (uint32_t r = r0 + threadIdx.x; r < r1; r += kBlock) atomicAdd(&sh_cnt[key[r] - (uint32_t)x0], 1u);
+        __syncthreads();
+        uint32_t tb = 0;
+        for (uint32_t i = threadIdx.x; i < nx; i += kBlock) {
+            const uint32_t c = own[x0 + i] + sh_cnt[i];
+            sum[x0 + i] = c;
+            tb += c;
+            if (c) lmin = min(lmin, (int32_t)c);
+        }
+        tb = wave_sum(tb);
+        if (lane_id() == 0) sh_part[threadIdx.x >> 6] = tb;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t all = 0;
+            for (int i = 0; i < kBlock / kWave; ++i) all += sh_part[i];
+            bin_total[b] = all;                                  // (a bin holds 2048 edges: their supports sum to far less than 2^32 ... unless the graph is beyond the index limit, which the 64-bit total reports)
+            t += all;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sum[m] = 0u; bin_total[nb] = 0u; }
+    if (threadIdx.x == 0 && t) atomicAdd(total, t);
+    lmin = wave_min(lmin);
+    if (lane_id() == 0 && lmin != 0x7FFFFFFF) atomicMin(min_pos, lmin);
+}
+
+// Dense index of a bin's edges.  An edge's slice is [its records' values | its own-role entries]; the slices of a
+// bin's 2^kBinBits consecutive edges are one contiguous WINDOW of the index (~40 KB).  One workgroup per bin assembles
+// the window in LDS -- every record takes its position from a per-edge cursor (LDS atomic), the own-role entries are
+// copied out of the tasks' dense blocks -- and then writes it as one coalesced stream: no global atomic, no scattered
+// store, every line of the index written whole, once.  A window that does not fit the LDS buffer (hub edges) is written
+// in place instead.  All loads of a phase are issued before the first is used: two workgroups per CU, and the kernel
+// lives on memory-level parallelism.
+constexpr int kFinBlock = 512;
+constexpr uint32_t kWinCap = 7168;                 // entries of the LDS window (56 KB; with the two 8 KB tables: 2 workgroups per CU)
+constexpr int kFinE = (int)(kBinEdges / kFinBlock);          // consecutive edges per thread
+constexpr int kFinU = 4;                           // records per thread per trip
+static_assert(kFinE == 4, "a thread loads its edges' supports and own-role counts as one 16-byte vector each");
+// The kernel also does what followed the index build: the slice offsets off[] (a workgroup scan of the bin's supports on
+// top of the bin's base -- the 100 M-element device scan is gone) and the peel's initial state (support, alive marker or
+// "gone" for a triangle-free edge, the count of those and the smallest positive support for the first level).
+__global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__restrict__ key, const int2 *__restrict__ val,
+                                                         const uint32_t *__restrict__ boff, int64_t nb,
+                                                         const uint32_t *__restrict__ own, const uint32_t *__restrict__ cnt,
+                                                         const uint32_t *__restrict__ bin_base,
+                                                         const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
+                                                         int2 *__restrict__ dense, int64_t m,
+                                                         uint32_t *__restrict__ off, int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
+                                                         int32_t *__restrict__ truss, uint32_t *__restrict__ init, int32_t *__restrict__ light0)
+{
+    // init[0] += triangle-free edges; init[1] = the smallest positive support (from k_bin_count) = the peel's first level L1.
+    // The edges with support L1 ARE that level's first frontier (nothing has been decremented yet): they are stamped with
+    // round 1 / trussness L1 + 2 and appended to light queue 0 here (one reservation per bin on init[2]), so the peel starts
+    // with a PROCESS step instead of a dense SCAN of every edge (0.55 ms at C3).  Only when they are light units (L1 <= kLight).
+    __shared__ uint32_t sh_off[kBinEdges + 4];     // slice offsets relative to the window
+    __shared__ uint32_t sh_cur[kBinEdges];
+    __shared__ uint32_t sh_wsum[kFinBlock / kWave];
+    __shared__ int2 sh_win[kWinCap];
+    __shared__ uint32_t sh_hsum[kFinBlock / kWave];
+    __shared__ uint32_t sh_qbase;
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    uint32_t zeros = 0;
+    const int32_t L1 = (int32_t)init[1];
+    const bool queue_first = light0 != nullptr && L1 <= kLight;
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int64_t x0 = b << kBinBits;
+        const uint32_t nx = (uint32_t)min((int64_t)kBinEdges, m - x0);
+        const uint64_t r0 = boff[b], r1 = boff[b + 1];
+        const uint32_t base = bin_base[b];
+        // ---- the thread's 4 consecutive edges: supports and own-role counts, then (for the edges that have some) where their blocks are
+        const uint32_t i0 = threadIdx.x * (uint32_t)kFinE;
+        uint32_t c[kFinE], ow[kFinE];
+        unsigned long long oo[kFinE];
+        if (i0 + kFinE <= nx) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(cnt + x0 + i0);
+            const uint4 q = *reinterpret_cast<const uint4 *>(own + x0 + i0);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+            ow[0] = q.x; ow[1] = q.y; ow[2] = q.z; ow[3] = q.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) { const bool in = i0 + (uint32_t)u < nx; c[u] = in ? cnt[x0 + i0 + u] : 0u; ow[u] = in ? own[x0 + i0 + u] : 0u; }
+        }
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u) oo[u] = ow[u] ? ownoff[x0 + i0 + u] : 0ull;
+        // slice offsets: exclusive scan of the supports over the workgroup
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        const uint32_t incl = wave_incl_scan(mine);
+        uint32_t hits = 0;
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u) hits += (queue_first && (int32_t)c[u] == L1) ? 1u : 0u;
+        const uint32_t hincl = wave_incl_scan(hits);
+        if (lane == kWave - 1) { sh_wsum[w] = incl; sh_hsum[w] = hincl; }
+        __syncthreads();
+        uint32_t before = 0, hbefore = 0, hall = 0;
+#pragma unroll
+        for (int i = 0; i < kFinBlock / kWave; ++i) { before += i < w ? sh_wsum[i] : 0u; hbefore += i < w ? sh_hsum[i] : 0u; hall += sh_hsum[i]; }
+        if (threadIdx.x == 0 && hall) sh_qbase = atomicAdd(&init[2], hall);
+        uint32_t o[kFinE + 1];                                      // relative to the window
+        o[0] = before + incl - mine;
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u) o[u + 1] = o[u] + c[u];
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u)
+            if (i0 + (uint32_t)u < nx) { sh_off[i0 + u] = o[u]; sh_cur[i0 + u] = o[u]; }
+        if (threadIdx.x == kFinBlock - 1) sh_off[kBinEdges] = o[kFinE];      // the bin's total (edges beyond nx count 0)
+        // ... written out, with the peel's initial state
+        if (i0 + kFinE <= nx) {
+            *reinterpret_cast<uint4 *>(off + x0 + i0) = make_uint4(base + o[0], base + o[1], base + o[2], base + o[3]);
+            int4 sv, mv, tv;
+            int32_t *svp = &sv.x, *mvp = &mv.x, *tvp = &tv.x;
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) {
+                const bool first = queue_first && (int32_t)c[u] == L1;
+                svp[u] = (int32_t)c[u];
+                mvp[u] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);   // round 1: the first frontier; round 0: gone before the first sub-round
+                tvp[u] = first ? L1 + 2 : 2;
+                if (!c[u]) ++zeros;
+            }
+            *reinterpret_cast<int4 *>(sup + x0 + i0) = sv;
+            *reinterpret_cast<int4 *>(stamp + x0 + i0) = mv;
+            *reinterpret_cast<int4 *>(truss + x0 + i0) = tv;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (i0 + (uint32_t)u < nx) {
+                const int64_t e = x0 + i0 + u;
+                const bool first = queue_first && (int32_t)c[u] == L1;
+                off[e] = base + o[u];
+                sup[e] = (int32_t)c[u];
+                stamp[e] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);
+                truss[e] = first ? L1 + 2 : 2;
+                if (!c[u]) ++zeros;
+            }
+        }
+        __syncthreads();
+        if (hall) {                                                 // the bin's part of the first frontier, in edge order
+            uint32_t q = sh_qbase + hbefore + hincl - hits;
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (queue_first && (int32_t)c[u] == L1 && i0 + (uint32_t)u < nx) light0[q++] = (int32_t)(x0 + i0 + u);
+        }
+        const uint32_t W = sh_off[kBinEdges];
+        if (b == nb - 1 && threadIdx.x == 0) off[m] = base + W;
+        const bool inwin = W <= kWinCap;                            // (workgroup-uniform)
+        // ---- records
+        for (uint64_t r = r0 + threadIdx.x; r < r1; r += (uint64_t)kFinBlock * kFinU) {
+            uint32_t k[kFinU];
+            int2 v[kFinU];
+#pragma unroll
+            for (int u = 0; u < kFinU; ++u) {
+                const uint64_t rr = r + (uint64_t)u * kFinBlock;
+                if (rr < r1) { k[u] = key[rr]; v[u] = val[rr]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kFinU; ++u) {
+                const uint64_t rr = r + (uint64_t)u * kFinBlock;
+                if (rr < r1) {
+                    const uint32_t p = atomicAdd(&sh_cur[k[u] - (uint32_t)x0], 1u);
+                    if (inwin) sh_win[p] = v[u]; else dense[base + p] = v[u];
+                }
+            }
+        }
+        // ---- own-role entries of the thread's edges: they end the edges' slices; the 4 edges' copies advance together
+        uint32_t most = 0;
+#pragma unroll
+        for (int u = 0; u < kFinE; ++u) most = max(most, ow[u]);
+        for (uint32_t kk = 0; kk < most; ++kk) {
+            int2 t[kFinE];
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) t[u] = own_dense[oo[u] + kk];
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) {
+                const uint32_t p = o[u + 1] - ow[u] + kk;
+                if (inwin) sh_win[p] = t[u]; else dense[base + p] = t[u];
+            }
+        }
+        __syncthreads();
+        // ---- the window, as a stream
+        if (inwin) for (uint32_t j = threadIdx.x; j < W; j += kFinBlock) dense[base + j] = sh_win[j];
+        __syncthreads();
+    }
+    block_add_min(zeros, 0x7FFFFFFF, &init[0], (int32_t *)&init[1]);
+}
+
+// peel state from the slice lengths.  Triangle-free edges are peeled here (trussness 2); init[0]
+// counts them and init[1] receives the smallest positive support = the first populated level.
+__global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t *__restrict__ off,
+                                                      int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
+                                                      int32_t *__restrict__ truss, uint32_t *__restrict__ init)
+{
+    uint32_t zeros = 0;
+    int32_t lmin = 0x7FFFFFFF;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
+        const int32_t s0 = (int32_t)(off[e + 1] - off[e]);
+        sup[e] = s0;
+        if (s0 == 0) { stamp[e] = 0; truss[e] = 2; ++zeros; }       // round 0: gone before the first sub-round
+        else { stamp[e] = alive_marker((uint32_t)s0); lmin = min(lmin, s0); }
+    }
+    block_add_min(zeros, lmin, &init[0], (int32_t *)&init[1]);
+}
+
+} // namespace
+
+} // namespace komb

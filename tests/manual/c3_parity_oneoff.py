@@ -10,6 +10,13 @@ import numpy as np
 import komb_amd
 from oracle import oracle as O
 
+import threading
+def _heartbeat(t0=time.time()):                      # a line a minute: the single-thread oracle passes are silent for longer than that
+    while True:
+        time.sleep(60)
+        print(f"  ... {time.time() - t0:.0f} s", flush=True)
+threading.Thread(target=_heartbeat, daemon=True).start()
+
 nv, ncl, alpha, threads = 10_000_000, 24_250_000, 2.6, 1
 if len(sys.argv) > 3:
     nv, ncl, alpha = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])

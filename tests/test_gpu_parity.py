@@ -192,6 +192,37 @@ def _oracle_trussness_fast(O, rowptr, col):
     return O.trussness(rowptr, col)
 
 
+def test_two_contexts_in_two_threads(K, O):
+    """Reentrancy: two contexts of one process, each driven by its own thread at the same time (ctypes drops the GIL inside
+    the calls), different graphs; every run of both must equal the oracle.  A context owns its stream, pool, pinned staging
+    and control blocks; nothing in the library is process-global."""
+    import threading
+    graphs = [(50000, K.gen_hug_edges(50000, 130000, 2.4, 5)), (30000, K.gen_hug_edges(30000, 90000, 2.2, 8))]
+    want = []
+    for nv, uv in graphs:
+        rowptr, col = O.simplify(nv, uv)
+        want.append((O.coreness(rowptr, col), O.support(rowptr, col)[0], O.trussness(rowptr, col)))
+    errors = []
+
+    def work(i):
+        try:
+            nv, uv = graphs[i]
+            with K.KombAccel() as a:
+                a.from_edges(nv, uv)
+                for _ in range(6):
+                    deg, core = a.run_core()
+                    eu, ev, tr, sup = a.run_truss(with_support=True)
+                    if not (np.array_equal(core, want[i][0]) and np.array_equal(sup, want[i][1]) and np.array_equal(tr, want[i][2])):
+                        errors.append(f"thread {i}: result differs from the oracle")
+        except Exception as exc:  # noqa: BLE001
+            errors.append(f"thread {i}: {exc!r}")
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors
+
+
 def test_full_size_c2_properties(K, O):
     """BASELINE config C2 (|V|=1M, |E|~10M): k-core, supports and EVERY trussness value against the oracle,
     plus the size-independent properties."""
