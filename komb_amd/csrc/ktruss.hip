@@ -69,16 +69,12 @@ struct TrussProblem {
     const uint32_t *off;
     const int2 *inc;
     int32_t *sup;
-    int32_t *stamp;
-    int32_t *truss;
+    int32_t *stamp;                      // alive marker, then the sub-round the edge was peeled in: its trussness is
+                                         // rlevel[stamp] + 2 (PeelQueues::rlevel, written once per sub-round) -- no result store per edge
 
     __device__ __forceinline__ const int32_t *scan_marker() const { return stamp; }
     __device__ __forceinline__ const int32_t *scan_key() const { return sup; }
-    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const
-    {
-        stamp[e] = cv.round;
-        truss[e] = cv.level + 2;
-    }
+    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const { stamp[e] = cv.round; }
     __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
     {
         b = off[e];
@@ -100,8 +96,8 @@ struct TrussProblem {
         const bool xin = (ld.sx == r), yin = (ld.sy == r);
         const bool decx = !xin && (!yin || ld.me < ld.y);
         const bool decy = !yin && (!xin || ld.me < ld.x);
-        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; truss[ld.x] = L + 2; t0 = ld.x; c0 = marker_chunks(ld.sx); }
-        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; truss[ld.y] = L + 2; t1 = ld.y; c1 = marker_chunks(ld.sy); }
+        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; t0 = ld.x; c0 = marker_chunks(ld.sx); }
+        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; t1 = ld.y; c1 = marker_chunks(ld.sy); }
     }
 };
 
@@ -117,16 +113,11 @@ struct ShardTruss {
     const int2 *inc;
     int32_t *sup;
     int32_t *stamp;
-    int32_t *truss;
     uint32_t lo, hi;                     // internal edge ids this rank owns
 
     __device__ __forceinline__ const int32_t *scan_marker() const { return stamp; }
     __device__ __forceinline__ const int32_t *scan_key() const { return sup; }
-    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const
-    {
-        stamp[e] = cv.round;
-        truss[e] = cv.level + 2;
-    }
+    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const { stamp[e] = cv.round; }
     __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
     {
         b = off[e];
@@ -150,8 +141,8 @@ struct ShardTruss {
         const bool decx = !xin && (!yin || ld.me < ld.y) && mine(ld.x);
         const bool decy = !yin && (!xin || ld.me < ld.x) && mine(ld.y);
         // (triggered edges are reported as light units: the next frontier is re-classified after the exchange)
-        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; truss[ld.x] = L + 2; t0 = ld.x; }
-        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; truss[ld.y] = L + 2; t1 = ld.y; }
+        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; t0 = ld.x; }
+        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; t1 = ld.y; }
     }
 };
 
@@ -626,7 +617,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
         ctx->timer.start(s);
         k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, n_bins, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
-                                                                      d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff, d_light0);
+                                                                      d_off, d_sup, d_stamp, d_grp + kInitOff, d_light0);
         st.ms_compact += ctx->timer.stop(s);
         peel_inited = true;
         bufs.release(d_toff); bufs.release(d_bintot); bufs.release((void *)d_recval); bufs.release(d_reckey);
@@ -680,7 +671,12 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&Q.code, (size_t)m));
-    TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss};
+    // rlevel[r] = the level sub-round r peeled at (one store per PROCESS step, by its finaliser): with the sub-round stamps the
+    // peel writes anyway, that IS every peeled edge's trussness -- no result store per edge (0.6 ms of scattered 4-byte stores
+    // at C3).  A sub-round peels at least one edge: m + 2 entries; [0] = level 0 (the triangle-free edges' stamp).
+    KOMB_HIP(ctx, bufs.alloc(&Q.rlevel, (size_t)m + 2));
+    KOMB_HIP(ctx, hipMemsetAsync(Q.rlevel, 0, 2 * sizeof(int32_t), s));
+    TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp};
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
@@ -746,7 +742,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), local_item_limit(kTrussLocalItems), local_density_limit(kTrussLocalDensity), true, 2, d_truss,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 TrussCollect C{(uint32_t)m, d_off, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
-                k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);
+                PeelQueues Qc = Q;
+                Qc.rlevel = nullptr;                   // (the collect pass has sub-rounds of its own: they are nobody's trussness)
+                k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Qc, C, launch);
             },
             [&](const LocalGraph &lg, void *items, uint64_t total_items, LocalCtrl *d_lctrl, uint32_t *d_cnt, int *nl) -> int {
                 return local_fixpoint(ctx, d_lctrl, d_cnt, lg, TrussLocal{(const uint2 *)items}, total_items, nl);
@@ -770,7 +768,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     ctx->timer.start(s);
     if (!peel_inited) {
         peel_ctrl_pre(s, d_grp);
-        k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_truss, d_grp + kInitOff);
+        k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_grp + kInitOff);
     }
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
     int launches = 0, rc = KOMB_OK;
@@ -782,7 +780,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         // finish under the same rule as in the replicated peel, after one exchange of the live supports (shard_dev.h)
         uint32_t iw[2] = {0u, 0u};
         KOMB_HIP(ctx, d2h(ctx, iw, d_grp + kInitOff, sizeof(iw)));     // triangle-free edges; the smallest positive support
-        ShardTruss SP{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, d_truss, 0u, 0u};
+        ShardTruss SP{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, 0u, 0u};
         shard_bounds((uint64_t)m, rank, world, &SP.lo, &SP.hi);
         ShardStats ss;
         rc = shard_peel(ctx, bufs, SP, d_sup, (uint32_t)m, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
@@ -813,6 +811,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }, &batch);
         launches += batch;
     }
+    // the peeled edges' trussness from their sub-round stamps (one coalesced pass; see Q.rlevel above)
+    if (rc == KOMB_OK) k_truss_resolve<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, m);
     st.ms_peel = ctx->timer.stop(s);
     KOMB_TRY(rc);
 #ifdef KOMB_STEP_TIMERS
@@ -831,7 +831,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.max_trussness = ctx->h_ctrl[0].max_level + 2;
     for (int i = 0; i < 2; ++i) { bufs.release(Q.light[i]); bufs.release(Q.heavy[i]); bufs.release(Q.live[i]); }
     bufs.release(Q.code);
-    bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc);
+    bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc); bufs.release(Q.rlevel);
 
     // ---- canonical-order results with original vertex ids
     phase.next("truss: canonical gather");

@@ -129,6 +129,9 @@ struct PeelQueues {
     int2 *heavy[2];          // (unit id, chunk index)
     int32_t *live[2];        // compacted ids of the units still live (SCAN's input once it pays off)
     int scalar_scan;         // debug: dense sweeps without the 16-byte loads
+    int32_t *rlevel = nullptr;   // optional: rlevel[r] = the level sub-round r peeled at, written once per PROCESS step by its
+                                 // finaliser -- a problem whose result is "the level a unit was peeled at" then needs no
+                                 // result store per unit: the sub-round stamp it writes anyway says it (k-truss)
 };
 
 // ---------------------------------------------------------------- appenders
@@ -234,7 +237,8 @@ __device__ __forceinline__ uint32_t plan_step(const CtrlView &cv, uint32_t grid,
 // participating workgroup has arrived; the independent atomics are issued from different lanes
 // so they cost one round trip, not seven.  The new state is also left in *out (LDS) so that a
 // single workgroup can go on to the next step without re-reading global memory.
-__device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out, uint32_t acc, int32_t launch)
+__device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out, uint32_t acc, int32_t launch,
+                                              int32_t *rlevel)
 {
     const int lane = lane_id();
     // from here on the state belongs to the NEXT launch: late workgroups of this one must not act on it
@@ -256,6 +260,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
     const int32_t nmin = __shfl((int)v, 3);
     const uint32_t live_n = (uint32_t)__shfl((int)v, 4);
     if (lane != 0) return;
+    if (!scan && rlevel) rlevel[cv.round] = cv.level;       // the units stamped with this sub-round were peeled at this level
     int32_t mode = cv.mode, level = cv.level, round = cv.round, done = 0, nsel = sel;
     int32_t live_sel = cv.live_sel, live_mode = cv.live_mode;
     uint32_t live_count = cv.live_count;
@@ -669,11 +674,11 @@ __global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32
 #endif
         last = __shfl(last, 0);
         total = (uint32_t)__shfl((int)total, 0);
-        if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total, launch);
+        if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total, launch, Q.rlevel);
         return;
     }
     // one workgroup did the whole step: finalise locally, chain the next step if it is small too
-    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc, launch);
+    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc, launch, Q.rlevel);
     if (P::kSingleStep) return;                        // (shard_dev.h: the next frontier has to be exchanged first)
     __syncthreads();
     cv = sh_cv;

@@ -21,6 +21,19 @@ namespace {
 //     not-kept upper slot is the k-th entry of that sorted list, and k = c - (kept upper slots before j): a stream on
 //     both sides.  (Until round 3 this case binary-searched u in v's oriented row: 3.5 random lines per edge, 4.7 ms of
 //     a 31 ms step; the sort of the 50 M (target, oriented id) pairs and this pass take 2.x ms.)
+// Trussness after the peel: an edge the engine peeled carries the sub-round it went in (stamp), and rlevel[] says which level
+// that sub-round worked at (PeelQueues::rlevel; stamp 0 = triangle-free = level 0); an edge a finish took over (local fixed
+// point, LDS tail) still carries its alive marker and has its value in truss[] already.  One coalesced pass instead of a
+// scattered 4-byte result store per peeled edge inside the peel (0.6 ms there at C3, 0.15 ms here).
+__global__ __launch_bounds__(kBlock) void k_truss_resolve(const int32_t *__restrict__ stamp, const int32_t *__restrict__ rlevel,
+                                                         int32_t *__restrict__ truss, int64_t m)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
+        const int32_t s = stamp[e];
+        if (!marker_alive(s)) truss[e] = rlevel[s] + 2;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_popc_words(const unsigned long long *__restrict__ bits, int64_t nwords, uint32_t *__restrict__ cnt)
 {
     for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w <= nwords; w += (int64_t)gridDim.x * kBlock)

@@ -119,11 +119,11 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
                                                          const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
                                                          int2 *__restrict__ dense, int64_t m,
                                                          uint32_t *__restrict__ off, int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
-                                                         int32_t *__restrict__ truss, uint32_t *__restrict__ init, int32_t *__restrict__ light0)
+                                                         uint32_t *__restrict__ init, int32_t *__restrict__ light0)
 {
     // init[0] += triangle-free edges; init[1] = the smallest positive support (from k_bin_count) = the peel's first level L1.
     // The edges with support L1 ARE that level's first frontier (nothing has been decremented yet): they are stamped with
-    // round 1 / trussness L1 + 2 and appended to light queue 0 here (one reservation per bin on init[2]), so the peel starts
+    // round 1 (its level, hence their trussness, is recorded when that sub-round ends) and appended to light queue 0 here (one reservation per bin on init[2]), so the peel starts
     // with a PROCESS step instead of a dense SCAN of every edge (0.55 ms at C3).  Only when they are light units (L1 <= kLight).
     __shared__ uint32_t sh_off[kBinEdges + 4];     // slice offsets relative to the window
     __shared__ uint32_t sh_cur[kBinEdges];
@@ -179,19 +179,17 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
         // ... written out, with the peel's initial state
         if (i0 + kFinE <= nx) {
             *reinterpret_cast<uint4 *>(off + x0 + i0) = make_uint4(base + o[0], base + o[1], base + o[2], base + o[3]);
-            int4 sv, mv, tv;
-            int32_t *svp = &sv.x, *mvp = &mv.x, *tvp = &tv.x;
+            int4 sv, mv;
+            int32_t *svp = &sv.x, *mvp = &mv.x;
 #pragma unroll
             for (int u = 0; u < kFinE; ++u) {
                 const bool first = queue_first && (int32_t)c[u] == L1;
                 svp[u] = (int32_t)c[u];
-                mvp[u] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);   // round 1: the first frontier; round 0: gone before the first sub-round
-                tvp[u] = first ? L1 + 2 : 2;
+                mvp[u] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);   // round 1: the first frontier; round 0 (trussness 2): gone before the first sub-round
                 if (!c[u]) ++zeros;
             }
             *reinterpret_cast<int4 *>(sup + x0 + i0) = sv;
             *reinterpret_cast<int4 *>(stamp + x0 + i0) = mv;
-            *reinterpret_cast<int4 *>(truss + x0 + i0) = tv;
         } else {
 #pragma unroll
             for (int u = 0; u < kFinE; ++u) if (i0 + (uint32_t)u < nx) {
@@ -200,7 +198,6 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
                 off[e] = base + o[u];
                 sup[e] = (int32_t)c[u];
                 stamp[e] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);
-                truss[e] = first ? L1 + 2 : 2;
                 if (!c[u]) ++zeros;
             }
         }
@@ -253,18 +250,18 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
     block_add_min(zeros, 0x7FFFFFFF, &init[0], (int32_t *)&init[1]);
 }
 
-// peel state from the slice lengths.  Triangle-free edges are peeled here (trussness 2); init[0]
+// peel state from the slice lengths.  Triangle-free edges are peeled here (stamp 0 = sub-round 0 = trussness 2); init[0]
 // counts them and init[1] receives the smallest positive support = the first populated level.
 __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t *__restrict__ off,
                                                       int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
-                                                      int32_t *__restrict__ truss, uint32_t *__restrict__ init)
+                                                      uint32_t *__restrict__ init)
 {
     uint32_t zeros = 0;
     int32_t lmin = 0x7FFFFFFF;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
         const int32_t s0 = (int32_t)(off[e + 1] - off[e]);
         sup[e] = s0;
-        if (s0 == 0) { stamp[e] = 0; truss[e] = 2; ++zeros; }       // round 0: gone before the first sub-round
+        if (s0 == 0) { stamp[e] = 0; ++zeros; }                     // round 0 (level 0, trussness 2): gone before the first sub-round
         else { stamp[e] = alive_marker((uint32_t)s0); lmin = min(lmin, s0); }
     }
     block_add_min(zeros, lmin, &init[0], (int32_t *)&init[1]);
