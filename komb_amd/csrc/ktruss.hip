@@ -324,7 +324,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     unsigned long long *d_mom = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_mom, 12));                           // [0..4] graph moments, [5] sum of supports, [6,7] capacity bounds, [8] sharded-check mismatches
     KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 12 * sizeof(unsigned long long), s));
-    KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s));
     st.ms_allreduce = 0.0;
 
     // Three layouts of the index build:
@@ -381,6 +380,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.ms_sort = 0.0; st.tri_records = 0; st.ms_compact = 0.0; st.ms_tri_count = 0.0; st.ms_tri_fill = 0.0;
     st.index_layout = layout;
     auto zero_counts = [&]() -> hipError_t { return hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s); };
+    // (the stream build on one GPU never touches the third-role counters: half the fill)
+    if (world == 1 && layout == IDX_STREAM) KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
+    else KOMB_HIP(ctx, zero_counts());
     bool have_counts = false;                  // d_cnt holds the supports (and d_mom[5] their sum)
     if (world > 1) {
         const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
