@@ -246,7 +246,7 @@ static int compact_slots(komb_ctx *ctx, DevBufs &bufs, const int32_t *src, const
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cc, d_cb, nchunks + 1));
     uint32_t kept = 0;
     KOMB_HIP(ctx, d2h(ctx, &kept, d_cb + nchunks, sizeof(uint32_t)));
-    KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept + 4));        // + 4: the triangle enumeration reads 16 bytes at a time
+    KOMB_HIP(ctx, bufs.alloc(out_col, (size_t)kept + 8));        // + 8: the triangle enumeration reads 16 bytes at a time, past the end of the last row
     KOMB_HIP(ctx, bufs.alloc(out_src, (size_t)kept));
     k_slot_filter<Pred, true><<<g, kBlock, 0, s>>>(src, col, ns, pred, nullptr, d_cb, *out_col, *out_src, d_bits, nullptr, nullptr);
     if ((int64_t)kept * 4 < nv) k_rowptr_search<<<grid_for(nv + 1), kBlock, 0, s>>>(*out_src, (int64_t)kept, nv, out_rowptr);

@@ -50,7 +50,11 @@ namespace {
 #endif
 constexpr int kTriV = KOMB_TRI_V;               // consecutive source vertices per task (<= 63: lane l holds orow[v0 + l])
 constexpr int kTriCap = KOMB_TRI_CAP;
-constexpr int kTriR = 4;                       // consecutive elements of one row N+(b) a lane probes per trip (one 16-byte load)
+#ifndef KOMB_TRI_R
+#define KOMB_TRI_R 4
+#endif
+constexpr int kTriR = KOMB_TRI_R;              // consecutive elements of one row N+(b) a lane probes per trip (16-byte loads; 4 or 8)
+static_assert(kTriR == 4 || kTriR == 8, "chunks are loaded as 16-byte vectors");
 struct __attribute__((packed, aligned(4))) Int4U { int32_t x, y, z, w; };      // 16 bytes at a 4-byte aligned address
 struct __attribute__((packed, aligned(4))) UInt2U { uint32_t x, y; };
 constexpr int kTriBuf = 128;                   // parked triangles per wave on the unstaged path (handled once >= 64 are waiting)
@@ -379,8 +383,13 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                     int32_t wv[kTriR];
                     if (live && !(ablate & 1)) {
                         // the rows are 4-byte aligned only; the array is padded so that the last chunk may read past its row
-                        const Int4U q = *reinterpret_cast<const Int4U *>(ocol + j0);
-                        wv[0] = q.x; wv[1] = q.y; wv[2] = q.z; wv[3] = q.w;
+#pragma unroll
+                        for (int k4 = 0; k4 < kTriR; k4 += 4) {
+                            if (k4 == 0 || (uint32_t)k4 < nin) {
+                                const Int4U q = *reinterpret_cast<const Int4U *>(ocol + j0 + k4);
+                                wv[k4] = q.x; wv[k4 + 1] = q.y; wv[k4 + 2] = q.z; wv[k4 + 3] = q.w;
+                            } else { wv[k4] = 0; wv[k4 + 1] = 0; wv[k4 + 2] = 0; wv[k4 + 3] = 0; }
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < kTriR; ++k) wv[k] = (int32_t)(j0 + (uint32_t)k);
