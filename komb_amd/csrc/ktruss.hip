@@ -305,8 +305,13 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
     unsigned long long *d_kubits = nullptr;                          // ... and is an upper slot (its row's id below its column's)
     uint32_t *d_urank = nullptr;                                     // upper slots per 64-slot word (the gather turns it into their prefix sum)
-    if (use_classes) KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrientClass{d_deg, d_deg8, d_deg2, dth[0], dth[1], dth[2]}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank));
-    else KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, &d_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank));
+    // the source row of every oriented slot (osrc) is needed by round 2's bounded slices, the LDS tail and the graph moments
+    // (first call on a graph, and subgraph runs) only: otherwise it is not written, and the oriented row pointers come from the keep bits
+    const bool need_osrc = (vmask_host != nullptr || !ctx->moments_valid) || finish_mode(FIN_LOCAL) == FIN_LDS ||
+                           (getenv("KOMB_INDEX") && !strcmp(getenv("KOMB_INDEX"), "slices"));
+    int32_t **p_osrc = need_osrc ? &d_osrc : nullptr;
+    if (use_classes) KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrientClass{d_deg, d_deg8, d_deg2, dth[0], dth[1], dth[2]}, d_orow, &d_ocol, p_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank, w_rowptr));
+    else KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, p_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank, w_rowptr));
     st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
 
