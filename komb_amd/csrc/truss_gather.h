@@ -24,7 +24,7 @@ namespace {
 // Trussness after the peel: an edge the engine peeled carries the sub-round it went in (stamp), and rlevel[] says which level
 // that sub-round worked at (PeelQueues::rlevel; stamp 0 = triangle-free = level 0); an edge a finish took over (local fixed
 // point, LDS tail) still carries its alive marker and has its value in truss[] already.  One coalesced pass instead of a
-// scattered 4-byte result store per peeled edge inside the peel (0.6 ms there at C3, 0.15 ms here).
+// scattered 4-byte result store per peeled edge inside the peel (0.6 ms there at C3, 0.25 ms here).
 __global__ __launch_bounds__(kBlock) void k_truss_resolve(const int32_t *__restrict__ stamp, const int32_t *__restrict__ rlevel,
                                                          int32_t *__restrict__ truss, int64_t m)
 {
