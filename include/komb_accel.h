@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KOMB_ACCEL_ABI_VERSION 4
+#define KOMB_ACCEL_ABI_VERSION 5
 
 typedef enum komb_status {
     KOMB_OK          =  0,
@@ -83,6 +83,9 @@ typedef struct komb_stats {
     int32_t shard_exchanges;        /* all-reduce callbacks made by the peel (two per sub-round + level changes) */
     double  ms_exchange;            /* host time inside them (stream drain + callback); part of ms_core / ms_peel */
     int64_t exchange_words;         /* 32-bit words they carried                                                 */
+    /* graph build (ABI version 5): host wall-clock parts of ms_build (which is now wall-clock too: upload + device work) */
+    double  ms_build_h2d;           /* staged host -> device copy of the raw pairs / the CSR                      */
+    double  ms_build_relabel;       /* (degree,id) renumbering, internal CSR, oriented half, canonical edge map   */
 } komb_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

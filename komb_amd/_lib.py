@@ -43,6 +43,7 @@ class KombStats(ctypes.Structure):
         ("ms_sort", ctypes.c_double), ("tri_records", ctypes.c_int64),
         ("index_layout", ctypes.c_int32), ("shard_exchanges", ctypes.c_int32),
         ("ms_exchange", ctypes.c_double), ("exchange_words", ctypes.c_int64),
+        ("ms_build_h2d", ctypes.c_double), ("ms_build_relabel", ctypes.c_double),
     ]
 
 

@@ -72,6 +72,7 @@ void komb_destroy(komb_ctx *ctx)
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->device);
         graph_free(ctx);
+        stager_free(ctx);
         ctx->pool.clear();
         ctx->timer.destroy();
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
@@ -110,10 +111,10 @@ int komb_graph_get_csr(komb_ctx *ctx, int64_t *rowptr, int32_t *col)
     if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_graph_get_csr: no graph loaded");
     if (!rowptr || (ctx->ne > 0 && !col)) KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_graph_get_csr: null output");
     std::vector<uint32_t> rp((size_t)ctx->nv + 1);
-    KOMB_HIP(ctx, hipMemcpy(rp.data(), ctx->d_rowptr, rp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    KOMB_HIP(ctx, hipMemcpy(rp.data(), ctx->d_o_rowptr, rp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < rp.size(); ++i) rowptr[i] = (int64_t)rp[i];
     if (ctx->ne > 0)
-        KOMB_HIP(ctx, hipMemcpy(col, ctx->d_col, (size_t)(2 * ctx->ne) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        KOMB_HIP(ctx, hipMemcpy(col, ctx->d_o_col, (size_t)(2 * ctx->ne) * sizeof(int32_t), hipMemcpyDeviceToHost));
     return KOMB_OK;
 }
 

@@ -232,17 +232,25 @@ struct komb_ctx {
     hipStream_t stream = nullptr;
     komb::Timer timer;
 
-    // ---- resident simple graph (symmetric CSR, rows ascending)
+    // ---- resident simple graph.  Two id spaces:
+    //   ORIGINAL ids -- what the caller passed and what every result is reported in;
+    //   INTERNAL ids -- rank of a vertex in (degree, original id) order, used by the k-truss path: its (degree,id)
+    //   orientation is then simply "lower id -> higher id", and comes with the graph (graph_build.hip).
     int64_t nv = -1, ne = 0;
-    uint32_t *d_rowptr = nullptr;            // [nv+1]
-    int32_t  *d_col = nullptr;               // [2*ne]
-    int32_t  *d_src = nullptr;               // [2*ne] row of every slot
+    uint32_t *d_o_rowptr = nullptr;          // [nv+1]  symmetric CSR, ORIGINAL ids, rows ascending (komb_graph_get_csr, merge.hip)
+    int32_t  *d_o_col = nullptr;             // [2*ne]
+    int32_t  *d_o2i = nullptr, *d_i2o = nullptr;   // [nv] original -> internal id and back
+    int32_t  *d_deg_i = nullptr;             // [nv] degree by INTERNAL id
+    uint32_t *d_orow = nullptr;              // [nv+1]  oriented CSR, INTERNAL ids, rows ascending (source below target): internal edge id = oriented slot
+    int32_t  *d_ocol = nullptr, *d_osrc = nullptr; // [ne (+8)] target / source of every oriented slot
+    int32_t  *d_ceu = nullptr, *d_cev = nullptr;   // [ne] canonical edge list: ORIGINAL ids, (min,max) lexicographic
+    uint32_t *d_canon2e = nullptr;           // [ne] internal edge id of every canonical edge
+    int64_t g_mom[5] = {0, 0, 0, 0, 0};      // graph moments of the whole graph (k_graph_moments), computed with the graph
 
     // ---- k-core results
-    int32_t *d_deg = nullptr;                // [nv] degree (a2)
-    int32_t *d_core = nullptr;               // [nv] coreness (a3)
+    int32_t *d_deg = nullptr;                // [nv] degree (a2), ORIGINAL ids
+    int32_t *d_core = nullptr;               // [nv] coreness (a3), ORIGINAL ids
     bool core_done = false;
-    bool moments_valid = false;              // komb_stats graph moments computed for the resident graph
 
     // ---- k-truss results (internal edge id = oriented slot)
     int64_t t_ne = -1;                       // edges of the (sub)graph last run
@@ -254,6 +262,7 @@ struct komb_ctx {
     komb::PeelCtrl *h_ctrl = nullptr;        // [2]
     komb::LocalCtrl *h_local = nullptr;      // [2]
     void *h_stage = nullptr;                 // pinned landing area of the small device-to-host reads (kStageBytes)
+    struct H2DStager *stager = nullptr;      // pinned staging buffers + streams of the graph upload (graph_build.hip), made on first use
 
     komb_stats stats{};
 };
@@ -271,6 +280,10 @@ struct DevBufs {
         hipError_t e = ctx->pool.get(&q, (count ? count : 1) * sizeof(T));
         if (e == hipSuccess) { owned.push_back(q); *out = (T *)q; }
         return e;
+    }
+    void detach(void *q)                             // the caller keeps q (a pool block it will put() back itself)
+    {
+        for (auto &p : owned) if (p == q) p = nullptr;
     }
     void release(void *q)
     {
@@ -335,6 +348,8 @@ int prim_sort_pairs_u32_u64(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, u
 int prim_select_reversed(komb_ctx *ctx, const int32_t *osrc, const int32_t *ocol, int64_t m, uint32_t *out, uint32_t *d_num);
 int prim_sort_pairs_u32_u32(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
                             int64_t n, int end_bit, uint32_t **sorted_keys, uint32_t **sorted_vals);
+int prim_sort_pairs_u64_u32(komb_ctx *ctx, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                            int64_t n, int end_bit, uint64_t **sorted_keys, uint32_t **sorted_vals);
 
 // ---- stages (each in its own translation unit)
 int core_run(komb_ctx *ctx, int rank = 0, int world = 1, komb_allreduce_fn fn = nullptr, void *user = nullptr, bool sharded = false);
@@ -344,6 +359,10 @@ int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t 
 int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv);
 int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);
 void graph_free(komb_ctx *ctx);
+void stager_free(komb_ctx *ctx);
+// sum d^2, sum min(d,d), max d, (unused), sum d+ + d+ of an oriented graph (ktruss.hip; the build calls it once per graph)
+int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *osrc, const int32_t *ocol, int64_t m,
+                  const uint32_t *orow, int64_t out[5]);
 void truss_free(komb_ctx *ctx);
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done);
 void peel_collect_ctrl(hipStream_t s, PeelCtrl *d_collect, const PeelCtrl *d_from);

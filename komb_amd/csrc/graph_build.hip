@@ -1,47 +1,152 @@
 // graph_build.hip -- row a1 of the hot-path table: the simple undirected graph
 // igraph_create + igraph_simplify(multiple=true, loops=true) would hold
 // (reference src/graph.cpp:418, src/graph.cpp:438), built on the device and
-// left resident in HBM as a symmetric CSR with ascending rows.
+// left resident in HBM.
 //
-// Layout: rowptr uint32[nv+1] (slot offsets; the design limit is 2^32-1 slots),
-// col int32[2*ne].  Both directions of every edge are materialised as 64-bit
-// keys (src<<32 | dst), radix-sorted and uniqued; col is the low word of the
-// surviving keys and rowptr the positions where the high word changes.
+// What stays resident (common.h, komb_ctx):
+//   * the symmetric CSR in ORIGINAL ids, rows ascending (komb_graph_get_csr; the canonical edge order of every result);
+//   * the ORIENTED graph of the k-truss path in INTERNAL ids = rank of a vertex in (degree, original id) order: every edge
+//     once, from its lower to its higher endpoint, as a CSR with ascending rows plus the source of every slot -- the
+//     internal edge id is the oriented slot.  In degree order the (degree,id) orientation is an id compare, so no run has
+//     to orient anything;
+//   * the canonical edge list (original ids, (min,max)-lexicographic) and, for every canonical edge, its internal edge id.
+//
+// How: both directions of every raw pair as 64-bit keys (src << vb | dst, vb = bits of a vertex id), radix-sorted on the
+// 2*vb significant bits and uniqued -> original CSR.  Vertices are radix-sorted (stably) by degree -> the renumbering.
+// Every canonical edge then emits its oriented internal slot as a (key, canonical id) record; one more radix sort puts the
+// records in oriented CSR order, and one pass splits them into targets, sources and the canonical -> internal map (the only
+// scattered store of the build: one 4-byte word per edge).  k-core keeps working on the original-id CSR (kcore.hip says why).
+//
+// The raw pairs arrive in pageable host memory (1.8 GB at |E| = 100M): they are staged through pinned buffers by a few
+// host threads (a single-threaded staging copy runs at 8-12 GB/s, a third of what the link takes).
 #include "common.h"
+
+#include <algorithm>
+#include <chrono>
+#include <thread>
+
+// ---------------------------------------------------------------- host -> device staging
+struct H2DStager {
+    static constexpr int kThreads = 8, kBufs = 2;
+    static constexpr size_t kChunk = 8u << 20;
+    void *pin[kThreads][kBufs] = {};
+    hipStream_t st[kThreads] = {};
+    hipEvent_t ev[kThreads][kBufs] = {};
+    bool ok = false;
+};
 
 namespace komb {
 
+void stager_free(komb_ctx *ctx)
+{
+    H2DStager *g = ctx->stager;
+    if (!g) return;
+    for (int t = 0; t < H2DStager::kThreads; ++t) {
+        for (int b = 0; b < H2DStager::kBufs; ++b) {
+            if (g->pin[t][b]) (void)hipHostFree(g->pin[t][b]);
+            if (g->ev[t][b]) (void)hipEventDestroy(g->ev[t][b]);
+        }
+        if (g->st[t]) (void)hipStreamDestroy(g->st[t]);
+    }
+    delete g;
+    ctx->stager = nullptr;
+}
+
 namespace {
 
-constexpr uint64_t kDropKey = ~0ull;          // loops / padding sort to the end
+H2DStager *stager_get(komb_ctx *ctx)
+{
+    if (ctx->stager) return ctx->stager->ok ? ctx->stager : nullptr;
+    H2DStager *g = new (std::nothrow) H2DStager();
+    if (!g) return nullptr;
+    ctx->stager = g;
+    bool ok = true;
+    for (int t = 0; t < H2DStager::kThreads && ok; ++t) {
+        ok = hipStreamCreate(&g->st[t]) == hipSuccess;
+        for (int b = 0; b < H2DStager::kBufs && ok; ++b)
+            ok = hipHostMalloc(&g->pin[t][b], H2DStager::kChunk, hipHostMallocDefault) == hipSuccess &&
+                 hipEventCreateWithFlags(&g->ev[t][b], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) (void)hipGetLastError();
+    g->ok = ok;
+    return ok ? g : nullptr;
+}
 
-__global__ __launch_bounds__(kBlock) void k_make_keys(const int64_t *__restrict__ uv, int64_t n_raw, int64_t nv,
+// blocking copy of pageable host memory to the device; complete on return
+hipError_t h2d_staged(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    H2DStager *g = bytes >= (64u << 20) ? stager_get(ctx) : nullptr;
+    if (!g) {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+    }
+    const size_t nchunks = (bytes + H2DStager::kChunk - 1) / H2DStager::kChunk;
+    hipError_t err[H2DStager::kThreads];
+    std::thread th[H2DStager::kThreads];
+    const int dev = ctx->device;
+    for (int t = 0; t < H2DStager::kThreads; ++t) {
+        err[t] = hipSuccess;
+        th[t] = std::thread([=, &err]() {
+            hipError_t e = hipSetDevice(dev);
+            size_t turn = 0;
+            for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += H2DStager::kThreads, ++turn) {
+                const int b = (int)(turn % H2DStager::kBufs);
+                if (turn >= (size_t)H2DStager::kBufs) e = hipEventSynchronize(g->ev[t][b]);      // the buffer's previous copy has left it
+                if (e != hipSuccess) break;
+                const size_t off = c * H2DStager::kChunk, len = std::min(H2DStager::kChunk, bytes - off);
+                memcpy(g->pin[t][b], (const char *)src + off, len);
+                e = hipMemcpyAsync((char *)dst + off, g->pin[t][b], len, hipMemcpyHostToDevice, g->st[t]);
+                if (e == hipSuccess) e = hipEventRecord(g->ev[t][b], g->st[t]);
+            }
+            const hipError_t e2 = hipStreamSynchronize(g->st[t]);
+            err[t] = e != hipSuccess ? e : e2;
+        });
+    }
+    hipError_t e = hipSuccess;
+    for (int t = 0; t < H2DStager::kThreads; ++t) { th[t].join(); if (err[t] != hipSuccess) e = err[t]; }
+    return e;
+}
+
+// ---------------------------------------------------------------- kernels
+inline int grid_for(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;
+    return (int)g;
+}
+
+// both directions of every raw pair as keys (src << vb | dst); loops and padding become the drop key (all ones in the
+// 2*vb sorted bits = the loop on vertex 2^vb - 1, which no valid key is), which sorts to the end
+__global__ __launch_bounds__(kBlock) void k_make_keys(const int64_t *__restrict__ uv, int64_t n_raw, int64_t nv, int vb,
                                                       uint64_t *__restrict__ keys, int *__restrict__ bad)
 {
+    const uint64_t drop = (1ull << (2 * vb)) - 1ull;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_raw; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t u = uv[2 * i], v = uv[2 * i + 1];
-        uint64_t k0 = kDropKey, k1 = kDropKey;
+        const longlong2 p = reinterpret_cast<const longlong2 *>(uv)[i];
+        const int64_t u = p.x, v = p.y;
+        uint64_t k0 = drop, k1 = drop;
         if (u < 0 || v < 0 || u >= nv || v >= nv) *bad = 1;
         else if (u != v) {
-            k0 = ((uint64_t)u << 32) | (uint64_t)v;
-            k1 = ((uint64_t)v << 32) | (uint64_t)u;
+            k0 = ((uint64_t)u << vb) | (uint64_t)v;
+            k1 = ((uint64_t)v << vb) | (uint64_t)u;
         }
-        keys[2 * i] = k0;
-        keys[2 * i + 1] = k1;
+        reinterpret_cast<ulonglong2 *>(keys)[i] = make_ulonglong2(k0, k1);
     }
 }
 
-// uniq[0..ns) sorted by (src,dst): col[j] = dst, rowptr[v] = first slot with src >= v
-__global__ __launch_bounds__(kBlock) void k_keys_to_csr(const uint64_t *__restrict__ uniq, int64_t ns, int64_t nv,
+// uniq[0..ns) sorted by (src,dst): col[j] = dst, src[j] = src, rowptr[v] = first slot with src >= v
+__global__ __launch_bounds__(kBlock) void k_keys_to_csr(const uint64_t *__restrict__ uniq, int64_t ns, int64_t nv, int vb,
                                                         uint32_t *__restrict__ rowptr, int32_t *__restrict__ col,
                                                         int32_t *__restrict__ src)
 {
+    const uint64_t mask = (1ull << vb) - 1ull;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
         const uint64_t k = uniq[j];
-        const int64_t s = (int64_t)(k >> 32);
-        col[j] = (int32_t)(k & 0xFFFFFFFFu);
+        const int64_t s = (int64_t)(k >> vb);
+        col[j] = (int32_t)(k & mask);
         src[j] = (int32_t)s;
-        const int64_t p = (j == 0) ? -1 : (int64_t)(uniq[j - 1] >> 32);
+        const int64_t p = (j == 0) ? -1 : (int64_t)(uniq[j - 1] >> vb);
         for (int64_t v = p + 1; v <= s; ++v) rowptr[v] = (uint32_t)j;
         if (j == ns - 1)
             for (int64_t v = s + 1; v <= nv; ++v) rowptr[v] = (uint32_t)ns;
@@ -94,26 +199,188 @@ __global__ __launch_bounds__(kBlock) void k_fill_src(const uint32_t *__restrict_
         for (uint32_t j = rowptr[v] + (uint32_t)lane; j < rowptr[v + 1]; j += 64) src[j] = (int32_t)v;
 }
 
-inline int grid_for(int64_t n)
+// ---- the renumbering
+// sort records of the vertices: (degree, original id); first slot of the upper half (column above row) of every original
+// row and its length (the canonical edges the row owns)
+__global__ __launch_bounds__(kBlock) void k_vertex_keys(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
+                                                        uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
+                                                        uint32_t *__restrict__ first_upper, uint32_t *__restrict__ upper_cnt)
 {
-    int64_t g = (n + kBlock - 1) / kBlock;
-    if (g < 1) g = 1;
-    if (g > 256 * 16) g = 256 * 16;
-    return (int)g;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) {
+        if (v == nv) { upper_cnt[v] = 0u; continue; }
+        const uint32_t b = rowptr[v], e = rowptr[v + 1];
+        dkey[v] = e - b;
+        dval[v] = (uint32_t)v;
+        uint32_t lo = b, hi = e;                                  // first slot with col > v (rows hold no loops)
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (col[mid] < (int32_t)v) lo = mid + 1; else hi = mid;
+        }
+        first_upper[v] = lo;
+        upper_cnt[v] = e - lo;
+    }
+}
+
+// i2o[i] = the vertex with the i-th smallest (degree, id); o2i its inverse
+__global__ __launch_bounds__(kBlock) void k_invert(const uint32_t *__restrict__ sorted_ids, int64_t nv, int32_t *__restrict__ i2o, int32_t *__restrict__ o2i)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
+        const uint32_t v = sorted_ids[i];
+        i2o[i] = (int32_t)v;
+        o2i[v] = (int32_t)i;
+    }
+}
+
+// every upper slot (u < v) of the original CSR = canonical edge k = ebase[u] + (j - first_upper[u]): its endpoints, and its
+// oriented internal slot as a sort record (key = lower internal id << vb | higher internal id, value = k)
+__global__ __launch_bounds__(kBlock) void k_emit_records(const int32_t *__restrict__ src, const int32_t *__restrict__ col, int64_t ns,
+                                                         const uint32_t *__restrict__ first_upper, const uint32_t *__restrict__ ebase,
+                                                         const int32_t *__restrict__ o2i, int vb,
+                                                         int32_t *__restrict__ ceu, int32_t *__restrict__ cev,
+                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
+        const int32_t u = src[j], v = col[j];
+        if (v < u) continue;
+        const uint32_t k = ebase[u] + ((uint32_t)j - first_upper[u]);
+        const uint64_t a = (uint64_t)(uint32_t)o2i[u], b = (uint64_t)(uint32_t)o2i[v];
+        ceu[k] = u; cev[k] = v;
+        keys[k] = a < b ? (a << vb) | b : (b << vb) | a;
+        vals[k] = k;
+    }
+}
+
+// oriented row pointers: orow[a] = first sorted record whose source is >= a (one thread per row, binary search: the rows
+// without out-edges -- isolated vertices, local maxima -- need no gap filling)
+__global__ __launch_bounds__(kBlock) void k_orow_search(const uint64_t *__restrict__ keys, int64_t ne, int64_t nv, int vb, uint32_t *__restrict__ orow)
+{
+    for (int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x; a <= nv; a += (int64_t)gridDim.x * kBlock) {
+        int64_t lo = 0, hi = ne;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)(keys[mid] >> vb) < a) lo = mid + 1; else hi = mid;
+        }
+        orow[a] = (uint32_t)lo;
+    }
+}
+
+// the sorted records -> targets and sources of the oriented slots, and the canonical -> internal edge map
+__global__ __launch_bounds__(kBlock) void k_split_records(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t ne, int vb,
+                                                          int32_t *__restrict__ ocol, int32_t *__restrict__ osrc, uint32_t *__restrict__ canon2e)
+{
+    const uint64_t mask = (1ull << vb) - 1ull;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ne; e += (int64_t)gridDim.x * kBlock) {
+        const uint64_t k = keys[e];
+        ocol[e] = (int32_t)(k & mask);
+        osrc[e] = (int32_t)(k >> vb);
+        canon2e[vals[e]] = (uint32_t)e;
+    }
+}
+
+struct Scratch {                                   // device scratch of one build: freed on every way out
+    std::vector<void *> v;
+    template <class T> hipError_t get(T **out, size_t count)
+    {
+        void *q = nullptr;
+        const hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) { v.push_back(q); *out = (T *)q; }
+        return e;
+    }
+    void drop(void *p) { for (auto &q : v) if (q == p && p) { (void)hipFree(p); q = nullptr; } }
+    ~Scratch() { for (void *q : v) if (q) (void)hipFree(q); }
+};
+
+template <class T> hipError_t resident(T **out, size_t count) { return hipMalloc((void **)out, (count ? count : 1) * sizeof(T)); }
+
+inline int id_bits(int64_t nv)
+{
+    int vb = 1;
+    while (vb < 31 && (1ll << vb) < nv) ++vb;
+    return vb;
+}
+
+// From the original CSR (ctx->d_o_rowptr / d_o_col, with the row of every slot in d_src_o) to everything else that stays
+// resident.  d_k0 / d_k1: two scratch key buffers of at least ns / 2 entries each (or null: allocated here).
+int finish_graph(komb_ctx *ctx, Scratch &sc, const int32_t *d_src_o, int64_t nv, int64_t ns, int vb, uint64_t *d_k0, uint64_t *d_k1)
+{
+    hipStream_t s = ctx->stream;
+    const int64_t ne = ns / 2;
+    const int gv = grid_for(nv + 1), gs = grid_for(ns);
+    KOMB_HIP(ctx, resident(&ctx->d_o2i, (size_t)nv));
+    KOMB_HIP(ctx, resident(&ctx->d_i2o, (size_t)nv));
+    KOMB_HIP(ctx, resident(&ctx->d_deg_i, (size_t)nv));
+    KOMB_HIP(ctx, resident(&ctx->d_orow, (size_t)nv + 1));
+    KOMB_HIP(ctx, resident(&ctx->d_ocol, (size_t)ne + 8));              // + 8: the triangle enumeration reads 16 bytes at a time, past the end of the last row
+    KOMB_HIP(ctx, resident(&ctx->d_osrc, (size_t)ne));
+    KOMB_HIP(ctx, resident(&ctx->d_ceu, (size_t)ne));
+    KOMB_HIP(ctx, resident(&ctx->d_cev, (size_t)ne));
+    KOMB_HIP(ctx, resident(&ctx->d_canon2e, (size_t)ne));
+    KOMB_HIP(ctx, hipMemsetAsync(ctx->d_ocol + ne, 0, 8 * sizeof(int32_t), s));
+
+    // ---- vertices by (degree, original id)
+    uint32_t *d_dk[2] = {nullptr, nullptr}, *d_dv[2] = {nullptr, nullptr}, *d_fu = nullptr, *d_uc = nullptr, *d_ebase = nullptr;
+    for (int i = 0; i < 2; ++i) { KOMB_HIP(ctx, sc.get(&d_dk[i], (size_t)nv)); KOMB_HIP(ctx, sc.get(&d_dv[i], (size_t)nv)); }
+    KOMB_HIP(ctx, sc.get(&d_fu, (size_t)nv + 1));
+    KOMB_HIP(ctx, sc.get(&d_uc, (size_t)nv + 1));
+    KOMB_HIP(ctx, sc.get(&d_ebase, (size_t)nv + 1));
+    k_vertex_keys<<<gv, kBlock, 0, s>>>(ctx->d_o_rowptr, ctx->d_o_col, nv, d_dk[0], d_dv[0], d_fu, d_uc);
+    uint32_t *sk = nullptr, *sv = nullptr;
+    KOMB_TRY(prim_sort_pairs_u32_u32(ctx, d_dk[0], d_dk[1], d_dv[0], d_dv[1], nv, 32, &sk, &sv));
+    if (nv > 0) {
+        k_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, nv, ctx->d_i2o, ctx->d_o2i);
+        KOMB_HIP(ctx, hipMemcpyAsync(ctx->d_deg_i, sk, (size_t)nv * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // degrees by internal id
+    }
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_uc, d_ebase, nv + 1));
+
+    // ---- canonical edges -> sort records -> oriented CSR in internal ids, canonical -> internal map
+    if (ne > 0) {
+        uint32_t *d_v0 = nullptr, *d_v1 = nullptr;
+        if (!d_k0) KOMB_HIP(ctx, sc.get(&d_k0, (size_t)ne));
+        if (!d_k1) KOMB_HIP(ctx, sc.get(&d_k1, (size_t)ne));
+        KOMB_HIP(ctx, sc.get(&d_v0, (size_t)ne));
+        KOMB_HIP(ctx, sc.get(&d_v1, (size_t)ne));
+        k_emit_records<<<gs, kBlock, 0, s>>>(d_src_o, ctx->d_o_col, ns, d_fu, d_ebase, ctx->d_o2i, vb, ctx->d_ceu, ctx->d_cev, d_k0, d_v0);
+        uint64_t *skeys = nullptr; uint32_t *svals = nullptr;
+        KOMB_TRY(prim_sort_pairs_u64_u32(ctx, d_k0, d_k1, d_v0, d_v1, ne, 2 * vb, &skeys, &svals));
+        k_orow_search<<<gv, kBlock, 0, s>>>(skeys, ne, nv, vb, ctx->d_orow);
+        k_split_records<<<grid_for(ne), kBlock, 0, s>>>(skeys, svals, ne, vb, ctx->d_ocol, ctx->d_osrc, ctx->d_canon2e);
+    } else {
+        k_fill_u32<<<gv, kBlock, 0, s>>>(ctx->d_orow, nv + 1, 0u);
+    }
+    // ---- graph moments for the roofline model (properties of the graph, not results of the path)
+    KOMB_TRY(graph_moments(ctx, ctx->d_deg_i, nv, ctx->d_osrc, ctx->d_ocol, ne, ctx->d_orow, ctx->g_mom));
+    KOMB_HIP(ctx, hipStreamSynchronize(s));
+    return KOMB_OK;
+}
+
+double wall_ms(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void publish_stats(komb_ctx *ctx, int64_t nv, int64_t ne)
+{
+    ctx->nv = nv;
+    ctx->ne = ne;
+    ctx->stats = komb_stats{};
+    ctx->stats.nv = nv; ctx->stats.ne = ne;
+    ctx->stats.sum_deg_sq = ctx->g_mom[0]; ctx->stats.wedge_items = ctx->g_mom[1];
+    ctx->stats.max_degree = (int32_t)ctx->g_mom[2]; ctx->stats.oriented_items = ctx->g_mom[4];
 }
 
 } // namespace
 
 void graph_free(komb_ctx *ctx)
 {
-    if (ctx->d_rowptr) (void)hipFree(ctx->d_rowptr);
-    if (ctx->d_col) (void)hipFree(ctx->d_col);
-    if (ctx->d_src) (void)hipFree(ctx->d_src);
-    if (ctx->d_deg) (void)hipFree(ctx->d_deg);
-    if (ctx->d_core) (void)hipFree(ctx->d_core);
-    ctx->d_rowptr = nullptr; ctx->d_col = nullptr; ctx->d_src = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
-    ctx->nv = -1; ctx->ne = 0; ctx->core_done = false; ctx->moments_valid = false;
-    truss_free(ctx);
+    void *all[] = {ctx->d_o_rowptr, ctx->d_o_col, ctx->d_o2i, ctx->d_i2o, ctx->d_deg_i, ctx->d_orow, ctx->d_ocol, ctx->d_osrc,
+                   ctx->d_ceu, ctx->d_cev, ctx->d_canon2e, ctx->d_deg, ctx->d_core};
+    truss_free(ctx);                                     // (its canonical endpoint arrays may BE d_ceu / d_cev: released first)
+    for (void *p : all) if (p) (void)hipFree(p);
+    ctx->d_o_rowptr = nullptr; ctx->d_o_col = nullptr; ctx->d_o2i = ctx->d_i2o = nullptr;
+    ctx->d_deg_i = nullptr; ctx->d_orow = nullptr; ctx->d_ocol = ctx->d_osrc = nullptr;
+    ctx->d_ceu = ctx->d_cev = nullptr; ctx->d_canon2e = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
+    ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
+    for (auto &m : ctx->g_mom) m = 0;
     ctx->pool.clear();                                   // scratch sized for the old graph
 }
 
@@ -126,64 +393,64 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
         KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph_from_edges: %lld raw pairs", (long long)n_raw);
     hipStream_t s = ctx->stream;
     Range r_all("komb_graph_from_edges");
-    ctx->timer.start(s);
+    const auto t_all = std::chrono::steady_clock::now();
+    const int vb = id_bits(nv);
+    double ms_h2d = 0.0;
+    struct Fail { komb_ctx *c; bool armed = true; ~Fail() { if (armed) graph_free(c); } } fail{ctx};   // nothing half-built stays behind
 
-    KOMB_HIP(ctx, hipMalloc(&ctx->d_rowptr, (size_t)(nv + 1) * sizeof(uint32_t)));
+    Scratch sc;
+    KOMB_HIP(ctx, resident(&ctx->d_o_rowptr, (size_t)nv + 1));
     int64_t ns = 0;
+    int32_t *d_src_o = nullptr;
+    uint64_t *d_k0 = nullptr, *d_k1 = nullptr;
     if (n_raw > 0) {
-        int64_t *d_uv = nullptr; uint64_t *d_k0 = nullptr, *d_k1 = nullptr; int *d_bad = nullptr;
-        auto cleanup = [&]() { if (d_uv) (void)hipFree(d_uv); if (d_k0) (void)hipFree(d_k0); if (d_k1) (void)hipFree(d_k1); if (d_bad) (void)hipFree(d_bad); };
+        int64_t *d_uv = nullptr; int *d_bad = nullptr;
         const int64_t nk = 2 * n_raw;
-        hipError_t e = hipMalloc(&d_uv, (size_t)nk * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc(&d_k0, (size_t)nk * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc(&d_k1, (size_t)nk * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(int));
-        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_uv, uv, (size_t)nk * sizeof(int64_t), hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
-        k_make_keys<<<grid_for(n_raw), kBlock, 0, s>>>(d_uv, n_raw, nv, d_k0, d_bad);
+        KOMB_HIP(ctx, sc.get(&d_uv, (size_t)nk));
+        KOMB_HIP(ctx, sc.get(&d_k0, (size_t)nk));
+        KOMB_HIP(ctx, sc.get(&d_k1, (size_t)nk));
+        KOMB_HIP(ctx, sc.get(&d_bad, 1));
+        KOMB_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), s));
+        const auto t_h2d = std::chrono::steady_clock::now();
+        KOMB_HIP(ctx, h2d_staged(ctx, d_uv, uv, (size_t)nk * sizeof(int64_t)));
+        ms_h2d = wall_ms(t_h2d);
+        k_make_keys<<<grid_for(n_raw), kBlock, 0, s>>>(d_uv, n_raw, nv, vb, d_k0, d_bad);
         int bad = 0;
-        e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
-        if (bad) { cleanup(); KOMB_FAIL(ctx, KOMB_ERR_ARG, "graph_from_edges: vertex id outside [0,%lld)", (long long)nv); }
-        (void)hipFree(d_uv); d_uv = nullptr;
+        KOMB_HIP(ctx, d2h(ctx, &bad, d_bad, sizeof(int)));
+        if (bad) KOMB_FAIL(ctx, KOMB_ERR_ARG, "graph_from_edges: vertex id outside [0,%lld)", (long long)nv);
+        sc.drop(d_uv);
 
         uint64_t *sorted = nullptr;
-        int st = prim_sort_u64(ctx, d_k0, d_k1, nk, 64, &sorted);
+        KOMB_TRY(prim_sort_u64(ctx, d_k0, d_k1, nk, 2 * vb, &sorted));
         uint64_t *other = (sorted == d_k0) ? d_k1 : d_k0;
         int64_t nu = 0;
-        if (st == KOMB_OK) st = prim_unique_u64(ctx, sorted, other, nk, &nu);
-        if (st != KOMB_OK) { cleanup(); return st; }
+        KOMB_TRY(prim_unique_u64(ctx, sorted, other, nk, &nu));
         // the drop key, if present, is the last unique key
         if (nu > 0) {
             uint64_t last = 0;
-            e = d2h(ctx, &last, other + (nu - 1), sizeof(uint64_t));
-            if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
-            if (last == kDropKey) --nu;
+            KOMB_HIP(ctx, d2h(ctx, &last, other + (nu - 1), sizeof(uint64_t)));
+            if (last == (1ull << (2 * vb)) - 1ull) --nu;
         }
         ns = nu;
-        if (ns > 0xFFFFFFF0ll) { cleanup(); KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld slots; limit is 2^32-16", (long long)ns); }
-        if (ns / 2 > INT32_MAX - 16) { cleanup(); KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld edges; limit is 2^31-16", (long long)(ns / 2)); }
-        e = hipMalloc(&ctx->d_col, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&ctx->d_src, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
-        if (e != hipSuccess) { cleanup(); KOMB_HIP(ctx, e); }
-        if (ns > 0) k_keys_to_csr<<<grid_for(ns), kBlock, 0, s>>>(other, ns, nv, ctx->d_rowptr, ctx->d_col, ctx->d_src);
-        else k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_rowptr, nv + 1, 0u);
-        e = hipStreamSynchronize(s);
-        cleanup();
-        KOMB_HIP(ctx, e);
+        if (ns > 0xFFFFFFF0ll) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld slots; limit is 2^32-16", (long long)ns);
+        if (ns / 2 > INT32_MAX - 16) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld edges; limit is 2^31-16", (long long)(ns / 2));
+        KOMB_HIP(ctx, resident(&ctx->d_o_col, (size_t)ns));
+        KOMB_HIP(ctx, sc.get(&d_src_o, (size_t)ns));
+        if (ns > 0) k_keys_to_csr<<<grid_for(ns), kBlock, 0, s>>>(other, ns, nv, vb, ctx->d_o_rowptr, ctx->d_o_col, d_src_o);
+        else k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_o_rowptr, nv + 1, 0u);
     } else {
-        KOMB_HIP(ctx, hipMalloc(&ctx->d_col, sizeof(int32_t)));
-        KOMB_HIP(ctx, hipMalloc(&ctx->d_src, sizeof(int32_t)));
-        k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_rowptr, nv + 1, 0u);
-        KOMB_HIP(ctx, hipStreamSynchronize(s));
+        KOMB_HIP(ctx, resident(&ctx->d_o_col, 1));
+        k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_o_rowptr, nv + 1, 0u);
     }
-    ctx->nv = nv;
-    ctx->ne = ns / 2;
-    ctx->stats = komb_stats{};
-    ctx->stats.nv = nv; ctx->stats.ne = ctx->ne;
-    ctx->stats.ms_build = ctx->timer.stop(s);
+    const auto t_rel = std::chrono::steady_clock::now();
+    KOMB_HIP(ctx, hipStreamSynchronize(s));
+    KOMB_TRY(finish_graph(ctx, sc, d_src_o, nv, ns, vb, d_k0, d_k1));
+    const double ms_rel = wall_ms(t_rel);
+    fail.armed = false;
+    publish_stats(ctx, nv, ns / 2);
+    ctx->stats.ms_build = wall_ms(t_all);
+    ctx->stats.ms_build_h2d = ms_h2d;
+    ctx->stats.ms_build_relabel = ms_rel;
     return KOMB_OK;
 }
 
@@ -198,37 +465,38 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
     if (ns > 0xFFFFFFF0ll || ns / 2 > INT32_MAX - 16)
         KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld slots; limit is 2^32-16", (long long)ns);
     hipStream_t s = ctx->stream;
-    ctx->timer.start(s);
-    int64_t *d_rp64 = nullptr; int *d_bad = nullptr;
-    hipError_t e = hipMalloc(&ctx->d_rowptr, (size_t)(nv + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_col, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_src, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_rp64, (size_t)(nv + 1) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(int));
-    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rp64, rowptr, (size_t)(nv + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && ns > 0) e = hipMemcpyAsync(ctx->d_col, col, (size_t)ns * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    const auto t_all = std::chrono::steady_clock::now();
+    struct Fail { komb_ctx *c; bool armed = true; ~Fail() { if (armed) graph_free(c); } } fail{ctx};
+    Scratch sc;
+    int64_t *d_rp64 = nullptr; int *d_bad = nullptr; int32_t *d_src_o = nullptr;
+    KOMB_HIP(ctx, resident(&ctx->d_o_rowptr, (size_t)nv + 1));
+    KOMB_HIP(ctx, resident(&ctx->d_o_col, (size_t)ns));
+    KOMB_HIP(ctx, sc.get(&d_src_o, (size_t)ns));
+    KOMB_HIP(ctx, sc.get(&d_rp64, (size_t)nv + 1));
+    KOMB_HIP(ctx, sc.get(&d_bad, 1));
+    KOMB_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), s));
+    const auto t_h2d = std::chrono::steady_clock::now();
+    KOMB_HIP(ctx, h2d_staged(ctx, d_rp64, rowptr, (size_t)(nv + 1) * sizeof(int64_t)));
+    if (ns > 0) KOMB_HIP(ctx, h2d_staged(ctx, ctx->d_o_col, col, (size_t)ns * sizeof(int32_t)));
+    const double ms_h2d = wall_ms(t_h2d);
     int bad = 0;
-    if (e == hipSuccess) {
-        k_rowptr_narrow<<<grid_for(nv + 1), kBlock, 0, s>>>(d_rp64, nv + 1, ctx->d_rowptr, d_bad);
-        e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    k_rowptr_narrow<<<grid_for(nv + 1), kBlock, 0, s>>>(d_rp64, nv + 1, ctx->d_o_rowptr, d_bad);
+    KOMB_HIP(ctx, d2h(ctx, &bad, d_bad, sizeof(int)));
+    if (!bad && nv > 0) {                                        // rowptr is sane: rows can be walked safely
+        k_fill_src<<<grid_for(nv * 16), kBlock, 0, s>>>(ctx->d_o_rowptr, nv, d_src_o);
+        k_validate_csr<<<grid_for(nv), kBlock, 0, s>>>(ctx->d_o_rowptr, ctx->d_o_col, nv, d_bad);
+        KOMB_HIP(ctx, d2h(ctx, &bad, d_bad, sizeof(int)));
     }
-    if (e == hipSuccess && !bad && nv > 0) {                     // rowptr is sane: rows can be walked safely
-        k_fill_src<<<grid_for(nv * 16), kBlock, 0, s>>>(ctx->d_rowptr, nv, ctx->d_src);
-        k_validate_csr<<<grid_for(nv), kBlock, 0, s>>>(ctx->d_rowptr, ctx->d_col, nv, d_bad);
-        e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-    }
-    if (d_rp64) (void)hipFree(d_rp64);
-    if (d_bad) (void)hipFree(d_bad);
-    if (e != hipSuccess) { graph_free(ctx); KOMB_HIP(ctx, e); }
-    if (bad) { graph_free(ctx); KOMB_FAIL(ctx, KOMB_ERR_ARG, "graph_from_csr: CSR is not simple, symmetric and row-sorted"); }
-    ctx->nv = nv;
-    ctx->ne = ns / 2;
-    ctx->stats = komb_stats{};
-    ctx->stats.nv = nv; ctx->stats.ne = ctx->ne;
-    ctx->stats.ms_build = ctx->timer.stop(s);
+    if (bad) KOMB_FAIL(ctx, KOMB_ERR_ARG, "graph_from_csr: CSR is not simple, symmetric and row-sorted");
+    sc.drop(d_rp64);
+    const auto t_rel = std::chrono::steady_clock::now();
+    KOMB_TRY(finish_graph(ctx, sc, d_src_o, nv, ns, id_bits(nv), nullptr, nullptr));
+    const double ms_rel = wall_ms(t_rel);
+    fail.armed = false;
+    publish_stats(ctx, nv, ns / 2);
+    ctx->stats.ms_build = wall_ms(t_all);
+    ctx->stats.ms_build_h2d = ms_h2d;
+    ctx->stats.ms_build_relabel = ms_rel;
     return KOMB_OK;
 }
 

@@ -5,11 +5,13 @@
 // peeled; a triangle-free edge has trussness 2.
 //
 // MI355X-first design (no intersections inside the peel loop):
-//   1. orient every edge from the lower to the higher (degree,id) endpoint: an
-//      ordered stream compaction of the CSR slots (k_slot_filter) gives the
-//      oriented CSR (orow/ocol, rows still ascending by id).  The internal edge
-//      id is the oriented slot.  On power-law unitig graphs the oriented rows
-//      are tiny (max ~10^2), whatever the hub degrees are.
+//   1. every edge points from its lower to its higher (degree,id) endpoint.  The
+//      graph is resident in INTERNAL ids = (degree,id) ranks (graph_build.hip),
+//      so that oriented CSR (orow/ocol) is simply the upper half of every row
+//      and comes with the graph; an induced subgraph is an ordered stream
+//      compaction of its slots (k_slot_filter).  The internal edge id is the
+//      oriented slot.  On power-law unitig graphs the oriented rows are tiny
+//      (max ~10^2), whatever the hub degrees are.
 //   2. enumerate every triangle once (k_triangles: edge a->b, every element of
 //      N+(b) looked up in the LDS-staged N+(a)) and build the incidence index:
 //      for every edge, the pairs of the other two edges of its triangles
@@ -31,8 +33,7 @@
 //      never touches the adjacency again.
 //   4. gather results into canonical (min,max)-lexicographic edge order with
 //      ORIGINAL vertex ids -- the identity the C ABI promises.  No search: the
-//      oriented copies that sit in the other endpoint's row travel through a
-//      stable radix sort by target id, after which every access is a stream.
+//      graph carries the internal edge id of every canonical edge.
 #include "peel_dev.h"
 #include "truss_tail.h"
 #include "local_dev.h"
@@ -66,7 +67,7 @@ struct TrussProblem {
     static constexpr bool kChain = false;
     static constexpr bool kSingleStep = false;
     uint32_t units;
-    const uint32_t *off;
+    const uint2 *off2;                   // (start, length) of every edge's incidence slice
     const int2 *inc;
     int32_t *sup;
     int32_t *stamp;                      // alive marker, then the sub-round the edge was peeled in: its trussness is
@@ -77,8 +78,9 @@ struct TrussProblem {
     __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const { stamp[e] = cv.round; }
     __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
     {
-        b = off[e];
-        len = off[e + 1] - b;
+        const uint2 o = off2[e];
+        b = o.x;
+        len = o.y;
     }
     struct Loaded { int32_t me, x, y, sx, sy; };
     __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
@@ -109,7 +111,7 @@ struct ShardTruss {
     static constexpr bool kChain = false;
     static constexpr bool kSingleStep = true;
     uint32_t units;
-    const uint32_t *off;
+    const uint2 *off2;
     const int2 *inc;
     int32_t *sup;
     int32_t *stamp;
@@ -120,8 +122,9 @@ struct ShardTruss {
     __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const { stamp[e] = cv.round; }
     __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
     {
-        b = off[e];
-        len = off[e + 1] - b;
+        const uint2 o = off2[e];
+        b = o.x;
+        len = o.y;
     }
     __device__ __forceinline__ bool mine(int32_t e) const { return (uint32_t)e - lo < hi - lo; }
     struct Loaded { int32_t me, x, y, sx, sy; };
@@ -153,7 +156,7 @@ struct TrussCollect {
     static constexpr bool kChain = false;
     static constexpr bool kSingleStep = false;
     uint32_t units;
-    const uint32_t *off;                 // the peel's incidence index
+    const uint2 *off2;                   // the peel's incidence index
     const int2 *inc;
     const int32_t *stamp;                // alive markers
     const int32_t *num;                  // [m] id in the remainder (live edges only)
@@ -166,8 +169,9 @@ struct TrussCollect {
     __device__ __forceinline__ void mark_scanned(uint32_t, const CtrlView &) const {}
     __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
     {
-        b = off[e];
-        len = off[e + 1] - b;
+        const uint2 o = off2[e];
+        b = o.x;
+        len = o.y;
     }
     struct Loaded { int32_t me, x, y, sx, sy; };
     __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
@@ -212,6 +216,19 @@ struct TrussLocal {
 
 } // namespace
 
+int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *osrc, const int32_t *ocol, int64_t m,
+                  const uint32_t *orow, int64_t out[5])
+{
+    unsigned long long *d_mom = nullptr, h[5] = {0, 0, 0, 0, 0};
+    DevBufs bufs(ctx);
+    KOMB_HIP(ctx, bufs.alloc(&d_mom, 5));
+    KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    k_graph_moments<<<1024, kBlock, 0, ctx->stream>>>(deg, nv, osrc, ocol, m, orow, d_mom);
+    KOMB_HIP(ctx, d2h(ctx, h, d_mom, sizeof(h)));
+    for (int i = 0; i < 5; ++i) out[i] = (int64_t)h[i];
+    return KOMB_OK;
+}
+
 void truss_free(komb_ctx *ctx)
 {
     ctx->pool.put(ctx->d_t_eu);
@@ -246,72 +263,42 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     DevBufs bufs(ctx);
     const int gv = grid_for(nv);
 
-    // ---- a5: working CSR = whole graph, or the subgraph induced by vmask (original ids kept)
-    const uint32_t *w_rowptr = ctx->d_rowptr;
-    const int32_t *w_col = ctx->d_col, *w_src = ctx->d_src;
-    int64_t w_ns = 2 * ctx->ne;
+    // ---- a5 + orientation: the oriented CSR of the whole graph is resident (graph_build.hip: internal ids are (degree, id) ranks,
+    // so "lower -> higher (degree,id)" is the upper half of every row); a subgraph induced by vmask is an ordered filter of
+    // its slots.  The internal edge id is the oriented slot.
+    Range phase("truss: orientation");
+    const uint32_t *d_orow = ctx->d_orow;
+    const int32_t *d_ocol = ctx->d_ocol, *d_osrc = ctx->d_osrc;
+    int64_t m = ctx->ne;
+    const int32_t *d_deg = ctx->d_deg_i;                             // degrees in the (sub)graph, internal ids
+    uint8_t *d_mask_o = nullptr;                                     // vmask by original id (kept for the gather)
+    unsigned long long *d_obits = nullptr;                           // vmask: bit e = oriented slot e of the whole graph is kept
+    uint32_t *d_wrank = nullptr;                                     // ... and the kept slots before each 64-slot word
+    ctx->timer.start(s);
     if (vmask_host) {
-        uint8_t *d_mask = nullptr; uint32_t *d_rp = nullptr; int32_t *d_c = nullptr, *d_s = nullptr;
-        KOMB_HIP(ctx, bufs.alloc(&d_mask, (size_t)nv));
+        uint8_t *d_mask_i = nullptr; uint32_t *d_rp = nullptr; int32_t *d_c = nullptr, *d_s = nullptr;
+        KOMB_HIP(ctx, bufs.alloc(&d_mask_o, (size_t)nv));
+        KOMB_HIP(ctx, bufs.alloc(&d_mask_i, (size_t)nv));
         KOMB_HIP(ctx, bufs.alloc(&d_rp, (size_t)nv + 1));
-        KOMB_HIP(ctx, hipMemcpyAsync(d_mask, vmask_host, (size_t)nv, hipMemcpyHostToDevice, s));
-        int64_t ns_sub = 0;
-        KOMB_TRY(compact_slots(ctx, bufs, ctx->d_src, ctx->d_col, w_ns, nv, PredMask{d_mask}, d_rp, &d_c, &d_s, &ns_sub));
-        bufs.release(d_mask);
-        w_rowptr = d_rp; w_col = d_c; w_src = d_s; w_ns = ns_sub;
-        if (ns_sub == 0) {
+        KOMB_HIP(ctx, hipMemcpyAsync(d_mask_o, vmask_host, (size_t)nv, hipMemcpyHostToDevice, s));
+        k_mask_internal<<<gv, kBlock, 0, s>>>(d_mask_o, ctx->d_i2o, nv, d_mask_i);
+        int64_t m_sub = 0;
+        KOMB_TRY(compact_slots(ctx, bufs, ctx->d_osrc, ctx->d_ocol, m, nv, PredMask{d_mask_i}, d_rp, &d_c, &d_s, &m_sub, &d_obits, &d_wrank));
+        bufs.release(d_mask_i);
+        d_orow = d_rp; d_ocol = d_c; d_osrc = d_s; m = m_sub;
+        if (m_sub == 0) {
             KOMB_HIP(ctx, hipStreamSynchronize(s));
             KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
             KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, 4));
             ctx->t_ne = 0; ctx->truss_done = true;
             return KOMB_OK;
         }
+        int32_t *d_deg_sub = nullptr;
+        KOMB_HIP(ctx, bufs.alloc(&d_deg_sub, (size_t)nv));
+        KOMB_HIP(ctx, hipMemsetAsync(d_deg_sub, 0, (size_t)nv * sizeof(int32_t), s));
+        k_sub_degree<<<grid_for(m), kBlock, 0, s>>>(d_osrc, d_ocol, m, d_deg_sub);
+        d_deg = d_deg_sub;
     }
-
-    // ---- orientation: oriented CSR, internal edge id = oriented slot
-    Range phase("truss: orientation");
-    int32_t *d_deg = nullptr; uint32_t *d_orow = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_deg, (size_t)nv));
-    KOMB_HIP(ctx, bufs.alloc(&d_orow, (size_t)nv + 1));
-    ctx->timer.start(s);
-    uint8_t *d_deg8 = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_deg8, (size_t)nv));
-    // graphs whose 1-byte degree table outgrows the L2s (4 MiB per XCD) decide most slots on a 2-bit class table first
-    const bool use_classes = (nv > (4ll << 20) || getenv("KOMB_DEG_CLASSES")) && !getenv("KOMB_NO_DEG_CLASSES");   // (no result depends on it)
-    unsigned long long *d_dhist = nullptr;
-    uint32_t *d_deg2 = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_dhist, 256));
-    KOMB_HIP(ctx, hipMemsetAsync(d_dhist, 0, 256 * sizeof(unsigned long long), s));
-    k_degree<<<gv, kBlock, 0, s>>>(w_rowptr, nv, d_deg, d_deg8, d_dhist);
-    int32_t dth[3] = {255, 255, 255};
-    if (use_classes) {
-        // class thresholds: the quartiles of the slots' endpoint degrees (capped at 255)
-        KOMB_HIP(ctx, bufs.alloc(&d_deg2, (size_t)(nv + 15) / 16 + 1));
-        unsigned long long hh[256];
-        KOMB_HIP(ctx, d2h(ctx, hh, d_dhist, sizeof(hh)));
-        unsigned long long all = 0, run = 0;
-        for (int d = 0; d < 256; ++d) all += hh[d];
-        int q = 0;
-        for (int d = 0; d < 256 && q < 3; ++d) {
-            run += hh[d];
-            while (q < 3 && run * 4 >= all * (unsigned long long)(q + 1)) dth[q++] = d;
-        }
-        k_degree_classes<<<grid_for((nv + 15) / 16), kBlock, 0, s>>>(d_deg8, nv, dth[0], dth[1], dth[2], d_deg2);
-    }
-    bufs.release(d_dhist);
-    int32_t *d_ocol = nullptr, *d_osrc = nullptr;
-    int64_t m = 0;
-    unsigned long long *d_obits = nullptr;                           // bit j: working slot j is the oriented copy of its edge
-    uint32_t *d_wrank = nullptr;                                     // oriented slots before each 64-slot word of d_obits
-    unsigned long long *d_kubits = nullptr;                          // ... and is an upper slot (its row's id below its column's)
-    uint32_t *d_urank = nullptr;                                     // upper slots per 64-slot word (the gather turns it into their prefix sum)
-    // the source row of every oriented slot (osrc) is needed by round 2's bounded slices, the LDS tail and the graph moments
-    // (first call on a graph, and subgraph runs) only: otherwise it is not written, and the oriented row pointers come from the keep bits
-    const bool need_osrc = (vmask_host != nullptr || !ctx->moments_valid) || finish_mode(FIN_LOCAL) == FIN_LDS ||
-                           (getenv("KOMB_INDEX") && !strcmp(getenv("KOMB_INDEX"), "slices"));
-    int32_t **p_osrc = need_osrc ? &d_osrc : nullptr;
-    if (use_classes) KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrientClass{d_deg, d_deg8, d_deg2, dth[0], dth[1], dth[2]}, d_orow, &d_ocol, p_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank, w_rowptr));
-    else KOMB_TRY(compact_slots(ctx, bufs, w_src, w_col, w_ns, nv, PredOrient{d_deg, d_deg8}, d_orow, &d_ocol, p_osrc, &m, &d_obits, &d_wrank, &d_kubits, &d_urank, w_rowptr));
     st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
 
@@ -322,10 +309,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     const int64_t ntasks = (nv + tri_tv - 1) / tri_tv;
     const int gt = grid_for(ntasks, kTriWaves);
     uint32_t *d_own = nullptr, *d_other = nullptr, *d_cnt = nullptr, *d_off = nullptr;
+    uint2 *d_off2 = nullptr;                                         // (start, length) of every edge's slice of the index: what the peel and the gather read
     KOMB_HIP(ctx, bufs.alloc(&d_own, 2 * ((size_t)m + 1)));         // [own | other] contiguous: one all-reduce
     d_other = d_own + ((size_t)m + 1);
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)m + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_off2, (size_t)m + 4));
     unsigned long long *d_mom = nullptr;
     KOMB_HIP(ctx, bufs.alloc(&d_mom, 12));                           // [0..4] graph moments, [5] sum of supports, [6,7] capacity bounds, [8] sharded-check mismatches
     KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 12 * sizeof(unsigned long long), s));
@@ -375,8 +363,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     uint32_t *d_bintot = nullptr;              // stream: supports summed per bin, then their exclusive scan (every bin's window of the index)
     uint32_t *d_reckey = nullptr;              // stream: the sorted records' keys
     int2 *d_recval = nullptr;                  // stream: ... and values
-    int64_t n_bins = 0;
-    const TriStream no_stream{nullptr, nullptr, nullptr, 0ull, 0u};
+    const BinGeom geom = bin_geom(m);                               // stream: the bins of the index build (truss_index.h)
+    const int64_t n_bins = (int64_t)geom.nb;
+    const TriStream no_stream{nullptr, nullptr, nullptr, 0ull, 0u, 0u, 0};
 #ifdef KOMB_DEBUG_SWITCHES
     const int ablate = getenv("KOMB_TRI_ABLATE") ? atoi(getenv("KOMB_TRI_ABLATE")) : 0;    // breaks results on purpose: debug builds only
 #else
@@ -433,10 +422,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         if (own_cap * sizeof(int2) > budget / 2) own_cap = budget / 2 / sizeof(int2);
         if (rec_cap * 12ull > budget / 2) rec_cap = budget / 2 / 12ull;
         if (rec_cap > 0xFFFFFFF0ull) rec_cap = 0xFFFFFFF0ull;        // 32-bit record positions
-        int end_bit = 1;
-        // the sentinel key (1 << end_bit) - 1 lies at least a whole bin above the last edge id, so the sort by bin puts it last
-        while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)m + kBinEdges) ++end_bit;
-        const uint32_t sentinel = end_bit >= 32 ? 0xFFFFFFFFu : (uint32_t)((1ull << end_bit) - 1ull);
+        // keys of unused record positions: above every edge id, their bin field taken from the position (they spread over the bins)
+        const uint32_t sentinel = geom.sentinel_base();
         uint32_t *d_key = nullptr; int2 *d_val = nullptr;
         bool ok = bufs.alloc(&d_key, (size_t)rec_cap) == hipSuccess && bufs.alloc(&d_val, (size_t)rec_cap) == hipSuccess &&
                   bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess && bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess &&
@@ -444,7 +431,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         unsigned long long n_claimed = 0;
         if (ok) {
             KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 4 * sizeof(unsigned long long), s));
-            const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel};
+            const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel, geom.nb - 1u, kChunkBits};
             ctx->timer.start(s);
             k_triangles<TRI_SINGLE, uint32_t, false, true, true><<<gts, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr,
                                                                                       d_owndense, d_dcur, own_cap, d_ownoff, ablate, ts, tri_tv);
@@ -463,16 +450,15 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             uint32_t *d_key2 = nullptr; unsigned long long *d_val2 = nullptr;
             ok = bufs.alloc(&d_key2, (size_t)n_claimed + 1) == hipSuccess && bufs.alloc(&d_val2, (size_t)n_claimed + 1) == hipSuccess;
             if (ok) {
-                // sort the records by BIN (the key bits above kBinBits): two radix passes instead of four
+                // sort the records by BIN (the bin field of the key only): two radix passes instead of four
                 ctx->timer.start(s);
                 unsigned long long *sv = nullptr;
-                if (end_bit > kBinBits) KOMB_TRY(prim_sort_pairs_u32_u64(ctx, d_key, d_key2, (unsigned long long *)d_val, d_val2, (int64_t)n_claimed, kBinBits, end_bit, &d_skey, &sv));
+                if (geom.nb_bits > 0) KOMB_TRY(prim_sort_pairs_u32_u64(ctx, d_key, d_key2, (unsigned long long *)d_val, d_val2, (int64_t)n_claimed, kChunkBits, kChunkBits + geom.nb_bits, &d_skey, &sv));
                 else { d_skey = d_key; sv = (unsigned long long *)d_val; }      // a single bin: nothing to sort
                 st.ms_sort = ctx->timer.stop(s);
                 d_recval = (int2 *)sv;
                 if (d_skey == d_key) { bufs.release(d_key2); bufs.release(d_val2); } else { bufs.release(d_key); bufs.release(d_val); }
                 d_reckey = d_skey;
-                n_bins = (m + kBinEdges - 1) >> kBinBits;
                 KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)n_bins + 2));
                 KOMB_HIP(ctx, bufs.alloc(&d_bintot, (size_t)n_bins + 2));
                 KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
@@ -480,8 +466,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 ctx->timer.start(s);
                 peel_ctrl_pre(s, d_grp);
                 KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
-                k_bin_offsets<<<grid_for(n_bins + 1), kBlock, 0, s>>>(d_skey, (int64_t)n_claimed, n_bins, d_toff);
-                k_bin_count<<<grid_for(n_bins, 1, 256 * 8), kBlock, 0, s>>>(d_skey, d_toff, n_bins, d_own, m, d_cnt, d_bintot, d_mom + 5, (int32_t *)(d_grp + kInitOff + 1));
+                k_bin_offsets<<<grid_for(n_bins + 1), kBlock, 0, s>>>(d_skey, (int64_t)n_claimed, geom, d_toff);
+                k_bin_count<<<grid_for(n_bins, 1, 256 * 8), kBlock, 0, s>>>(d_skey, d_toff, geom, d_own, m, d_cnt, d_bintot, d_mom + 5, (int32_t *)(d_grp + kInitOff + 1));
                 st.ms_compact = ctx->timer.stop(s);
                 st.tri_records = (int64_t)n_claimed;
             } else (void)hipGetLastError();
@@ -588,17 +574,19 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }
     }
     st.index_layout = layout;
-    // graph statistics for the roofline model (sum d^2, sum min(d,d), max d, sum d+ + d+): properties of
-    // the graph, not results of the path -- computed on the first whole-graph run and on every subgraph run
-    const bool want_moments = vmask_host != nullptr || !ctx->moments_valid;
-    if (want_moments) k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_cnt, d_orow, d_mom);
+    // graph statistics for the roofline model (sum d^2, sum min(d,d), max d, sum d+ + d+): properties of the graph, not
+    // results of the path -- the whole graph's come with the graph (graph_build.hip), a subgraph's are computed here
+    const bool want_moments = vmask_host != nullptr;
+    if (want_moments) k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_orow, d_mom);
     {
         unsigned long long mom[9];
         KOMB_HIP(ctx, d2h(ctx, mom, d_mom, sizeof(mom)));
         if (want_moments) {
             st.sum_deg_sq = (int64_t)mom[0]; st.wedge_items = (int64_t)mom[1]; st.max_degree = (int32_t)mom[2];
             st.oriented_items = (int64_t)mom[4];
-            ctx->moments_valid = vmask_host == nullptr;
+        } else {
+            st.sum_deg_sq = ctx->g_mom[0]; st.wedge_items = ctx->g_mom[1]; st.max_degree = (int32_t)ctx->g_mom[2];
+            st.oriented_items = ctx->g_mom[4];
         }
         st.triangles = (int64_t)(mom[5] / 3);
         bufs.release(d_mom);
@@ -623,13 +611,15 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
         ctx->timer.start(s);
-        k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, n_bins, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
-                                                                      d_off, d_sup, d_stamp, d_grp + kInitOff, d_light0);
+        k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, geom, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
+                                                                      d_off2, d_sup, d_stamp, d_grp + kInitOff, d_light0);
         st.ms_compact += ctx->timer.stop(s);
         peel_inited = true;
         bufs.release(d_toff); bufs.release(d_bintot); bufs.release((void *)d_recval); bufs.release(d_reckey);
         bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
     } else {
+        // (bounded slices, exact two-pass: the slices follow each other in edge order; the pairs are made with the peel's initial state)
+        KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
         KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_off, m + 1));
         KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
         KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
@@ -683,7 +673,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // at C3).  A sub-round peels at least one edge: m + 2 entries; [0] = level 0 (the triangle-free edges' stamp).
     KOMB_HIP(ctx, bufs.alloc(&Q.rlevel, (size_t)m + 2));
     KOMB_HIP(ctx, hipMemsetAsync(Q.rlevel, 0, 2 * sizeof(int32_t), s));
-    TrussProblem P{(uint32_t)m, d_off, d_inc, d_sup, d_stamp};
+    TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp};
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
@@ -748,7 +738,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         const int lrc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)m, d_stamp, d_sup, Q.live[hc.live_sel],
             (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), local_item_limit(kTrussLocalItems), local_density_limit(kTrussLocalDensity), true, 2, d_truss,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
-                TrussCollect C{(uint32_t)m, d_off, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
+                TrussCollect C{(uint32_t)m, d_off2, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
                 PeelQueues Qc = Q;
                 Qc.rlevel = nullptr;                   // (the collect pass has sub-rounds of its own: they are nobody's trussness)
                 k_peel_step<TrussCollect><<<gp, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Qc, C, launch);
@@ -775,7 +765,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     ctx->timer.start(s);
     if (!peel_inited) {
         peel_ctrl_pre(s, d_grp);
-        k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_sup, d_stamp, d_grp + kInitOff);
+        k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_off2, d_sup, d_stamp, d_grp + kInitOff);
     }
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
     int launches = 0, rc = KOMB_OK;
@@ -787,7 +777,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         // finish under the same rule as in the replicated peel, after one exchange of the live supports (shard_dev.h)
         uint32_t iw[2] = {0u, 0u};
         KOMB_HIP(ctx, d2h(ctx, iw, d_grp + kInitOff, sizeof(iw)));     // triangle-free edges; the smallest positive support
-        ShardTruss SP{(uint32_t)m, d_off, d_inc, d_sup, d_stamp, 0u, 0u};
+        ShardTruss SP{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp, 0u, 0u};
         shard_bounds((uint64_t)m, rank, world, &SP.lo, &SP.hi);
         ShardStats ss;
         rc = shard_peel(ctx, bufs, SP, d_sup, (uint32_t)m, iw[0], (int32_t)iw[1], rank, world, fn, user, Q, d_ctrl,
@@ -840,39 +830,29 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     bufs.release(Q.code);
     bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc); bufs.release(Q.rlevel);
 
-    // ---- canonical-order results with original vertex ids
+    // ---- canonical-order results with original vertex ids: the graph carries its canonical edge list and the internal edge
+    // id of every canonical edge (graph_build.hip), so the whole-graph gather is one pass; a subgraph's results are the
+    // kept canonical edges in order, each reading its kept oriented slot's values
     phase.next("truss: canonical gather");
     ctx->timer.start(s);
-    const int64_t nwords = (w_ns + 63) / 64;
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_urank, d_urank, nwords + 1));     // upper slots before every word = canonical id of its first upper slot
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-    // the reversed oriented slots (source id above target id), stably sorted by target: see k_gather_canonical
-    uint32_t *d_kurank = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_kurank, (size_t)nwords + 1));
-    k_popc_words<<<grid_for(nwords + 1), kBlock, 0, s>>>(d_kubits, nwords, d_kurank);
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_kurank, d_kurank, nwords + 1));
-    uint32_t kept_upper = 0;
-    KOMB_HIP(ctx, d2h(ctx, &kept_upper, d_kurank + nwords, sizeof(uint32_t)));
-    const int64_t n_rev = m - (int64_t)kept_upper;
-    uint32_t *d_rkey = nullptr, *d_rkey2 = nullptr;
-    unsigned long long *d_rval = nullptr, *d_rval2 = nullptr, *d_rev_sorted = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_rkey, (size_t)n_rev + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_rkey2, (size_t)n_rev + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_rval, (size_t)n_rev + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_rval2, (size_t)n_rev + 1));
-    d_rev_sorted = d_rval;
-    if (n_rev > 0) {
-        k_rev_emit<<<grid_for(w_ns), kBlock, 0, s>>>(w_col, w_ns, d_obits, d_wrank, d_kubits, d_kurank, d_truss, d_off, d_rkey, d_rval);
-        int vbits = 1;
-        while (vbits < 32 && (1ll << vbits) < nv) ++vbits;
-        uint32_t *sk = nullptr;
-        KOMB_TRY(prim_sort_pairs_u32_u64(ctx, d_rkey, d_rkey2, d_rval, d_rval2, n_rev, 0, vbits, &sk, &d_rev_sorted));
+    if (!vmask_host) {
+        ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;          // (not pool blocks: truss_free's put() ignores them)
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+        k_gather_canonical<<<grid_for(m), kBlock, 0, s>>>(ctx->d_canon2e, m, d_truss, d_off2, ctx->d_t_truss, ctx->d_t_sup);
+    } else {
+        uint32_t *d_junk_rp = nullptr; int32_t *d_eu = nullptr, *d_ev = nullptr;
+        unsigned long long *d_kbits = nullptr; uint32_t *d_krank = nullptr;
+        int64_t n_sub = 0;
+        KOMB_HIP(ctx, bufs.alloc(&d_junk_rp, (size_t)nv + 1));
+        KOMB_TRY(compact_slots(ctx, bufs, ctx->d_ceu, ctx->d_cev, ctx->ne, nv, PredMask{d_mask_o}, d_junk_rp, &d_ev, &d_eu, &n_sub, &d_kbits, &d_krank));
+        if (n_sub != m) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss gather: %lld canonical edges kept, %lld oriented slots", (long long)n_sub, (long long)m);
+        bufs.detach(d_eu); bufs.detach(d_ev);                        // they stay with the context until the next run
+        ctx->d_t_eu = d_eu; ctx->d_t_ev = d_ev;
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+        k_gather_sub<<<grid_for(ctx->ne), kBlock, 0, s>>>(ctx->d_canon2e, ctx->ne, d_kbits, d_krank, d_obits, d_wrank, d_truss, d_off2, ctx->d_t_truss, ctx->d_t_sup);
     }
-    k_gather_canonical<<<grid_for(w_ns), kBlock, 0, s>>>(w_src, w_col, w_ns, d_obits, d_wrank, d_kubits, d_kurank, d_rev_sorted, d_urank, d_truss, d_off,
-                                                        ctx->d_t_eu, ctx->d_t_ev, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
     if (getenv("KOMB_POOL_DEBUG")) {
         size_t held = 0;

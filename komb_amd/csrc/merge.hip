@@ -177,9 +177,9 @@ int merge_run(komb_ctx *ctx, const double *susp_host, int32_t *order, int32_t *s
         KOMB_HIP(ctx, bufs.alloc(&d_gone, (size_t)2 * nv));
     }
     int64_t g = (nv + kBlock - 1) / kBlock;
-    k_merge_prio<<<(int)(g > 4096 ? 4096 : g), kBlock, 0, s>>>(ctx->d_rowptr, nv, d_susp, d_prio);
-    if (lds) k_merge_run<true><<<1, kWave, 0, s>>>(ctx->d_rowptr, ctx->d_col, (int32_t)nv, d_susp, d_prio, nullptr, nullptr, nullptr, nullptr, d_order, d_side, d_out);
-    else k_merge_run<false><<<1, kWave, 0, s>>>(ctx->d_rowptr, ctx->d_col, (int32_t)nv, d_susp, d_prio, d_arr, d_pos, d_val, d_gone, d_order, d_side, d_out);
+    k_merge_prio<<<(int)(g > 4096 ? 4096 : g), kBlock, 0, s>>>(ctx->d_o_rowptr, nv, d_susp, d_prio);
+    if (lds) k_merge_run<true><<<1, kWave, 0, s>>>(ctx->d_o_rowptr, ctx->d_o_col, (int32_t)nv, d_susp, d_prio, nullptr, nullptr, nullptr, nullptr, d_order, d_side, d_out);
+    else k_merge_run<false><<<1, kWave, 0, s>>>(ctx->d_o_rowptr, ctx->d_o_col, (int32_t)nv, d_susp, d_prio, d_arr, d_pos, d_val, d_gone, d_order, d_side, d_out);
     MergeOut ho{};
     KOMB_HIP(ctx, d2h(ctx, &ho, d_out, sizeof(ho)));
     KOMB_HIP(ctx, hipMemcpy(order, d_order, (size_t)2 * nv * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -151,4 +151,23 @@ int prim_sort_pairs_u32_u32(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, u
     return KOMB_OK;
 }
 
+// records of the graph build: 64-bit keys (internal source, internal target), 32-bit values (canonical edge id), sorted by
+// the key bits [0, end_bit).  Asynchronous on the context's stream.
+int prim_sort_pairs_u64_u32(komb_ctx *ctx, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                            int64_t n, int end_bit, uint64_t **sorted_keys, uint32_t **sorted_vals)
+{
+    hipcub::DoubleBuffer<uint64_t> dk(keys, keys_alt);
+    hipcub::DoubleBuffer<uint32_t> dv(vals, vals_alt);
+    if (n > 0) {
+        size_t bytes = 0;
+        KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (long long)n, 0, end_bit, ctx->stream));
+        TempBuf t(ctx);
+        KOMB_HIP(ctx, t.get(bytes));
+        KOMB_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(t.p, bytes, dk, dv, (long long)n, 0, end_bit, ctx->stream));
+    }
+    *sorted_keys = dk.Current();
+    *sorted_vals = dv.Current();
+    return KOMB_OK;
+}
+
 } // namespace komb

@@ -92,7 +92,7 @@ constexpr uint32_t kOwnChunk = 4096;                // entries a wavefront claim
 // -- the third-role entry of every triangle, and all three entries of a triangle whose task has no block (a spilled or
 // unstaged sub-range, a region that has run out) -- is appended as a record (key = the edge the entry belongs to, value =
 // the other two edges) to ONE stream, 64 records per store instruction, no atomic and no scattered store per triangle.
-// A wavefront claims kRecChunk positions of the stream at a time; what it leaves unused gets the sentinel key (larger
+// A wavefront claims kRecChunk positions of the stream at a time; what it leaves unused gets a sentinel key (larger
 // than every edge id).  The host then sorts the records by key (the destination-binned build of the index: DESIGN.md
 // section 4.2) and merges them with the dense blocks.  A claim beyond `cap` writes nothing: the host sees the cursor
 // pass the capacity and falls back to the exact two-pass build.
@@ -102,7 +102,9 @@ struct TriStream {
     int2 *val;                           // [cap]
     unsigned long long *cursor;          // positions claimed so far
     unsigned long long cap;
-    uint32_t sentinel;
+    uint32_t sentinel;                   // key of an unused position: above every edge id ...
+    uint32_t spread_mask;                // ... with the position's low bits in the key's bin field, so that they spread over the bins (truss_index.h)
+    int spread_shift;
 };
 
 template <int MODE, class OffT = uint32_t, bool BACK = false, bool DENSE = false, bool STREAM = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
@@ -492,7 +494,8 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
         }
       }   // sub-ranges
     }
-    if (STREAM) for (unsigned long long q = rec_pos + (unsigned long long)lane; q < rec_end && q < ts.cap; q += kWave) ts.key[q] = ts.sentinel;
+    if (STREAM) for (unsigned long long q = rec_pos + (unsigned long long)lane; q < rec_end && q < ts.cap; q += kWave)
+        ts.key[q] = ts.sentinel | (((uint32_t)q & ts.spread_mask) << ts.spread_shift);
 #ifdef KOMB_TRI_PROFILE
     if (lane == 0 && gw < 16384) g_tri_prof[2 * gw + 1] = wall_clock64();
 #endif

@@ -51,7 +51,7 @@ with komb_amd.KombAccel() as a:
         if items: os.environ["KOMB_LOCAL_ITEMS"] = items
         else: os.environ.pop("KOMB_LOCAL_ITEMS", None)
         for k, on in (("KOMB_TWO_PASS", rng.random() < 0.15), ("KOMB_OFF64", rng.random() < 0.3), ("KOMB_NO_OWN_DENSE", rng.random() < 0.3),
-                      ("KOMB_DEG_CLASSES", rng.random() < 0.5), ("KOMB_SHARD_PEEL", rng.random() < 0.15)):
+                      ("KOMB_SHARD_PEEL", rng.random() < 0.15)):
             if on: os.environ[k] = "1"
             else: os.environ.pop(k, None)
         os.environ["KOMB_INDEX"] = str(rng.choice(["stream", "stream", "slices", "two_pass"]))
@@ -73,7 +73,7 @@ with komb_amd.KombAccel() as a:
                   f"TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
                   f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')} NO_OWN_DENSE={os.environ.get('KOMB_NO_OWN_DENSE')} LOCAL_ITEMS={os.environ.get('KOMB_LOCAL_ITEMS')} "
                   f"INDEX={os.environ.get('KOMB_INDEX')} OWN_DENSE_CAP={os.environ.get('KOMB_OWN_DENSE_CAP')} REC_CAP={os.environ.get('KOMB_REC_CAP')} "
-                  f"DEG_CLASSES={os.environ.get('KOMB_DEG_CLASSES')} DEFER={os.environ.get('KOMB_LOCAL_DEFER_CHUNKS')} SHARD_PEEL={os.environ.get('KOMB_SHARD_PEEL')}", flush=True)
+                  f"DEFER={os.environ.get('KOMB_LOCAL_DEFER_CHUNKS')} SHARD_PEEL={os.environ.get('KOMB_SHARD_PEEL')}", flush=True)
         if g % 100 == 99:
             print(f"{g + 1} graphs, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {n_graphs} graphs, {bad} mismatches, {time.time() - t0:.0f} s")

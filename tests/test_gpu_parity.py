@@ -26,7 +26,7 @@ def _i64(x):
 
 def test_native_library_is_loaded(K):
     lib = K._lib.load()
-    assert lib.komb_abi_version() == 4
+    assert lib.komb_abi_version() == 5
     with open("/proc/self/maps") as f:
         assert "libkomb_accel.so" in f.read()
 
@@ -349,26 +349,45 @@ def test_sharded_peel_engine_single_rank(K, O, monkeypatch):
             assert a.stats()["shard_exchanges"] == 0
 
 
-def test_orientation_class_table(K, O, monkeypatch):
-    """Graphs above 4M vertices decide the orientation on a 2-bit degree-class table before the 1-byte one (the full-size C3
-    test runs that way); here the table is forced on small graphs -- power-law, regular (one class for everybody), dense --
-    and must change nothing."""
+def test_internal_renumbering_is_invisible(K, O):
+    """The library works on (degree, id)-ranked internal vertex ids (graph_build.hip) and reports everything in the caller's:
+    shapes whose degree order is far from their id order -- a hub at id 0, isolated vertices in the middle of the id range,
+    a regular ring (every degree equal: the order is the id order), a dense block at the low ids -- through both
+    constructors, with random induced subgraphs, must give the oracle's CSR, degrees, coreness, canonical edge order,
+    supports and trussness."""
     rng = np.random.default_rng(31)
     ring = np.stack([np.arange(3000), (np.arange(3000) + 1) % 3000], axis=1)
+    star = np.stack([np.zeros(500, np.int64), np.arange(1, 501)], axis=1)
+    clique = np.array([(i, j) for i in range(40) for j in range(i + 1, 40)], dtype=np.int64)
+    mixed = np.concatenate([star, clique + 600, np.stack([np.arange(700, 900), np.arange(701, 901)], axis=1),
+                            rng.integers(1000, 1400, (3000, 2))]).astype(np.int64)
     cases = [(40000, K.gen_hug_edges(40000, 110000, 2.3, 21)), (3000, np.concatenate([ring, np.roll(ring, 1, axis=1)]).astype(np.int64)),
-             (600, rng.integers(0, 600, (40000, 2)).astype(np.int64)), (70000, K.gen_hug_edges(70000, 180000, 2.1, 3))]
+             (600, rng.integers(0, 600, (40000, 2)).astype(np.int64)), (1500, mixed), (70000, K.gen_hug_edges(70000, 180000, 2.1, 3))]
     for nv, uv in cases:
-        with K.KombAccel() as a:
-            a.from_edges(nv, uv)
-            monkeypatch.delenv("KOMB_DEG_CLASSES", raising=False)
-            r0 = a.run_truss(with_support=True)
-            monkeypatch.setenv("KOMB_DEG_CLASSES", "1")
-            r1 = a.run_truss(with_support=True)
-            monkeypatch.delenv("KOMB_DEG_CLASSES", raising=False)
-            for x, y in zip(r0, r1):
-                assert np.array_equal(x, y)
-            rowptr, col = a.get_csr()
-            assert np.array_equal(r1[2], O.trussness(rowptr, col))
+        o_rowptr, o_col = O.simplify(nv, uv)
+        oeu, oev = O.edge_list(o_rowptr, o_col)
+        osup, _ = O.support(o_rowptr, o_col)
+        otr = O.trussness(o_rowptr, o_col)
+        ocore = O.coreness(o_rowptr, o_col)
+        for ctor in ("edges", "csr"):
+            with K.KombAccel() as a:
+                if ctor == "edges": a.from_edges(nv, uv)
+                else: a.from_csr(o_rowptr, o_col)
+                rowptr, col = a.get_csr()
+                assert np.array_equal(rowptr, o_rowptr) and np.array_equal(col, o_col)
+                deg, core = a.run_core()
+                assert np.array_equal(deg, O.degree(o_rowptr)) and np.array_equal(core, ocore)
+                eu, ev, tr, sup = a.run_truss(with_support=True)
+                assert np.array_equal(eu, oeu) and np.array_equal(ev, oev)
+                assert np.array_equal(sup, osup) and np.array_equal(tr, otr)
+                for frac in (0.5, 0.05):
+                    mask = (rng.random(nv) < frac).astype(np.uint8)
+                    seu, sev, stra = a.run_truss(mask)
+                    weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
+                    assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+                # a whole-graph run after a subgraph run: the resident canonical edge list is untouched
+                eu2, ev2, tr2 = a.run_truss()
+                assert np.array_equal(eu2, oeu) and np.array_equal(ev2, oev) and np.array_equal(tr2, otr)
 
 
 def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
