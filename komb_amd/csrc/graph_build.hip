@@ -9,7 +9,8 @@
 //     once, from its lower to its higher endpoint, as a CSR with ascending rows plus the source of every slot -- the
 //     internal edge id is the oriented slot.  In degree order the (degree,id) orientation is an id compare, so no run has
 //     to orient anything;
-//   * the canonical edge list (original ids, (min,max)-lexicographic) and, for every canonical edge, its internal edge id.
+//   * the canonical edge list (original ids, (min,max)-lexicographic) and, for every canonical edge, its internal edge id;
+//   * one 64-byte line per vertex describing its oriented row to the triangle enumeration (truss_wedge.h).
 //
 // How: both directions of every raw pair as 64-bit keys (src << vb | dst, vb = bits of a vertex id), radix-sorted on the
 // 2*vb significant bits and uniqued -> original CSR.  Vertices are radix-sorted (stably) by degree -> the renumbering.
@@ -315,6 +316,7 @@ int finish_graph(komb_ctx *ctx, Scratch &sc, const int32_t *d_src_o, int64_t nv,
     KOMB_HIP(ctx, resident(&ctx->d_ceu, (size_t)ne));
     KOMB_HIP(ctx, resident(&ctx->d_cev, (size_t)ne));
     KOMB_HIP(ctx, resident(&ctx->d_canon2e, (size_t)ne));
+    KOMB_HIP(ctx, resident(&ctx->d_vline, 4 * (size_t)nv));
     KOMB_HIP(ctx, hipMemsetAsync(ctx->d_ocol + ne, 0, 8 * sizeof(int32_t), s));
 
     // ---- vertices by (degree, original id)
@@ -347,6 +349,8 @@ int finish_graph(komb_ctx *ctx, Scratch &sc, const int32_t *d_src_o, int64_t nv,
     } else {
         k_fill_u32<<<gv, kBlock, 0, s>>>(ctx->d_orow, nv + 1, 0u);
     }
+    // ---- the oriented rows' lines for the triangle enumeration (truss_wedge.h)
+    KOMB_TRY(vertex_lines(ctx, ctx->d_orow, ctx->d_ocol, nv, ctx->d_vline));
     // ---- graph moments for the roofline model (properties of the graph, not results of the path)
     KOMB_TRY(graph_moments(ctx, ctx->d_deg_i, nv, ctx->d_osrc, ctx->d_ocol, ne, ctx->d_orow, ctx->g_mom));
     KOMB_HIP(ctx, hipStreamSynchronize(s));
@@ -373,12 +377,12 @@ void publish_stats(komb_ctx *ctx, int64_t nv, int64_t ne)
 void graph_free(komb_ctx *ctx)
 {
     void *all[] = {ctx->d_o_rowptr, ctx->d_o_col, ctx->d_o2i, ctx->d_i2o, ctx->d_deg_i, ctx->d_orow, ctx->d_ocol, ctx->d_osrc,
-                   ctx->d_ceu, ctx->d_cev, ctx->d_canon2e, ctx->d_deg, ctx->d_core};
+                   ctx->d_ceu, ctx->d_cev, ctx->d_canon2e, ctx->d_vline, ctx->d_deg, ctx->d_core};
     truss_free(ctx);                                     // (its canonical endpoint arrays may BE d_ceu / d_cev: released first)
     for (void *p : all) if (p) (void)hipFree(p);
     ctx->d_o_rowptr = nullptr; ctx->d_o_col = nullptr; ctx->d_o2i = ctx->d_i2o = nullptr;
     ctx->d_deg_i = nullptr; ctx->d_orow = nullptr; ctx->d_ocol = ctx->d_osrc = nullptr;
-    ctx->d_ceu = ctx->d_cev = nullptr; ctx->d_canon2e = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
+    ctx->d_ceu = ctx->d_cev = nullptr; ctx->d_canon2e = nullptr; ctx->d_vline = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
     for (auto &m : ctx->g_mom) m = 0;
     ctx->pool.clear();                                   // scratch sized for the old graph
@@ -411,9 +415,15 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
         KOMB_HIP(ctx, sc.get(&d_k1, (size_t)nk));
         KOMB_HIP(ctx, sc.get(&d_bad, 1));
         KOMB_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), s));
+        const bool dbg = getenv("KOMB_BUILD_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "komb build: allocations %.1f ms\n", wall_ms(t_all));
+        const auto t_st = std::chrono::steady_clock::now();
+        (void)stager_get(ctx);
+        if (dbg) fprintf(stderr, "komb build: staging buffers %.1f ms\n", wall_ms(t_st));
         const auto t_h2d = std::chrono::steady_clock::now();
         KOMB_HIP(ctx, h2d_staged(ctx, d_uv, uv, (size_t)nk * sizeof(int64_t)));
         ms_h2d = wall_ms(t_h2d);
+        if (dbg) fprintf(stderr, "komb build: copy %.1f ms\n", ms_h2d);
         k_make_keys<<<grid_for(n_raw), kBlock, 0, s>>>(d_uv, n_raw, nv, vb, d_k0, d_bad);
         int bad = 0;
         KOMB_HIP(ctx, d2h(ctx, &bad, d_bad, sizeof(int)));
@@ -442,10 +452,12 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
         KOMB_HIP(ctx, resident(&ctx->d_o_col, 1));
         k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_o_rowptr, nv + 1, 0u);
     }
-    const auto t_rel = std::chrono::steady_clock::now();
     KOMB_HIP(ctx, hipStreamSynchronize(s));
+    if (getenv("KOMB_BUILD_DEBUG")) fprintf(stderr, "komb build: original CSR done at %.1f ms\n", wall_ms(t_all));
+    const auto t_rel = std::chrono::steady_clock::now();
     KOMB_TRY(finish_graph(ctx, sc, d_src_o, nv, ns, vb, d_k0, d_k1));
     const double ms_rel = wall_ms(t_rel);
+    if (getenv("KOMB_BUILD_DEBUG")) fprintf(stderr, "komb build: renumbering + oriented CSR %.1f ms\n", ms_rel);
     fail.armed = false;
     publish_stats(ctx, nv, ns / 2);
     ctx->stats.ms_build = wall_ms(t_all);

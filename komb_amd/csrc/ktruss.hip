@@ -45,6 +45,7 @@
 
 #include "truss_orient.h"
 #include "truss_tri.h"
+#include "truss_wedge.h"
 #include "truss_index.h"
 #include "truss_gather.h"
 
@@ -229,6 +230,13 @@ int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *
     return KOMB_OK;
 }
 
+int vertex_lines(komb_ctx *ctx, const uint32_t *orow, const int32_t *ocol, int64_t nv, void *lines)
+{
+    if (nv > 0) k_vertex_lines<<<grid_for(nv), kBlock, 0, ctx->stream>>>(orow, ocol, nv, (uint4 *)lines);
+    KOMB_HIP(ctx, hipGetLastError());
+    return KOMB_OK;
+}
+
 void truss_free(komb_ctx *ctx)
 {
     ctx->pool.put(ctx->d_t_eu);
@@ -298,6 +306,17 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, hipMemsetAsync(d_deg_sub, 0, (size_t)nv * sizeof(int32_t), s));
         k_sub_degree<<<grid_for(m), kBlock, 0, s>>>(d_osrc, d_ocol, m, d_deg_sub);
         d_deg = d_deg_sub;
+    }
+    // the enumeration by wedges (truss_wedge.h; the default) reads one 64-byte line per target vertex: start and length of its
+    // oriented row, pivots and a signature of the row's elements.  The whole graph's lines come with the graph (graph_build.hip),
+    // a subgraph's are made here.  KOMB_ENUM=probe selects round 3's enumeration (truss_tri.h).
+    const bool wedge = !(getenv("KOMB_ENUM") && !strcmp(getenv("KOMB_ENUM"), "probe"));
+    const uint4 *d_line = ctx->d_vline;
+    if (wedge && vmask_host) {
+        uint4 *d_line_sub = nullptr;
+        KOMB_HIP(ctx, bufs.alloc(&d_line_sub, 4 * (size_t)nv));
+        k_vertex_lines<<<grid_for(nv), kBlock, 0, s>>>(d_orow, d_ocol, nv, d_line_sub);
+        d_line = d_line_sub;
     }
     st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
@@ -381,7 +400,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (world > 1) {
         const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
         ctx->timer.start(s);
-        k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
+        if (wedge) k_wedges<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, d_line, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr, 0ull, nullptr, no_stream, tri_tv, ablate);
+        else k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
         st.ms_tri_count = ctx->timer.stop(s);
         k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
         // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
@@ -433,7 +453,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 4 * sizeof(unsigned long long), s));
             const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel, geom.nb - 1u, kChunkBits};
             ctx->timer.start(s);
-            k_triangles<TRI_SINGLE, uint32_t, false, true, true><<<gts, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr,
+            if (wedge) k_wedges<TRI_SINGLE><<<std::min(gt, 256 * KOMB_WEDGE_EU), kBlock, 0, s>>>(d_orow, d_ocol, d_line, nv, 0, ntasks, d_own, d_other, d_owndense, d_dcur, own_cap, d_ownoff, ts, tri_tv, ablate);
+            else k_triangles<TRI_SINGLE, uint32_t, false, true, true><<<gts, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr,
                                                                                       d_owndense, d_dcur, own_cap, d_ownoff, ablate, ts, tri_tv);
             st.ms_tri_fill = ctx->timer.stop(s);
             unsigned long long dc[4] = {0, 0, 0, 0};
@@ -809,7 +830,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         launches += batch;
     }
     // the peeled edges' trussness from their sub-round stamps (one coalesced pass; see Q.rlevel above)
-    if (rc == KOMB_OK) k_truss_resolve<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, m);
+    int2 *d_res = nullptr;                                           // (trussness, initial support) by internal edge id
+    KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
+    if (rc == KOMB_OK) k_truss_resolve<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, d_off2, d_res, m);
     st.ms_peel = ctx->timer.stop(s);
     KOMB_TRY(rc);
 #ifdef KOMB_STEP_TIMERS
@@ -839,7 +862,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;          // (not pool blocks: truss_free's put() ignores them)
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-        k_gather_canonical<<<grid_for(m), kBlock, 0, s>>>(ctx->d_canon2e, m, d_truss, d_off2, ctx->d_t_truss, ctx->d_t_sup);
+        k_gather_canonical<<<grid_for(m), kBlock, 0, s>>>(ctx->d_canon2e, m, d_res, ctx->d_t_truss, ctx->d_t_sup);
     } else {
         uint32_t *d_junk_rp = nullptr; int32_t *d_eu = nullptr, *d_ev = nullptr;
         unsigned long long *d_kbits = nullptr; uint32_t *d_krank = nullptr;
@@ -851,7 +874,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         ctx->d_t_eu = d_eu; ctx->d_t_ev = d_ev;
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-        k_gather_sub<<<grid_for(ctx->ne), kBlock, 0, s>>>(ctx->d_canon2e, ctx->ne, d_kbits, d_krank, d_obits, d_wrank, d_truss, d_off2, ctx->d_t_truss, ctx->d_t_sup);
+        k_gather_sub<<<grid_for(ctx->ne), kBlock, 0, s>>>(ctx->d_canon2e, ctx->ne, d_kbits, d_krank, d_obits, d_wrank, d_res, ctx->d_t_truss, ctx->d_t_sup);
     }
     st.ms_gather = ctx->timer.stop(s);
     if (getenv("KOMB_POOL_DEBUG")) {

@@ -17,24 +17,26 @@ namespace {
 // Trussness after the peel: an edge the engine peeled carries the sub-round it went in (stamp), and rlevel[] says which level
 // that sub-round worked at (PeelQueues::rlevel; stamp 0 = triangle-free = level 0); an edge a finish took over (local fixed
 // point, LDS tail) still carries its alive marker and has its value in truss[] already.  One coalesced pass instead of a
-// scattered 4-byte result store per peeled edge inside the peel (0.6 ms there at C3, 0.25 ms here).
+// scattered 4-byte result store per peeled edge inside the peel (0.6 ms there at C3, 0.25 ms here).  The pass also packs
+// the edge's initial support next to its trussness.
 __global__ __launch_bounds__(kBlock) void k_truss_resolve(const int32_t *__restrict__ stamp, const int32_t *__restrict__ rlevel,
-                                                         int32_t *__restrict__ truss, int64_t m)
+                                                         const int32_t *__restrict__ truss, const uint2 *__restrict__ off2,
+                                                         int2 *__restrict__ res, int64_t m)
 {
+    // res[e] = (trussness, the support the peel started from): ONE 8-byte word per edge for the gather's one random read
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
         const int32_t s = stamp[e];
-        if (!marker_alive(s)) truss[e] = rlevel[s] + 2;
+        res[e] = make_int2(marker_alive(s) ? truss[e] : rlevel[s] + 2, (int32_t)off2[e].y);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ canon2e, int64_t m,
-                                                             const int32_t *__restrict__ truss, const uint2 *__restrict__ off2,
+__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ canon2e, int64_t m, const int2 *__restrict__ res,
                                                              int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < m; k += (int64_t)gridDim.x * kBlock) {
-        const uint32_t e = canon2e[k];
-        tr_out[k] = truss[e];
-        sup_out[k] = (int32_t)off2[e].y;
+        const int2 r = res[canon2e[k]];
+        tr_out[k] = r.x;
+        sup_out[k] = r.y;
     }
 }
 
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__r
 __global__ __launch_bounds__(kBlock) void k_gather_sub(const uint32_t *__restrict__ canon2e, int64_t ne,
                                                        const unsigned long long *__restrict__ kbits, const uint32_t *__restrict__ krank,
                                                        const unsigned long long *__restrict__ obits, const uint32_t *__restrict__ wrank,
-                                                       const int32_t *__restrict__ truss, const uint2 *__restrict__ off2,
+                                                       const int2 *__restrict__ res,
                                                        int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < ne; k += (int64_t)gridDim.x * kBlock) {
@@ -52,8 +54,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_sub(const uint32_t *__restric
         const uint32_t c = krank[k >> 6] + (uint32_t)__popcll(kw & ((1ull << (k & 63)) - 1ull));
         const uint32_t e = canon2e[k];
         const uint32_t o = wrank[e >> 6] + (uint32_t)__popcll(obits[e >> 6] & ((1ull << (e & 63u)) - 1ull));
-        tr_out[c] = truss[o];
-        sup_out[c] = (int32_t)off2[o].y;
+        const int2 r = res[o];
+        tr_out[c] = r.x;
+        sup_out[c] = r.y;
     }
 }
 
