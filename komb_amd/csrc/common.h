@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -178,6 +179,7 @@ struct DevPool {
     struct Block { void *p; size_t bytes; bool used; };
     std::vector<Block> blocks;
     size_t n_malloc = 0, n_trim = 0;                 // statistics (KOMB_POOL_DEBUG)
+    double ms_malloc = 0.0;                          // host time inside hipMalloc
     hipError_t get(void **out, size_t bytes)
     {
         if (bytes == 0) bytes = 16;
@@ -188,7 +190,9 @@ struct DevPool {
         if (best >= 0) { blocks[best].used = true; *out = blocks[best].p; return hipSuccess; }
         void *q = nullptr;
         ++n_malloc;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&q, bytes);
+        ms_malloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (e != hipSuccess) {                       // give cached blocks back and retry once
             ++n_trim;
             trim();

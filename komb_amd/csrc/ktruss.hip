@@ -829,10 +829,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         }, &batch);
         launches += batch;
     }
-    // the peeled edges' trussness from their sub-round stamps (one coalesced pass; see Q.rlevel above)
-    int2 *d_res = nullptr;                                           // (trussness, initial support) by internal edge id
-    KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
-    if (rc == KOMB_OK) k_truss_resolve<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, d_off2, d_res, m);
     st.ms_peel = ctx->timer.stop(s);
     KOMB_TRY(rc);
 #ifdef KOMB_STEP_TIMERS
@@ -851,13 +847,17 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.max_trussness = ctx->h_ctrl[0].max_level + 2;
     for (int i = 0; i < 2; ++i) { bufs.release(Q.light[i]); bufs.release(Q.heavy[i]); bufs.release(Q.live[i]); }
     bufs.release(Q.code);
-    bufs.release(d_stamp); bufs.release(d_sup); bufs.release(d_inc); bufs.release(Q.rlevel);
+    bufs.release(d_sup); bufs.release(d_inc);
 
     // ---- canonical-order results with original vertex ids: the graph carries its canonical edge list and the internal edge
     // id of every canonical edge (graph_build.hip), so the whole-graph gather is one pass; a subgraph's results are the
     // kept canonical edges in order, each reading its kept oriented slot's values
     phase.next("truss: canonical gather");
     ctx->timer.start(s);
+    // the peeled edges' trussness from their sub-round stamps, packed with the initial support (one coalesced pass; see Q.rlevel above)
+    int2 *d_res = nullptr;                                           // (trussness, initial support) by internal edge id
+    KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
+    k_truss_resolve<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, d_off2, d_res, m);
     if (!vmask_host) {
         ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;          // (not pool blocks: truss_free's put() ignores them)
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
@@ -880,7 +880,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (getenv("KOMB_POOL_DEBUG")) {
         size_t held = 0;
         for (const auto &b : ctx->pool.blocks) held += b.bytes;
-        fprintf(stderr, "komb pool: %zu blocks, %.2f GB held, %zu hipMalloc calls so far, %zu trims\n", ctx->pool.blocks.size(), held / 1e9, ctx->pool.n_malloc, ctx->pool.n_trim);
+        fprintf(stderr, "komb pool: %zu blocks, %.2f GB held, %zu hipMalloc calls so far (%.1f ms inside them), %zu trims\n", ctx->pool.blocks.size(), held / 1e9, ctx->pool.n_malloc, ctx->pool.ms_malloc, ctx->pool.n_trim);
     }
     ctx->t_ne = m;
     ctx->truss_done = true;

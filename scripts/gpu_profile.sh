@@ -5,7 +5,7 @@ tag=$1; cfg=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/profiles
 export KOMB_PROF_OUT=gpurun_out/profiles
-cmd="python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-build"
+cmd="python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-build --no-extras"
 timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt -- $cmd > gpurun_out/${tag}_kt.log 2>&1 || exit 1
 timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $cmd > gpurun_out/${tag}_fetch.log 2>&1 || exit 1
 timeout -k 10 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- $cmd > gpurun_out/${tag}_write.log 2>&1 || exit 1

@@ -32,7 +32,7 @@ def short(name):
         return "k_local_step<Truss>" if "TrussLocal" in n else "k_local_step<Core>"
     if n.startswith("k_triangles<2") and n.split("(")[0].rstrip().endswith("true, true>"):
         return "k_triangles<stream>"
-    for key, nice in (("k_triangles<0", "k_triangles<count>"), ("k_triangles<1", "k_triangles<fill>"),
+    for key, nice in (("k_wedges<2", "k_wedges<stream>"), ("k_wedges<0", "k_wedges<count>"), ("k_triangles<0", "k_triangles<count>"), ("k_triangles<1", "k_triangles<fill>"),
                       ("k_triangles<2", "k_triangles<single>"), ("k_compact_inc<", "k_compact_inc")):
         if n.startswith(key):
             return nice
