@@ -5,6 +5,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -52,11 +53,14 @@ komb_ctx *komb_create(const komb_opts *opts)
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctrl, 2 * sizeof(PeelCtrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_local, 2 * sizeof(LocalCtrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_stage, kStageBytes, hipHostMallocDefault);
-    // The library works on the device's default (legacy) stream.  A stream of its own (hipStreamNonBlocking) was tried in
-    // order to run independent work beside the peel: there was nothing to gain (both sides are bound by HBM), and
-    // with two processes sharing one GPU the peel's launch-to-launch hand-over of its control block became unreliable on it
-    // (stale control blocks; tests/test_distributed.py caught it), so everything stays on the default stream.
+    // Every context works on a stream of its own: a BLOCKING one (hipStreamCreate, not hipStreamNonBlocking), so that the
+    // legacy default stream -- the synchronous hipMemcpy calls of the fetch entry points, a host that launches work of its own
+    // there -- still orders with it, while two contexts (two host threads, or a host's RCCL stream beside the library) no
+    // longer serialise on one queue.  (Round 2 tried a non-blocking stream before the peel's launches carried their sequence
+    // word and saw stale control blocks with two processes on one GPU; with the sequence word the engine no longer depends
+    // on launch-order visibility)  KOMB_NULL_STREAM=1 puts the context back on the default stream.
     ctx->stream = nullptr;
+    if (e == hipSuccess && !getenv("KOMB_NULL_STREAM")) { e = hipStreamCreate(&ctx->stream); ctx->own_stream = e == hipSuccess; }
     if (e == hipSuccess && !ctx->timer.init()) e = hipErrorUnknown;
     if (e != hipSuccess) {
         ctx->err = std::string("device initialisation failed: ") + hipGetErrorString(e);
@@ -75,6 +79,7 @@ void komb_destroy(komb_ctx *ctx)
         stager_free(ctx);
         ctx->pool.clear();
         ctx->timer.destroy();
+        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
         if (ctx->h_local) (void)hipHostFree(ctx->h_local);
         if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);

@@ -233,7 +233,8 @@ struct komb_ctx {
     std::string err;
     bool device_ok = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // the context's own blocking stream (api.cpp)
+    bool own_stream = false;
     komb::Timer timer;
 
     // ---- resident simple graph.  Two id spaces:
