@@ -250,6 +250,8 @@ struct komb_ctx {
     int32_t  *d_ocol = nullptr, *d_osrc = nullptr; // [ne (+8)] target / source of every oriented slot
     int32_t  *d_ceu = nullptr, *d_cev = nullptr;   // [ne] canonical edge list: ORIGINAL ids, (min,max) lexicographic
     uint32_t *d_canon2e = nullptr;           // [ne] internal edge id of every canonical edge
+    void     *d_wtasks = nullptr;            // [n_wtasks] task descriptors of the triangle enumeration (truss_wedge.h)
+    int64_t   n_wtasks = 0;
     uint4    *d_vline = nullptr;             // [4*nv] one 64-byte line per vertex: start, length, pivots and signature of its oriented row (truss_wedge.h)
     int64_t g_mom[5] = {0, 0, 0, 0, 0};      // graph moments of the whole graph (k_graph_moments), computed with the graph
 
@@ -367,6 +369,7 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
 void graph_free(komb_ctx *ctx);
 void stager_free(komb_ctx *ctx);
 // sum d^2, sum min(d,d), max d, (unused), sum d+ + d+ of an oriented graph (ktruss.hip; the build calls it once per graph)
+int build_tasks(komb_ctx *ctx, const uint32_t *orow, int64_t nv, bool resident, void **tasks, int64_t *ntasks);   // ktruss.hip
 int vertex_lines(komb_ctx *ctx, const uint32_t *orow, const int32_t *ocol, int64_t nv, void *lines);   // ktruss.hip (k_vertex_lines)
 int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *osrc, const int32_t *ocol, int64_t m,
                   const uint32_t *orow, int64_t out[5]);

@@ -10,7 +10,8 @@
 //     internal edge id is the oriented slot.  In degree order the (degree,id) orientation is an id compare, so no run has
 //     to orient anything;
 //   * the canonical edge list (original ids, (min,max)-lexicographic) and, for every canonical edge, its internal edge id;
-//   * one 64-byte line per vertex describing its oriented row to the triangle enumeration (truss_wedge.h).
+//   * one 64-byte line per vertex describing its oriented row to the triangle enumeration, and that enumeration's task
+//     table (truss_wedge.h).
 //
 // How: both directions of every raw pair as 64-bit keys (src << vb | dst, vb = bits of a vertex id), radix-sorted on the
 // 2*vb significant bits and uniqued -> original CSR.  Vertices are radix-sorted (stably) by degree -> the renumbering.
@@ -351,6 +352,7 @@ int finish_graph(komb_ctx *ctx, Scratch &sc, const int32_t *d_src_o, int64_t nv,
     }
     // ---- the oriented rows' lines for the triangle enumeration (truss_wedge.h)
     KOMB_TRY(vertex_lines(ctx, ctx->d_orow, ctx->d_ocol, nv, ctx->d_vline));
+    KOMB_TRY(build_tasks(ctx, ctx->d_orow, nv, true, &ctx->d_wtasks, &ctx->n_wtasks));
     // ---- graph moments for the roofline model (properties of the graph, not results of the path)
     KOMB_TRY(graph_moments(ctx, ctx->d_deg_i, nv, ctx->d_osrc, ctx->d_ocol, ne, ctx->d_orow, ctx->g_mom));
     KOMB_HIP(ctx, hipStreamSynchronize(s));
@@ -377,12 +379,12 @@ void publish_stats(komb_ctx *ctx, int64_t nv, int64_t ne)
 void graph_free(komb_ctx *ctx)
 {
     void *all[] = {ctx->d_o_rowptr, ctx->d_o_col, ctx->d_o2i, ctx->d_i2o, ctx->d_deg_i, ctx->d_orow, ctx->d_ocol, ctx->d_osrc,
-                   ctx->d_ceu, ctx->d_cev, ctx->d_canon2e, ctx->d_vline, ctx->d_deg, ctx->d_core};
+                   ctx->d_ceu, ctx->d_cev, ctx->d_canon2e, ctx->d_vline, ctx->d_wtasks, ctx->d_deg, ctx->d_core};
     truss_free(ctx);                                     // (its canonical endpoint arrays may BE d_ceu / d_cev: released first)
     for (void *p : all) if (p) (void)hipFree(p);
     ctx->d_o_rowptr = nullptr; ctx->d_o_col = nullptr; ctx->d_o2i = ctx->d_i2o = nullptr;
     ctx->d_deg_i = nullptr; ctx->d_orow = nullptr; ctx->d_ocol = ctx->d_osrc = nullptr;
-    ctx->d_ceu = ctx->d_cev = nullptr; ctx->d_canon2e = nullptr; ctx->d_vline = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
+    ctx->d_ceu = ctx->d_cev = nullptr; ctx->d_canon2e = nullptr; ctx->d_vline = nullptr; ctx->d_wtasks = nullptr; ctx->n_wtasks = 0; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
     for (auto &m : ctx->g_mom) m = 0;
     ctx->pool.clear();                                   // scratch sized for the old graph

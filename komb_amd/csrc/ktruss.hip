@@ -230,6 +230,30 @@ int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *
     return KOMB_OK;
 }
 
+// the task table of the wedge enumeration for an oriented CSR (truss_wedge.h); *tasks is a pool block (bufs) or, with
+// resident = true, a hipMalloc'd array the caller keeps
+int build_tasks(komb_ctx *ctx, const uint32_t *orow, int64_t nv, bool resident, void **tasks, int64_t *ntasks)
+{
+    // light vertices per task: kWedgeV, fewer when that leaves the chip without enough tasks (>= 4 per resident wavefront)
+    const int group = (int)std::max<int64_t>(1, std::min<int64_t>(kWedgeV, nv / (256 * KOMB_WEDGE_EU * kTriWaves * 4)));
+    DevBufs bufs(ctx);
+    hipStream_t s = ctx->stream;
+    uint32_t *d_cnt = nullptr, *d_toff = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)nv + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)nv + 1));
+    k_task_count<<<grid_for(nv + 1), kBlock, 0, s>>>(orow, nv, group, d_cnt);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_toff, nv + 1));
+    uint32_t n = 0;
+    KOMB_HIP(ctx, d2h(ctx, &n, d_toff + nv, sizeof(uint32_t)));
+    uint2 *d_t = nullptr;
+    if (resident) KOMB_HIP(ctx, hipMalloc((void **)&d_t, ((size_t)n + 1) * sizeof(uint2)));
+    else KOMB_HIP(ctx, ctx->pool.get((void **)&d_t, ((size_t)n + 1) * sizeof(uint2)));
+    if (nv > 0) k_task_fill<<<grid_for(nv), kBlock, 0, s>>>(orow, nv, group, d_toff, d_t);
+    KOMB_HIP(ctx, hipStreamSynchronize(s));                          // (d_toff goes back to the pool when this returns)
+    *tasks = d_t; *ntasks = (int64_t)n;
+    return KOMB_OK;
+}
+
 int vertex_lines(komb_ctx *ctx, const uint32_t *orow, const int32_t *ocol, int64_t nv, void *lines)
 {
     if (nv > 0) k_vertex_lines<<<grid_for(nv), kBlock, 0, ctx->stream>>>(orow, ocol, nv, (uint4 *)lines);
@@ -318,6 +342,16 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         k_vertex_lines<<<grid_for(nv), kBlock, 0, s>>>(d_orow, d_ocol, nv, d_line_sub);
         d_line = d_line_sub;
     }
+    // ... and its tasks (runs of light vertices, single heavy rows, parts of rows too long to stage: truss_wedge.h)
+    const uint2 *d_wtasks = (const uint2 *)ctx->d_wtasks;
+    int64_t n_wtasks = ctx->n_wtasks;
+    if (wedge && vmask_host) {
+        void *t = nullptr;
+        KOMB_TRY(build_tasks(ctx, d_orow, nv, false, &t, &n_wtasks));
+        bufs.owned.push_back(t);                                     // (a pool block: back to the pool with the rest)
+        d_wtasks = (const uint2 *)t;
+    }
+    const int gw = grid_for(n_wtasks, kTriWaves);
     st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
 
@@ -398,9 +432,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     else KOMB_HIP(ctx, zero_counts());
     bool have_counts = false;                  // d_cnt holds the supports (and d_mom[5] their sum)
     if (world > 1) {
-        const int64_t task_lo = ntasks * rank / world, task_hi = ntasks * (rank + 1) / world;
+        const int64_t nt = wedge ? n_wtasks : ntasks;
+        const int64_t task_lo = nt * rank / world, task_hi = nt * (rank + 1) / world;
         ctx->timer.start(s);
-        if (wedge) k_wedges<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, d_line, nv, task_lo, task_hi, d_own, d_other, nullptr, nullptr, 0ull, nullptr, no_stream, tri_tv, ablate);
+        if (wedge) k_wedges<TRI_COUNT><<<gw, kBlock, 0, s>>>(d_orow, d_ocol, d_line, d_wtasks, task_lo, task_hi, d_own, d_other, nullptr, nullptr, 0ull, nullptr, no_stream, nullptr, ablate);
         else k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
         st.ms_tri_count = ctx->timer.stop(s);
         k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
@@ -448,18 +483,24 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         bool ok = bufs.alloc(&d_key, (size_t)rec_cap) == hipSuccess && bufs.alloc(&d_val, (size_t)rec_cap) == hipSuccess &&
                   bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess && bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess &&
                   bufs.alloc(&d_dcur, 4) == hipSuccess;
+        // the wedge enumeration's wave-private record scratch (truss_wedge.h); without the memory for it a sub-range whose
+        // records outgrow the LDS buffer gives up its dense block, as in round 3
+        const int gws = std::min(gw, 256 * KOMB_WEDGE_EU);
+        uint2 *d_scratch = nullptr;
+        if (ok && wedge && !getenv("KOMB_NO_REC_SCRATCH") && bufs.alloc(&d_scratch, (size_t)gws * kTriWaves * kScratchRec) != hipSuccess) { (void)hipGetLastError(); d_scratch = nullptr; }
         unsigned long long n_claimed = 0;
         if (ok) {
             KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 4 * sizeof(unsigned long long), s));
             const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel, geom.nb - 1u, kChunkBits};
             ctx->timer.start(s);
-            if (wedge) k_wedges<TRI_SINGLE><<<std::min(gt, 256 * KOMB_WEDGE_EU), kBlock, 0, s>>>(d_orow, d_ocol, d_line, nv, 0, ntasks, d_own, d_other, d_owndense, d_dcur, own_cap, d_ownoff, ts, tri_tv, ablate);
+            if (wedge) k_wedges<TRI_SINGLE><<<gws, kBlock, 0, s>>>(d_orow, d_ocol, d_line, d_wtasks, 0, n_wtasks, d_own, d_other, d_owndense, d_dcur, own_cap, d_ownoff, ts, d_scratch, ablate);
             else k_triangles<TRI_SINGLE, uint32_t, false, true, true><<<gts, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr,
                                                                                       d_owndense, d_dcur, own_cap, d_ownoff, ablate, ts, tri_tv);
             st.ms_tri_fill = ctx->timer.stop(s);
             unsigned long long dc[4] = {0, 0, 0, 0};
             KOMB_HIP(ctx, d2h(ctx, dc, d_dcur, sizeof(dc)));
             n_claimed = dc[2];
+            bufs.release(d_scratch);
             if (getenv("KOMB_TRI_DEBUG"))
                 fprintf(stderr, "komb triangles: stream build: %llu record positions claimed of %llu, dense own-role region %llu entries claimed of %llu, %llu task ranges overflowed their record buffer\n",
                         dc[2], rec_cap, dc[0], own_cap, dc[1]);

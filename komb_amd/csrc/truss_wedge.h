@@ -32,6 +32,13 @@ constexpr int kLineWords = 16;                  // 64 bytes per vertex: start, l
 constexpr int kSigBlocks = 4;
 constexpr int kPivots = 6;                      // the row's elements at positions seg, 2 seg, ... 6 seg, seg = ceil(length / 7)
 constexpr int kWCand = 128;                     // parked candidates per wavefront
+#ifndef KOMB_WEDGE_V
+#define KOMB_WEDGE_V 32
+#endif
+constexpr int kWedgeV = KOMB_WEDGE_V;           // light vertices per task at most (<= 63: lane l holds orow[v0 + l]); same-box A/B at
+                                                // |E| = 100M: 8: 6.77 ms, 16: 5.76-6.0, 32: 5.46-5.69, 48: 5.58, 63: 5.58
+static_assert(kWedgeV >= 1 && kWedgeV <= 63, "a task's row pointers live in the lanes of one wavefront");
+constexpr uint32_t kScratchRec = (uint32_t)kTriCap * (kTriCap - 1) / 2 + 128;     // records of a staged sub-range at most (+ one LDS buffer's slack)
 
 __device__ __forceinline__ void sig_slot(int32_t c, uint32_t &blk, unsigned long long &mask)
 {
@@ -70,6 +77,56 @@ __global__ __launch_bounds__(kBlock) void k_vertex_lines(const uint32_t *__restr
     }
 }
 
+// ---- the enumeration's tasks.  A task is a run of consecutive source vertices -- or, for a row too long to stage, one of
+// several PARTS of that row's owned edges.  Vertex ids are (degree,id) ranks, so heavy rows are neighbours: a fixed number
+// of vertices per task would hand one wavefront sixteen hub rows in a row (a K_250 inside a sparse graph: 12.7 ms of an
+// otherwise 1 ms enumeration on 16 wavefronts).  Rule: a row of kHeavyRow slots or more is a task of its own; lighter
+// vertices are grouped up to `group` (<= kWedgeV) of them, never across a multiple of `group`; a row beyond the LDS budget
+// (unstaged) is cut into parts of about kPartPairs wedges, its 64-edge batches dealt round-robin to the parts.
+// Descriptor: x = first vertex, y = vertices | part << 6 | parts << 19.
+#ifndef KOMB_HEAVY_ROW
+#define KOMB_HEAVY_ROW 32
+#endif
+constexpr uint32_t kHeavyRow = KOMB_HEAVY_ROW;
+constexpr unsigned long long kPartPairs = 16384;
+constexpr uint32_t kMaxParts = 8191;
+
+__device__ __forceinline__ bool task_starts(const uint32_t *__restrict__ orow, int64_t v, int group)
+{
+    if (v % group == 0) return true;
+    if (orow[v + 1] - orow[v] >= kHeavyRow) return true;
+    return orow[v] - orow[v - 1] >= kHeavyRow;                     // (v > 0 here)
+}
+
+__global__ __launch_bounds__(kBlock) void k_task_count(const uint32_t *__restrict__ orow, int64_t nv, int group, uint32_t *__restrict__ cnt)
+{
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) {
+        uint32_t c = 0;
+        if (v < nv && task_starts(orow, v, group)) {
+            const unsigned long long d = orow[v + 1] - orow[v];
+            c = 1;
+            if (d > (unsigned long long)kTriCap) {
+                const unsigned long long parts = (d * (d - 1ull) / 2ull + kPartPairs - 1ull) / kPartPairs;
+                const unsigned long long batches = (d + kWave - 1ull) / kWave;
+                c = (uint32_t)min(min(parts, batches), (unsigned long long)kMaxParts);
+            }
+        }
+        cnt[v] = c;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_task_fill(const uint32_t *__restrict__ orow, int64_t nv, int group, const uint32_t *__restrict__ toff,
+                                                      uint2 *__restrict__ tasks)
+{
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
+        const uint32_t n = toff[v + 1] - toff[v];
+        if (!n) continue;
+        uint32_t nverts = 1;
+        while (v + nverts < nv && nverts < (uint32_t)group && !task_starts(orow, v + nverts, group)) ++nverts;
+        for (uint32_t p = 0; p < n; ++p) tasks[toff[v] + p] = make_uint2((uint32_t)v, nverts | (p << 6) | (n << 19));
+    }
+}
+
 // MODE: TRI_COUNT (supports only: own[] by plain stores, other[] by atomics) or TRI_SINGLE (the record-stream build:
 // own-role entries as dense per-task blocks, everything else as records; truss_tri.h)
 #ifndef KOMB_WEDGE_EU
@@ -77,17 +134,21 @@ __global__ __launch_bounds__(kBlock) void k_vertex_lines(const uint32_t *__restr
 #endif
 template <int MODE>
 __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
-                                                                   const uint4 *__restrict__ line,
-                                                                   int64_t nv, int64_t task_lo, int64_t task_hi,
+                                                                   const uint4 *__restrict__ line, const uint2 *__restrict__ tasks,
+                                                                   int64_t task_lo, int64_t task_hi,
                                                                    uint32_t *own, uint32_t *other,
                                                                    int2 *__restrict__ dense, unsigned long long *dense_cursor, unsigned long long dense_cap,
-                                                                   unsigned long long *__restrict__ ownoff, TriStream ts, int tv, int ablate)
+                                                                   unsigned long long *__restrict__ ownoff, TriStream ts, uint2 *__restrict__ scratch, int ablate)
 {
+    // scratch (TRI_SINGLE): kScratchRec record slots per wavefront of the grid.  A staged sub-range keeps one 8-byte record per
+    // triangle until it is done (its dense own-role block needs every cursor first); what the LDS buffer cannot hold moves
+    // here -- wave-private, written and read back as a stream -- instead of giving the block up.  A staged sub-range has at most
+    // C(kTriCap, 2) triangles, which fits: only rows too long to stage send their own-role entries through the record stream.
     // ablate (debug builds, KOMB_TRI_ABLATE; breaks results on purpose): 1 = survivors are dropped (no look-up), 2 = no candidate tests, 4 = no line loads, 8 = look-ups find nothing
     constexpr bool STREAM = MODE == TRI_SINGLE;
     __shared__ int32_t sh_col[kTriWaves][kTriCap];
     __shared__ uint32_t sh_cnt[kTriWaves][kTriCap];
-    __shared__ uint32_t sh_orow[kTriWaves][kTriV + 1];
+    __shared__ uint32_t sh_orow[kTriWaves][kWedgeV + 1];
     __shared__ uint32_t sh_pref[kTriWaves][kWave];
     __shared__ uint32_t sh_rend[kTriWaves][kWave];
     __shared__ uint2 sh_rec[kTriWaves][kTriRec];
@@ -128,9 +189,12 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
         if (has && q < ts.cap) { ts.key[q] = key; ts.val[q] = val; }
     };
 
-    for (int64_t task = task_lo + gw; task < task_hi; task += nw) {
-      const int64_t v0t = task * tv;
-      const int nvt_all = (int)min((int64_t)tv, nv - v0t);
+    // the heaviest tasks (the last ones: hub rows) go first
+    for (int64_t task = task_hi - 1 - gw; task >= task_lo; task -= nw) {
+      const uint2 td = tasks[task];
+      const int64_t v0t = (int64_t)td.x;
+      const int nvt_all = (int)(td.y & 63u);
+      const uint32_t part = (td.y >> 6) & kMaxParts, nparts = td.y >> 19;       // (nparts > 1: one unstaged row, this task owns its batches part, part + nparts, ...)
       const uint32_t myrow = (lane <= nvt_all) ? orow[v0t + lane] : 0u;       // lane l holds orow[v0t + l]
       // A task whose rows exceed the LDS budget is cut into sub-ranges of consecutive vertices that fit; a single row
       // longer than the budget runs unstaged (its candidates are read from global memory, all three roles are records).
@@ -183,6 +247,8 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
 
         // ---- staged sub-range: record = (e_rel | i_rel << 8 | cursor_e << 16 | cursor_i << 24, j); see truss_tri.h
         uint32_t n_rec = 0, n_done = 0;                         // wave-uniform: records, records whose third role is written
+        uint32_t n_scr = 0;                                     // wave-uniform: records moved to the wavefront's scratch
+        uint2 *scr = scratch ? scratch + (size_t)gw * kScratchRec : nullptr;
         bool spilled = false;                                   // wave-uniform: the own-role entries are records too
         auto drain = [&](uint32_t lo, uint32_t hi, bool third, bool own_role) {
             __builtin_amdgcn_wave_barrier();
@@ -266,11 +332,15 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
                     }
                     if (n_rec > (uint32_t)kTriRec - kWave) {
                         // the buffer is full: the sub-range gives up its dense block -- everything kept so far, and what follows, become records
-                        if (!spilled) {
+                        if (!spilled && scr && n_scr + n_rec <= kScratchRec) {
+                            drain(n_done, n_rec, true, false);                    // their third-role records go out now
+                            for (uint32_t x = (uint32_t)lane; x < n_rec; x += kWave) scr[n_scr + x] = s_rec[x];
+                            n_scr += n_rec;
+                            if (lane == 0) atomicAdd(dense_cursor + 1, 1ull);     // statistics
+                        } else if (!spilled) {
                             drain(n_done, n_rec, true, false);
                             drain(0, n_rec, false, true);
                             spilled = true;
-                            if (lane == 0) atomicAdd(dense_cursor + 1, 1ull);     // statistics
                         } else drain(n_done, n_rec, true, true);
                         n_rec = 0; n_done = 0;
                     }
@@ -280,7 +350,7 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
             n_cand = 0;
         };
 
-        for (uint32_t p0 = 0; p0 < E; p0 += kWave) {
+        for (uint32_t p0 = part * (uint32_t)kWave; p0 < E; p0 += nparts * (uint32_t)kWave) {
             // lane <-> owned edge e = S0 + p0 + lane = (a -> b); its candidates are the slots of row a behind it
             const uint32_t rel = p0 + (uint32_t)lane;
             uint32_t ncand = 0, rend = 0;
@@ -339,7 +409,7 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
         }
         if (!staged) {
             flush_tris();
-            if (MODE == TRI_SINGLE) for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { own[S0 + k] = 0u; ownoff[S0 + k] = kOwnSpill; }
+            if (MODE == TRI_SINGLE && part == 0u) for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { own[S0 + k] = 0u; ownoff[S0 + k] = kOwnSpill; }
             continue;
         }
         if (MODE == TRI_SINGLE) { drain(n_done, n_rec, true, spilled); n_done = n_rec; }
@@ -377,17 +447,27 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
         if (to_dense) {
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { own[S0 + k] = s_cnt[k]; ownoff[S0 + k] = base + (uint32_t)s_col[k]; }
-            for (uint32_t b0 = 0; b0 < n_rec; b0 += kWave) {
+            for (uint32_t b0 = 0; b0 < n_rec + n_scr; b0 += kWave) {
                 const uint32_t x = b0 + (uint32_t)lane;
-                if (x < n_rec) {
-                    const uint2 rc = s_rec[x];
+                if (x < n_rec + n_scr) {
+                    const uint2 rc = x < n_rec ? s_rec[x] : scr[x - n_rec];
                     const uint32_t er = rc.x & 0xFFu, ir = (rc.x >> 8) & 0xFFu;
                     dense[base + (uint32_t)s_col[er] + ((rc.x >> 16) & 0xFFu)] = make_int2((int)(S0 + ir), (int)rc.y);
                     dense[base + (uint32_t)s_col[ir] + (rc.x >> 24)] = make_int2((int)(S0 + er), (int)rc.y);
                 }
             }
         } else {
-            if (MODE == TRI_SINGLE && !spilled) drain(0, n_rec, false, true);      // no room in the region: own-role entries of every record become records
+            if (MODE == TRI_SINGLE && !spilled) {                // no room in the region: own-role entries of every record become records
+                drain(0, n_rec, false, true);
+                for (uint32_t b0 = 0; b0 < n_scr; b0 += kWave) {
+                    const uint32_t x = b0 + (uint32_t)lane;
+                    const bool has = x < n_scr;
+                    const uint2 rc = has ? scr[x] : make_uint2(0u, 0u);
+                    const uint32_t e = S0 + (rc.x & 0xFFu), i = S0 + ((rc.x >> 8) & 0xFFu), jj = rc.y;
+                    rec_append(has, e, make_int2((int)i, (int)jj));
+                    rec_append(has, i, make_int2((int)e, (int)jj));
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
                 own[S0 + k] = MODE == TRI_SINGLE ? 0u : s_cnt[k];  // (stream: those entries are records, counted with the sorted stream)
