@@ -452,6 +452,8 @@ def main():
                                 "sweeps": core_stats["core_local_sweeps"], "ms": core_stats["ms_core_local"]},
                       "alg_bytes": 16 * nv + 24 * ne,
                       "GBps": (16 * nv + 24 * ne) / (core_ms * 1e-3) / 1e9 if core_ms > 0 else None},
+            # every KOMB_* switch the run saw (none changes a result; some change which engine runs, e.g. KOMB_SHARD_PEEL, KOMB_ENUM)
+            "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("KOMB_")},
             "runtruss_faithful": faithful,
             "first_call": first_call,
             "c2": c2_block,

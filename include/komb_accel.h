@@ -182,7 +182,7 @@ int komb_corea_ranks(komb_ctx *ctx, const int32_t *degree, const int32_t *corene
  * reference fills `order` / `modes`; the first *n_block entries are the densest block (rows: side 0, columns:
  * side 1), *max_density its density.  Ties between equal priorities are resolved exactly as the reference's heap
  * resolves them (the same sift operations in the same order), which makes the peel sequential: the device runs
- * it on one lane (heaps in LDS up to 4096 nodes).  Two defects of the reference are not reproduced: removed[][]
+ * it on one lane (heaps in LDS up to 4096 nodes; graphs above 2^17 nodes are refused with KOMB_ERR_LIMIT).  Two defects of the reference are not reproduced: removed[][]
  * read uninitialised (:104-108) and `cols` sized by the number of rows (:191). */
 int komb_densest_block(komb_ctx *ctx, const double *suspiciousness, int32_t *order, int32_t *side,
                        int64_t *n_block, double *max_density);

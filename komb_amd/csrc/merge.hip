@@ -25,6 +25,8 @@ namespace komb {
 namespace {
 
 constexpr int kMergeLds = 4096;                 // nodes up to which both heaps live in LDS (2 x (4 + 4 + 8) bytes each + flags)
+constexpr int kMergeMaxNodes = 1 << 17;         // above it komb_densest_block returns KOMB_ERR_LIMIT (a few seconds of one lane's time at most)
+static_assert(2 * kMergeLds * (8 + 4 + 4 + 1) <= 160 * 1024, "the LDS heaps are sized for gfx950's 160 KB of LDS per workgroup");
 
 // priorities as the reference builds them (src/CombineCoreA.h:52-85): the score (or 0), then one +1.0 per incident slot
 __global__ __launch_bounds__(kBlock) void k_merge_prio(const uint32_t *__restrict__ rowptr, int64_t nv, const double *__restrict__ susp,
@@ -150,7 +152,10 @@ int merge_run(komb_ctx *ctx, const double *susp_host, int32_t *order, int32_t *s
     if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_densest_block: no graph loaded");
     const int64_t nv = ctx->nv;
     if (nv > 0 && (!order || !side)) KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_densest_block: null output");
-    if (nv > 0x3FFFFFFF) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "komb_densest_block: %lld nodes exceed the 2^30 limit of the removal order", (long long)nv);
+    // Above kMergeLds nodes the two heaps live in global memory and ONE lane walks them: ~35 us per step, 2 nv steps -- 0.7 s for
+    // 20 000 vertices, minutes for millions, on a stream nothing can cancel.  The exact tie order makes the peel sequential
+    // (DESIGN.md section 9), so large graphs are refused rather than left to occupy the device.
+    if (nv > kMergeMaxNodes) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "komb_densest_block: %lld nodes; the exact (sequential) densest-block peel is limited to %d", (long long)nv, kMergeMaxNodes);
     if (n_block) *n_block = 0;
     if (max_density) *max_density = 0.0;
     if (nv == 0) return KOMB_OK;

@@ -92,12 +92,14 @@ static __global__ void k_shard_scan_reset(uint32_t *words)
     if (threadIdx.x == 0) { words[0] = 0u; words[1] = 0x7FFFFFFFu; }
 }
 
-// the rank's line of the header exchange: hdr[rank] = its count, hdr[world + rank] = its smallest live key above the level
-static __global__ void k_shard_header(uint32_t *hdr, int world, int rank, const uint32_t *cnt, const uint32_t *mn, uint32_t *words)
+// the rank's line of the header exchange: hdr[rank] = its count, hdr[world + rank] = its smallest live key above the level,
+// hdr[2 world + rank] = its STATUS (0, or 1 once something failed on this rank: every rank learns of it with the next header and
+// all of them leave together, instead of one returning and the others waiting in a collective that will never complete)
+static __global__ void k_shard_header(uint32_t *hdr, int world, int rank, const uint32_t *cnt, const uint32_t *mn, uint32_t *words, uint32_t status)
 {
-    for (int i = (int)threadIdx.x; i < 2 * world; i += (int)blockDim.x) hdr[i] = 0u;
+    for (int i = (int)threadIdx.x; i < 3 * world; i += (int)blockDim.x) hdr[i] = 0u;
     __syncthreads();
-    if (threadIdx.x == 0) { hdr[rank] = *cnt; hdr[world + rank] = mn ? *mn : 0x7FFFFFFFu; }
+    if (threadIdx.x == 0) { hdr[rank] = cnt ? *cnt : 0u; hdr[world + rank] = mn ? *mn : 0x7FFFFFFFu; hdr[2 * world + rank] = status; }
     if (threadIdx.x == 1 && words) { words[2] = 0u; words[3] = 0u; }     // the fills of the queues the next k_shard_mark writes
 }
 
@@ -238,23 +240,33 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t 
     uint32_t *d_words = nullptr, *d_hdr = nullptr, *d_xbuf = nullptr;
     const size_t xwords = std::max<size_t>((size_t)units, 2 * (size_t)std::min<uint32_t>(tail_limit, units)) + 2;
     KOMB_HIP(ctx, bufs.alloc(&d_words, 8));
-    KOMB_HIP(ctx, bufs.alloc(&d_hdr, (size_t)2 * world));
-    KOMB_HIP(ctx, bufs.alloc(&d_xbuf, xwords));
-    std::vector<uint32_t> hdr((size_t)2 * world);
+    KOMB_HIP(ctx, bufs.alloc(&d_hdr, (size_t)3 * world));
+    KOMB_HIP(ctx, bufs.alloc(&d_xbuf, xwords));                      // (everything is allocated before the first collective)
+    std::vector<uint32_t> hdr((size_t)3 * world);
     ShardStats ss;
     if (zeros) ss.levels = 1;
-    auto exchange = [&](uint32_t *buf, int64_t count) -> int {
+    // A failure on ONE rank between two collectives must not leave the others waiting: it is recorded here, the rank keeps
+    // taking part in the collectives (their sizes come from the exchanged headers), and the next header carries the status
+    // word that makes every rank return KOMB_ERR_DEVICE in the same iteration.
+    int local_err = KOMB_OK;
+    std::string local_msg;
+    auto fail_later = [&](int code, const char *what) { if (local_err == KOMB_OK) { local_err = code; local_msg = what; } };
+    auto exchange = [&](uint32_t *buf, int64_t count, bool is_header) -> int {
         const auto t0 = std::chrono::steady_clock::now();
         KOMB_HIP(ctx, hipStreamSynchronize(s));             // the buffer is complete when the callback runs
-        if (world > 1 && fn(user, buf, count) != 0) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: all-reduce callback failed");
+        if (world > 1 && fn(user, buf, count) != 0) {
+            // (a header whose own exchange failed cannot be trusted for the sizes of what follows: this rank has to leave)
+            if (is_header) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: all-reduce callback failed");
+            fail_later(KOMB_ERR_DEVICE, "sharded peel: all-reduce callback failed");
+        }
         ss.ms_exchange += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ++ss.exchanges; ss.words += count;
         return KOMB_OK;
     };
     // counts (and minima) of all ranks -> hdr[]; returns the total and this rank's offset in the concatenation
     auto exchange_counts = [&](const uint32_t *cnt, const uint32_t *mn, uint64_t *total, uint64_t *my_off, int32_t *gmin) -> int {
-        k_shard_header<<<1, 64, 0, s>>>(d_hdr, world, rank, cnt, mn, d_words);
-        KOMB_TRY(exchange(d_hdr, (int64_t)2 * world));
+        k_shard_header<<<1, 64, 0, s>>>(d_hdr, world, rank, cnt, mn, d_words, local_err != KOMB_OK ? 1u : 0u);
+        KOMB_TRY(exchange(d_hdr, (int64_t)3 * world, true));
         KOMB_HIP(ctx, d2h(ctx, hdr.data(), d_hdr, hdr.size() * sizeof(uint32_t)));
         *total = 0; *my_off = 0; *gmin = 0x7FFFFFFF;
         for (int r = 0; r < world; ++r) {
@@ -262,6 +274,11 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t 
             *total += hdr[(size_t)r];
             *gmin = std::min(*gmin, (int32_t)hdr[(size_t)world + r]);
         }
+        for (int r = 0; r < world; ++r)
+            if (hdr[(size_t)2 * world + r]) {
+                if (r == rank || local_err != KOMB_OK) KOMB_FAIL(ctx, local_err != KOMB_OK ? local_err : KOMB_ERR_DEVICE, "%s", local_msg.empty() ? "sharded peel: failure on this rank" : local_msg.c_str());
+                KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: rank %d reported a failure; all ranks stop", r);
+            }
         return KOMB_OK;
     };
     auto grid_of = [](uint64_t n) { return (int)std::min<uint64_t>((n + kBlock - 1) / kBlock + 1, 2048); };
@@ -290,12 +307,20 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t 
             KOMB_TRY(exchange_counts(d_words, nullptr, &total, &my_off, &gmin));
             if (total != remaining) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: %llu live units found at the hand-over, %llu expected", (unsigned long long)total, (unsigned long long)remaining);
             k_shard_fill2<<<grid_of(total), kBlock, 0, s>>>(reinterpret_cast<uint2 *>(d_xbuf), total, my_off, hdr[(size_t)rank], own);
-            KOMB_TRY(exchange(d_xbuf, (int64_t)(2 * total)));
+            KOMB_TRY(exchange(d_xbuf, (int64_t)(2 * total), false));
             k_shard_put<<<grid_of(total), kBlock, 0, s>>>(reinterpret_cast<const uint2 *>(d_xbuf), total, key);
         }
         k_shard_handover<<<1, 64, 0, s>>>(d_ctrl, (uint32_t)remaining, L, round, ss.levels, ss.max_level, tail_limit);
         KOMB_HIP(ctx, d2h(ctx, &ctx->h_ctrl[0], d_ctrl, sizeof(PeelCtrl)));
-        KOMB_TRY(finish());
+        {
+            // the finish runs on every rank (allocations, a fixed point): the ranks agree on its outcome before any of them goes on
+            const int frc = finish();
+            if (frc != KOMB_OK) fail_later(frc, ctx->err.c_str());
+            if (world > 1) {
+                uint64_t t2 = 0, o2 = 0; int32_t g2 = 0;
+                KOMB_TRY(exchange_counts(nullptr, nullptr, &t2, &o2, &g2));
+            } else if (frc != KOMB_OK) return frc;
+        }
         const PeelCtrl &hc = ctx->h_ctrl[0];
         if (hc.done == 1) {
             ss.handed_over = (uint32_t)remaining;
@@ -341,7 +366,7 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t 
         if (!level_counted) { ++ss.levels; ss.max_level = L; level_counted = true; }
         // ---- exchange 2: the ids, each rank's list in its own segment of a zeroed buffer
         k_shard_fill<<<grid_of(total), kBlock, 0, s>>>(d_xbuf, total, my_off, hdr[(size_t)rank], Q.light[own_q]);
-        if (world > 1) KOMB_TRY(exchange(d_xbuf, (int64_t)total));
+        if (world > 1) KOMB_TRY(exchange(d_xbuf, (int64_t)total, false));
         // ---- every rank: stamp + classify the whole frontier, then one PROCESS step that keeps the rank's own decrements
         CtrlView cv{};
         cv.mode = MODE_PROCESS; cv.level = L; cv.round = round; cv.cur_sel = own_q;

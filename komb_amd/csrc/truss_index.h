@@ -139,6 +139,7 @@ constexpr int kFinBlock = 512;
 constexpr uint32_t kWinCap = 7168;                 // entries of the LDS window (56 KB; with the two 8 KB tables: 2 workgroups per CU)
 constexpr int kFinE = (int)(kBinEdges / kFinBlock);          // consecutive edges per thread
 constexpr int kFinU = 4;                           // records per thread per trip
+static_assert((kWinCap * 8 + 2 * kBinEdges * 4) * 2 <= 160 * 1024, "two finishing workgroups per CU: windows and tables are sized for gfx950's 160 KB of LDS");
 static_assert(kFinE == 4 && kFinE <= (1 << kChunkBits), "a thread's edges are 4 consecutive ones of a chunk: their supports and own-role counts are one 16-byte vector each");
 // The kernel also does what followed the index build: the slices' (start, length) pairs off2[] (a workgroup scan of the bin's supports on
 // top of the bin's base -- the 100 M-element device scan is gone) and the peel's initial state (support, alive marker or

@@ -289,6 +289,32 @@ def peel_main():
                 seu, sev, stra = a.truss_fetch()
                 weu, wev, wtr = O.trussness_induced(rowptr, col, mask)
                 assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+            if name == "hug60k" and world > 1:
+                # a failure on ONE rank between two collectives must not strand the others.  Rank 1's callback carries
+                # out the third data exchange of a sharded k-core and then reports failure: every rank has to come back with an
+                # error from the same iteration (the status word of the next header, shard_dev.h) -- nobody hangs -- and the
+                # context must work again afterwards.
+                import ctypes
+                good = kd.make_allreduce_callback(a.device, None)
+                calls = {"data": 0}
+
+                def _cb(user, dev_ptr, count):
+                    rc = good(user, dev_ptr, count)
+                    if count != 3 * world:
+                        calls["data"] += 1
+                        if rank == 1 and calls["data"] == 3:
+                            return 1
+                    return rc
+                bad = komb_amd._lib.ALLREDUCE_FN(_cb)
+                os.environ["KOMB_FINISH"] = "none"
+                rc = a._lib.komb_core_run_sharded(a._ctx, rank, world, ctypes.cast(bad, ctypes.c_void_p), None)
+                os.environ.pop("KOMB_FINISH", None)
+                assert rc == komb_amd._lib.KOMB_ERR_DEVICE, f"rank {rank}: the injected failure was not reported (rc {rc})"
+                msg = a._lib.komb_last_error(a._ctx).decode()
+                assert ("callback failed" in msg) if rank == 1 else ("rank 1 reported a failure" in msg), (rank, msg)
+                dist.barrier()
+                kd.core_run_sharded(a)
+                assert np.array_equal(a.core_fetch()[1], ocore)
         dist.barrier()
     if rank == 0:
         print("DIST_OK peel", world)
