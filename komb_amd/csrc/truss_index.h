@@ -27,7 +27,10 @@ namespace {
 // writes of per-edge arrays stay coalesced: a chunk is 64 consecutive edges.
 constexpr int kBinBits = 11;
 constexpr uint32_t kBinEdges = 1u << kBinBits;
-constexpr int kChunkBits = 6;
+#ifndef KOMB_CHUNK_BITS
+#define KOMB_CHUNK_BITS 6
+#endif
+constexpr int kChunkBits = KOMB_CHUNK_BITS;
 constexpr uint32_t kChunkMask = (1u << kChunkBits) - 1u;
 struct BinGeom {
     int nb_bits;                          // log2 of the number of bins
