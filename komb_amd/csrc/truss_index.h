@@ -262,18 +262,49 @@ __global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__rest
                 }
             }
         }
-        // ---- own-role entries of the thread's edges: they end the edges' slices; the 4 edges' copies advance together
-        uint32_t most = 0;
+        // ---- own-role entries of the thread's edges: they end the edges' slices
+        if (inwin) {
+            // the 4 edges' copies advance together (4 independent loads per trip), into the LDS window
+            uint32_t most = 0;
 #pragma unroll
-        for (int u = 0; u < kFinE; ++u) most = max(most, ow[u]);
-        for (uint32_t kk = 0; kk < most; ++kk) {
-            int2 t[kFinE];
+            for (int u = 0; u < kFinE; ++u) most = max(most, ow[u]);
+            for (uint32_t kk = 0; kk < most; ++kk) {
+                int2 t[kFinE];
 #pragma unroll
-            for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) t[u] = own_dense[oo[u] + kk];
+                for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) t[u] = own_dense[oo[u] + kk];
 #pragma unroll
-            for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) {
-                const uint32_t p = o[u + 1] - ow[u] + kk;
-                if (inwin) sh_win[p] = t[u]; else dense[base + p] = t[u];
+                for (int u = 0; u < kFinE; ++u) if (kk < ow[u]) sh_win[o[u + 1] - ow[u] + kk] = t[u];
+            }
+        } else {
+            // A window beyond the LDS buffer holds a chunk of hub edges (runs of hundreds of entries per edge).  A thread
+            // copying its own edges' runs would store 8 bytes at 512 unrelated addresses per trip; instead the workgroup
+            // flattens all (edge, k) pairs: consecutive threads copy consecutive entries of one run -- reads from the task's
+            // block and writes into the window are both whole lines.  The (unused) window buffer holds the table: per edge the
+            // entries before it, where its run starts in the window, and where its block is.
+            uint32_t *tab_pre = reinterpret_cast<uint32_t *>(sh_win), *tab_dst = tab_pre + kBinEdges + 4;
+            unsigned long long *tab_src = reinterpret_cast<unsigned long long *>(tab_dst + kBinEdges);
+            const uint32_t mine_ow = ow[0] + ow[1] + ow[2] + ow[3];
+            const uint32_t incl_ow = wave_incl_scan(mine_ow);
+            __syncthreads();                                        // (sh_wsum is free again: every thread has read its offsets)
+            if (lane == kWave - 1) sh_wsum[w] = incl_ow;
+            __syncthreads();
+            uint32_t before_ow = 0, total_ow = 0;
+#pragma unroll
+            for (int i = 0; i < kFinBlock / kWave; ++i) { before_ow += i < w ? sh_wsum[i] : 0u; total_ow += sh_wsum[i]; }
+            uint32_t run = before_ow + incl_ow - mine_ow;
+#pragma unroll
+            for (int u = 0; u < kFinE; ++u) {
+                tab_pre[i0 + u] = run; tab_dst[i0 + u] = o[u + 1] - ow[u]; tab_src[i0 + u] = oo[u];
+                run += ow[u];
+            }
+            if (threadIdx.x == kFinBlock - 1) tab_pre[kBinEdges] = run;
+            __syncthreads();
+            for (uint32_t x = threadIdx.x; x < total_ow; x += kFinBlock) {
+                uint32_t lo = 0;                                    // the edge whose run holds entry x: largest i with tab_pre[i] <= x
+#pragma unroll
+                for (uint32_t st = kBinEdges / 2; st > 0; st >>= 1) lo += (tab_pre[lo + st] <= x) ? st : 0u;
+                const uint32_t kk = x - tab_pre[lo];
+                dense[base + tab_dst[lo] + kk] = own_dense[tab_src[lo] + kk];
             }
         }
         __syncthreads();
