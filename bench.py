@@ -396,8 +396,16 @@ def main():
         ms, launches, nbytes = kernels[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         traffic, traffic_max, traffic_src = measured_traffic(args.config, dom)
+        # the longest single launch (the other reading of "dominant"): the enumeration's one launch per step
+        by_launch = max(kernels, key=lambda k: kernels[k][0] / max(kernels[k][1], 1))
+        bl_ms, bl_n, bl_bytes = kernels[by_launch]
         roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": dom,
+            "dominant_rule": "the kernel symbol with the largest time per step (all its launches together), as in rounds 1-3; "
+                             "by_launch names the kernel with the longest single launch",
+            "by_launch": {"kernel": by_launch, "avg_launch_us": bl_ms * 1e3 / max(bl_n, 1), "launches_per_step": bl_n,
+                          "achieved": (bl_bytes / (bl_ms * 1e-3) / 1e9 if bl_ms > 0 else 0.0),
+                          "frac": (bl_bytes / (bl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bl_ms > 0 else 0.0)}, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             # FETCH_SIZE is exact for line gathers and 1/2 for coalesced streams (calibrated on this box):
             # traffic = FETCH+WRITE is the lower bound, traffic_max = 2*FETCH+WRITE the upper bound
@@ -456,6 +464,9 @@ def main():
             "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("KOMB_")},
             "runtruss_faithful": faithful,
             "first_call": first_call,
+            # nothing a k-truss / k-core call computes is skipped after the first call: the graph moments (sum d^2, max degree, ...)
+            # that rounds 1-3 computed on the first call only are made with the graph since round 4
+            "statistics_skipped_after_first_call": [],
             "c2": c2_block,
             "setup_s": {"generate": t_gen, "graph_build_incl_h2d": t_build, "device_build_ms": build_stats["ms_build"],
                         "h2d_ms": build_stats["ms_build_h2d"], "renumber_orient_lines_ms": build_stats["ms_build_relabel"],
