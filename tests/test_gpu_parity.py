@@ -390,6 +390,37 @@ def test_internal_renumbering_is_invisible(K, O):
                 assert np.array_equal(eu2, oeu) and np.array_equal(ev2, oev) and np.array_equal(tr2, otr)
 
 
+def test_wedge_enumeration_paths(K, O, monkeypatch):
+    """The triangle enumeration by wedges (truss_wedge.h) against the oracle and against round 3's probe kernel on shapes that
+    reach each of its paths: K_700 (rows of up to 699 slots: unstaged, cut into PARTS of ~16 k wedges, all entries through the
+    record stream), a clique chain of K_150s (single-row tasks of 32..149 slots whose records outgrow the LDS buffer: the
+    wave-private scratch, switched off for comparison), a hub-heavy generator graph (rows around the 256-slot staging limit next
+    to thousands of light vertices per task), with the induced-subgraph variant (lines and tasks built per run)."""
+    rng = np.random.default_rng(5)
+    iu = np.triu_indices(700, 1)
+    k700 = np.stack(iu, axis=1).astype(np.int64)
+    iu = np.triu_indices(150, 1)
+    chain = np.concatenate([np.stack(iu, axis=1) + 140 * i for i in range(12)]).astype(np.int64)     # neighbours share 10 vertices
+    cases = [("K_700", 700, k700), ("chain of K_150", 140 * 12 + 20, chain),
+             ("hug 30k alpha 2.05", 30000, np.asarray(K.gen_hug_edges(30000, 100000, 2.05, 11)).reshape(-1, 2))]
+    for name, nv, uv in cases:
+        o_rowptr, o_col = O.simplify(nv, uv)
+        osup, otri = O.support(o_rowptr, o_col)
+        otr = O.trussness(o_rowptr, o_col)
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            for env in ({}, {"KOMB_NO_REC_SCRATCH": "1"}, {"KOMB_ENUM": "probe"}, {"KOMB_NO_OWN_DENSE": "1"}):
+                for k, v in env.items(): monkeypatch.setenv(k, v)
+                eu, ev, tr, sup = a.run_truss(with_support=True)
+                st = a.stats()
+                for k in env: monkeypatch.delenv(k, raising=False)
+                assert st["triangles"] == otri and np.array_equal(sup, osup) and np.array_equal(tr, otr), (name, env)
+            mask = (rng.random(nv) < 0.6).astype(np.uint8)
+            seu, sev, stra = a.run_truss(mask)
+            weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
+            assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr), name
+
+
 def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
     """A graph whose capacity-bounded slices hold more than 2^32 entries by themselves (dense uniform random, 30 000
     vertices, ~12.5 M edges of degree ~830: sum over edges of d(lower endpoint) - 1 ~ 1e10), so the single pass runs with
