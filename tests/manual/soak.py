@@ -1,7 +1,7 @@
 """Randomised soak: many graphs of assorted shapes, k-core and k-truss (with support) against the CPU oracle,
 each under a random choice of the finish (local fixed point / LDS tails / none), its hand-over thresholds and item
 limit, and of the index layout (record stream / bounded slices / two pass, 32 / 64-bit slice offsets, dense or block-less
-own-role entries, a dense region or a record stream that runs out), the orientation's class table, the fixed point's
+own-role entries, a dense region or a record stream that runs out), the fixed point's
 notification kernel, and -- one graph in seven -- the sharded peel's engine with one rank (shard_dev.h).
     python tests/manual/soak.py [n_graphs] [seed]"""
 import os, sys, time
