@@ -69,9 +69,6 @@ struct CoreProblem {
     }
     __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &, uint32_t &c0, uint32_t &) const
     {
-#ifdef KOMB_EXP_SKIP_HUBS
-        if (marker_chunks(ld.c) >= KOMB_EXP_SKIP_HUBS && marker_alive(ld.c)) return;      // EXPERIMENT (wrong results): what the hubs' decrements cost
-#endif
         if (marker_alive(ld.c)) {                       // a stale "alive" only costs a no-op decrement
             if (atomicSub(&degw[ld.u], 1) == cv.level + 1) { core[ld.u] = cv.level; t0 = ld.u; c0 = marker_chunks(ld.c); }
         }
