@@ -253,6 +253,7 @@ struct komb_ctx {
     void     *d_wtasks = nullptr;            // [n_wtasks] task descriptors of the triangle enumeration (truss_wedge.h)
     int64_t   n_wtasks = 0;
     uint4    *d_vline = nullptr;             // [4*nv] one 64-byte line per vertex: start, length, pivots and signature of its oriented row (truss_wedge.h)
+    int64_t g_own_bound = 0;                 // sum over the vertices of d+ (d+ - 1): bound on the own-role index entries (capacities of a k-truss run)
     int64_t g_mom[5] = {0, 0, 0, 0, 0};      // graph moments of the whole graph (k_graph_moments), computed with the graph
 
     // ---- k-core results
@@ -370,6 +371,7 @@ void graph_free(komb_ctx *ctx);
 void stager_free(komb_ctx *ctx);
 // sum d^2, sum min(d,d), max d, (unused), sum d+ + d+ of an oriented graph (ktruss.hip; the build calls it once per graph)
 int build_tasks(komb_ctx *ctx, const uint32_t *orow, int64_t nv, bool resident, void **tasks, int64_t *ntasks);   // ktruss.hip
+int own_bound(komb_ctx *ctx, const uint32_t *orow, int64_t nv, int64_t *out);                                  // ktruss.hip (k_own_bound)
 int vertex_lines(komb_ctx *ctx, const uint32_t *orow, const int32_t *ocol, int64_t nv, void *lines);   // ktruss.hip (k_vertex_lines)
 int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *osrc, const int32_t *ocol, int64_t m,
                   const uint32_t *orow, int64_t out[5]);

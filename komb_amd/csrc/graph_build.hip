@@ -353,6 +353,7 @@ int finish_graph(komb_ctx *ctx, Scratch &sc, const int32_t *d_src_o, int64_t nv,
     // ---- the oriented rows' lines for the triangle enumeration (truss_wedge.h)
     KOMB_TRY(vertex_lines(ctx, ctx->d_orow, ctx->d_ocol, nv, ctx->d_vline));
     KOMB_TRY(build_tasks(ctx, ctx->d_orow, nv, true, &ctx->d_wtasks, &ctx->n_wtasks));
+    KOMB_TRY(own_bound(ctx, ctx->d_orow, nv, &ctx->g_own_bound));
     // ---- graph moments for the roofline model (properties of the graph, not results of the path)
     KOMB_TRY(graph_moments(ctx, ctx->d_deg_i, nv, ctx->d_osrc, ctx->d_ocol, ne, ctx->d_orow, ctx->g_mom));
     KOMB_HIP(ctx, hipStreamSynchronize(s));
@@ -387,6 +388,7 @@ void graph_free(komb_ctx *ctx)
     ctx->d_ceu = ctx->d_cev = nullptr; ctx->d_canon2e = nullptr; ctx->d_vline = nullptr; ctx->d_wtasks = nullptr; ctx->n_wtasks = 0; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
     for (auto &m : ctx->g_mom) m = 0;
+    ctx->g_own_bound = 0;
     ctx->pool.clear();                                   // scratch sized for the old graph
 }
 

@@ -254,6 +254,18 @@ int build_tasks(komb_ctx *ctx, const uint32_t *orow, int64_t nv, bool resident, 
     return KOMB_OK;
 }
 
+int own_bound(komb_ctx *ctx, const uint32_t *orow, int64_t nv, int64_t *out)
+{
+    unsigned long long *d_b = nullptr, h = 0;
+    DevBufs bufs(ctx);
+    KOMB_HIP(ctx, bufs.alloc(&d_b, 1));
+    KOMB_HIP(ctx, hipMemsetAsync(d_b, 0, sizeof(unsigned long long), ctx->stream));
+    k_own_bound<<<grid_for(nv), kBlock, 0, ctx->stream>>>(orow, nv, d_b);
+    KOMB_HIP(ctx, d2h(ctx, &h, d_b, sizeof(h)));
+    *out = (int64_t)h;
+    return KOMB_OK;
+}
+
 int vertex_lines(komb_ctx *ctx, const uint32_t *orow, const int32_t *ocol, int64_t nv, void *lines)
 {
     if (nv > 0) k_vertex_lines<<<grid_for(nv), kBlock, 0, ctx->stream>>>(orow, ocol, nv, (uint4 *)lines);
@@ -460,10 +472,13 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (layout == IDX_STREAM) {
         // capacities: T <= sum_a C(d+(a), 2) triangles, at most three records each (a triangle of a task without a dense
         // block), plus what the chunked claims leave unused; with less memory than that, a stream that runs out falls back
-        unsigned long long *d_bound = d_mom + 6;
-        k_own_bound<<<gv, kBlock, 0, s>>>(d_orow, nv, d_bound);
-        unsigned long long bound = 0;
-        KOMB_HIP(ctx, d2h(ctx, &bound, d_bound, sizeof(bound)));
+        // (sum over the vertices of d+ (d+ - 1): of the whole graph it comes with the graph, graph_build.hip)
+        unsigned long long bound = (unsigned long long)ctx->g_own_bound;
+        if (vmask_host) {
+            unsigned long long *d_bound = d_mom + 6;
+            k_own_bound<<<gv, kBlock, 0, s>>>(d_orow, nv, d_bound);
+            KOMB_HIP(ctx, d2h(ctx, &bound, d_bound, sizeof(bound)));
+        }
         const int gts = std::min(gt, 256 * KOMB_TRI_EU);             // resident workgroups only: every wavefront ends with one partly used claim
         const unsigned long long slack = (unsigned long long)gts * kTriWaves * kRecChunk + kRecChunk;
         unsigned long long own_cap = bound + bound / 8 + (unsigned long long)gts * kTriWaves * kOwnChunk + kOwnChunk;
@@ -662,6 +677,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
     bufs.release(d_cnt_ref);
     uint32_t total = 0;
+    const uint32_t sum_supports = (uint32_t)st.triangles * 3u;      // (checked above: below 2^32 - 16) = the index's entries
     int2 *d_inc = nullptr;
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
     bool peel_inited = false;                  // the stream layout's finish also writes the peel's initial state
@@ -669,7 +685,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (layout == IDX_STREAM) {
         // every bin's window of the index from the scan of the per-bin totals (the slice offsets themselves are a workgroup scan inside k_bin_finish)
         KOMB_TRY(prim_exclusive_sum_u32(ctx, d_bintot, d_bintot, n_bins + 1));
-        KOMB_HIP(ctx, d2h(ctx, &total, d_bintot + n_bins, sizeof(uint32_t)));
+        total = sum_supports;                                        // (= the scan's last element: no round trip for it)
         KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
         KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
