@@ -6,23 +6,26 @@
 //
 // MI355X-first design (no intersections inside the peel loop):
 //   1. every edge points from its lower to its higher (degree,id) endpoint.  The
-//      graph is resident in INTERNAL ids = (degree,id) ranks (graph_build.hip),
-//      so that oriented CSR (orow/ocol) is simply the upper half of every row
-//      and comes with the graph; an induced subgraph is an ordered stream
-//      compaction of its slots (k_slot_filter).  The internal edge id is the
-//      oriented slot.  On power-law unitig graphs the oriented rows are tiny
-//      (max ~10^2), whatever the hub degrees are.
-//   2. enumerate every triangle once (k_triangles: edge a->b, every element of
-//      N+(b) looked up in the LDS-staged N+(a)) and build the incidence index:
-//      for every edge, the pairs of the other two edges of its triangles
-//      (24 bytes per triangle).  Default (round 3): ONE enumeration; the entries
-//      of a task's own edges leave it as a dense block, every other entry as a
-//      12-byte record of one stream -- no atomic, no scattered store per
-//      triangle; the records are radix-sorted by BIN (2048 consecutive edges)
-//      and one workgroup per bin assembles its window of the index in LDS
-//      (k_bin_count, k_bin_finish), which also writes the slice offsets, the
-//      peel's initial state and the first level's frontier.  Round 2's bounded
-//      slices (KOMB_INDEX=slices) and the exact count-scan-fill two-pass layout
+//      k-truss side of the graph is resident in INTERNAL ids = (degree,id) ranks
+//      (graph_build.hip), so that oriented CSR (orow/ocol) comes with the graph;
+//      an induced subgraph is an ordered stream compaction of its slots
+//      (k_slot_filter).  The internal edge id is the oriented slot.  On power-law
+//      unitig graphs the oriented rows are tiny (max ~10^2), whatever the hub
+//      degrees are.
+//   2. enumerate every triangle once and build the incidence index: for every
+//      edge, the pairs of the other two edges of its triangles (24 bytes per
+//      triangle).  Enumeration by WEDGES (truss_wedge.h, round 4): the slots of
+//      the LDS-staged row of a behind edge a->b are tested against a 64-byte line
+//      of b (pivots + Bloom signature), survivors looked up in N+(b) with one
+//      trip to memory.  ONE pass: the entries of a task's own edges leave it as a
+//      dense block, every other entry as a 12-byte record of one stream -- no
+//      atomic, no scattered store per triangle; the records are radix-sorted by
+//      BIN (64-edge chunks dealt round-robin, truss_index.h) and one workgroup per
+//      bin assembles its window of the index in LDS (k_bin_count, k_bin_finish),
+//      which also writes the slices' (start, length) pairs, the peel's initial
+//      state and the first level's frontier.  Round 3's probe enumeration
+//      (KOMB_ENUM=probe, truss_tri.h), round 2's bounded slices
+//      (KOMB_INDEX=slices) and the exact count-scan-fill two-pass layout
 //      (KOMB_INDEX=two_pass, the fallback) are kept and tested.
 //   3. peel: level-synchronous sub-rounds driven by the device control block
 //      (peel_dev.h).  A frontier edge walks its incidence slice; a triangle
