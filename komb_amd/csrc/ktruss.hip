@@ -90,7 +90,10 @@ struct TrussProblem {
     __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
     {
         Loaded ld;
-        const int2 p = inc[pos];
+        // (an index entry is read once per visit and never again soon: the non-temporal hint keeps it from displacing the stamp
+        // and support lines the gathers and atomics reuse -- same box: peel 9.2 -> 9.0 ms; the same hint on the stamp gathers: 10.2)
+        const unsigned long long pq = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(inc) + pos);
+        const int2 p = make_int2((int)(uint32_t)pq, (int)(uint32_t)(pq >> 32));
         ld.me = me; ld.x = p.x; ld.y = p.y;
         ld.sx = stamp[p.x]; ld.sy = stamp[p.y];
         return ld;
