@@ -472,8 +472,9 @@ def main():
             "c2": c2_block,
             "setup_s": {"generate": t_gen, "graph_build_incl_h2d": t_build, "device_build_ms": build_stats["ms_build"],
                         "h2d_ms": build_stats["ms_build_h2d"], "renumber_orient_lines_ms": build_stats["ms_build_relabel"],
-                        "note": "first graph build of the process: includes the HIP runtime's first large allocations and the pinned staging "
-                                "buffers; first_call.graph_build_ms is a second build in the same process.  The graph object holds the "
+                        "note": "first graph build of the process: includes the HIP runtime's first large allocations and first launches of "
+                                "every build kernel (komb_create has loaded the code object and made the pinned staging buffers); "
+                                "first_call.graph_build_ms is a second build in the same process.  The graph object holds the "
                                 "(degree,id)-renumbered oriented CSR, the canonical edge map, the per-vertex lines of the enumeration and the "
                                 "graph moments (all functions of the graph alone, built once with it); no k-truss / k-core call reuses "
                                 "anything a previous call computed"},

@@ -67,6 +67,11 @@ komb_ctx *komb_create(const komb_opts *opts)
         return ctx;
     }
     ctx->device_ok = true;
+    // One-time costs of a process' first use of the library -- loading its code object onto the device (the first kernel
+    // launch), the pinned staging buffers of the graph upload -- are paid here, not by the first graph build: komb2 creates
+    // its context on a second thread beside the SAM parse, so they leave its critical path (komb_amd/host/komb2.cpp).
+    // KOMB_NO_WARMUP=1 skips it.
+    if (!getenv("KOMB_NO_WARMUP")) warm_up(ctx);
     return ctx;
 }
 

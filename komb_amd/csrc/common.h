@@ -369,6 +369,7 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
 int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);
 void graph_free(komb_ctx *ctx);
 void stager_free(komb_ctx *ctx);
+void warm_up(komb_ctx *ctx);                 // graph_build.hip: first kernel launch of the library + the upload's staging buffers
 // sum d^2, sum min(d,d), max d, (unused), sum d+ + d+ of an oriented graph (ktruss.hip; the build calls it once per graph)
 int build_tasks(komb_ctx *ctx, const uint32_t *orow, int64_t nv, bool resident, void **tasks, int64_t *ntasks);   // ktruss.hip
 int own_bound(komb_ctx *ctx, const uint32_t *orow, int64_t nv, int64_t *out);                                  // ktruss.hip (k_own_bound)
