@@ -30,6 +30,7 @@ namespace {
 
 constexpr int kLineWords = 16;                  // 64 bytes per vertex: start, length, 6 pivots, 4 x 64-bit signature blocks
 constexpr int kSigBlocks = 4;
+constexpr int kLdsLine = 10;                    // words of a line kept in LDS: 4 signature blocks, start, length
 constexpr int kPivots = 6;                      // the row's elements at positions seg, 2 seg, ... 6 seg, seg = ceil(length / 7)
 constexpr int kWCand = 128;                     // parked candidates per wavefront
 #ifndef KOMB_WEDGE_V
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_task_fill(const uint32_t *__restrict
 // MODE: TRI_COUNT (supports only: own[] by plain stores, other[] by atomics) or TRI_SINGLE (the record-stream build:
 // own-role entries as dense per-task blocks, everything else as records; truss_tri.h)
 #ifndef KOMB_WEDGE_EU
-#define KOMB_WEDGE_EU 3
+#define KOMB_WEDGE_EU 4
 #endif
 template <int MODE>
 __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
@@ -153,7 +154,10 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
     __shared__ uint32_t sh_rend[kTriWaves][kWave];
     __shared__ uint2 sh_rec[kTriWaves][kTriRec];
     __shared__ uint2 sh_cand[kTriWaves][kWCand];
-    __shared__ __attribute__((aligned(16))) uint32_t sh_line[kTriWaves][kWave][kLineWords + 2];      // + 2: the lanes' lines start in different banks, 8-byte aligned
+    // of every edge's line LDS keeps what the candidate tests read -- the signature -- and start / length; the six pivots stay in
+    // the registers of the edge's lane and reach a survivor's lane by shuffle (8 KB of LDS less per workgroup: 4 instead of 3
+    // workgroups per CU)
+    __shared__ __attribute__((aligned(16))) uint32_t sh_line[kTriWaves][kWave][kLdsLine];
     __shared__ uint8_t sh_rid[kTriWaves][kTriCap];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x >> 6);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
     uint2 *s_rec = sh_rec[w];
     uint3 *s_tri = reinterpret_cast<uint3 *>(sh_rec[w]);
     uint2 *s_cand = sh_cand[w];
-    uint32_t (*s_line)[kLineWords + 2] = sh_line[w];
+    uint32_t (*s_line)[kLdsLine] = sh_line[w];
     uint8_t *s_rid = sh_rid[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
         // candidates that pass the signature are parked as (lane of their edge in the batch | slot of c in row a << 6, c)
         // and looked up in N+(b) densely, 64 at a time; p0 = the batch's first slot
         uint32_t n_cand = 0;                                    // wave-uniform
+        int32_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0, pv4 = 0, pv5 = 0;      // the pivots of this lane's edge of the current batch
         auto search_cands = [&](uint32_t p0) {
             __builtin_amdgcn_wave_barrier();
             if (ablate & 1) n_cand = 0;
@@ -276,16 +281,22 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
                 const uint32_t x = b0 + (uint32_t)lane;
                 uint32_t t = 0, i_rel = 0, l = 0, n = 0;
                 int32_t c = 0;
-                if (x < n_cand) {
+                const bool have = x < n_cand;
+                if (have) {
                     const uint2 cd = s_cand[x];
                     t = cd.x & 63u; i_rel = cd.x >> 6; c = (int32_t)cd.y;
+                }
+                // the pivots of the candidate's edge, from the registers of that edge's lane (all lanes take part in the shuffles)
+                const int32_t p0v = __shfl(pv0, (int)t), p1v = __shfl(pv1, (int)t), p2v = __shfl(pv2, (int)t);
+                const int32_t p3v = __shfl(pv3, (int)t), p4v = __shfl(pv4, (int)t), p5v = __shfl(pv5, (int)t);
+                if (have) {
                     const uint32_t *ln = s_line[t];
-                    l = ln[0];
-                    const uint32_t len = ln[1], seg = (len + (uint32_t)kPivots) / (uint32_t)(kPivots + 1);
+                    l = ln[8];
+                    const uint32_t len = ln[9], seg = (len + (uint32_t)kPivots) / (uint32_t)(kPivots + 1);
                     // segment of c: the number of pivots <= c (the pivots are ascending; unused ones are INT32_MAX)
-                    uint32_t sidx = ((int32_t)ln[2 + 3] <= c) ? 4u : 0u;
-                    sidx += ((int32_t)ln[2 + sidx + 1] <= c) ? 2u : 0u;
-                    sidx += (sidx < (uint32_t)kPivots && (int32_t)ln[2 + sidx] <= c) ? 1u : 0u;
+                    uint32_t sidx;
+                    if (p3v <= c) sidx = p5v <= c ? 6u : (p4v <= c ? 5u : 4u);
+                    else sidx = p1v <= c ? (p2v <= c ? 3u : 2u) : (p0v <= c ? 1u : 0u);
                     const uint32_t lo = sidx * seg;
                     l += lo;
                     n = lo < len ? min(seg, len - lo) : 0u;
@@ -364,8 +375,9 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
                 const uint4 *L = line + 4 * (int64_t)b;
                 const uint4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3];
                 uint32_t *d = s_line[lane];
-                d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
-                d[8] = q2.x; d[9] = q2.y; d[10] = q2.z; d[11] = q2.w; d[12] = q3.x; d[13] = q3.y; d[14] = q3.z; d[15] = q3.w;
+                d[0] = q2.x; d[1] = q2.y; d[2] = q2.z; d[3] = q2.w; d[4] = q3.x; d[5] = q3.y; d[6] = q3.z; d[7] = q3.w;
+                d[8] = q0.x; d[9] = q0.y;
+                pv0 = (int32_t)q0.z; pv1 = (int32_t)q0.w; pv2 = (int32_t)q1.x; pv3 = (int32_t)q1.y; pv4 = (int32_t)q1.z; pv5 = (int32_t)q1.w;
                 if (q0.y == 0u) ncand = 0;                      // b has no out-neighbours
             }
             // the candidates of the 64 edges are cut into chunks of 4 consecutive slots of ONE row and the chunks are flattened
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t
                         c = staged ? s_col[i0 + (uint32_t)k] : ocol[S0 + i0 + (uint32_t)k];
                         uint32_t blk; unsigned long long mask;
                         sig_slot(c, blk, mask);
-                        const unsigned long long word = *reinterpret_cast<const unsigned long long *>(ln + 8 + 2 * blk);
+                        const unsigned long long word = *reinterpret_cast<const unsigned long long *>(ln + 2 * blk);
                         cand = (word & mask) == mask;
                     }
                     const uint64_t cm = __ballot(cand);
