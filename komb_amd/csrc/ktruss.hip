@@ -697,7 +697,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
         ctx->timer.start(s);
-        k_bin_finish<<<grid_for(n_bins, 1, 256 * 2), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, geom, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
+        k_bin_finish<<<grid_for(n_bins, 1, 256 * kFinPerCu), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, geom, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
                                                                       d_off2, d_sup, d_stamp, d_grp + kInitOff, d_light0);
         st.ms_compact += ctx->timer.stop(s);
         peel_inited = true;

@@ -139,15 +139,23 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const uint32_t *__restrict
 // in place instead.  All loads of a phase are issued before the first is used: two workgroups per CU, and the kernel
 // lives on memory-level parallelism.
 constexpr int kFinBlock = 512;
-constexpr uint32_t kWinCap = 7168;                 // entries of the LDS window (56 KB; with the two 8 KB tables: 2 workgroups per CU)
+#ifndef KOMB_FIN_PER_CU
+#define KOMB_FIN_PER_CU 2
+#endif
+#ifndef KOMB_WIN_CAP
+#define KOMB_WIN_CAP 7168
+#endif
+constexpr int kFinPerCu = KOMB_FIN_PER_CU;          // finishing workgroups per CU
+constexpr uint32_t kWinCap = KOMB_WIN_CAP;          // entries of the LDS window (7168: 56 KB; with the two 8 KB tables: 2 workgroups per CU)
 constexpr int kFinE = (int)(kBinEdges / kFinBlock);          // consecutive edges per thread
 constexpr int kFinU = 4;                           // records per thread per trip
-static_assert((kWinCap * 8 + 2 * kBinEdges * 4) * 2 <= 160 * 1024, "two finishing workgroups per CU: windows and tables are sized for gfx950's 160 KB of LDS");
+static_assert((kWinCap * 8 + 2 * kBinEdges * 4 + 512) * kFinPerCu <= 160 * 1024, "the finishing workgroups of a CU: windows and tables are sized for gfx950's 160 KB of LDS");
+static_assert(kWinCap * 8 >= (2 * kBinEdges + 4) * 4 + kBinEdges * 8, "the window buffer doubles as the table of the in-place copy");
 static_assert(kFinE == 4 && kFinE <= (1 << kChunkBits), "a thread's edges are 4 consecutive ones of a chunk: their supports and own-role counts are one 16-byte vector each");
 // The kernel also does what followed the index build: the slices' (start, length) pairs off2[] (a workgroup scan of the bin's supports on
 // top of the bin's base -- the 100 M-element device scan is gone) and the peel's initial state (support, alive marker or
 // "gone" for a triangle-free edge, the count of those and the smallest positive support for the first level).
-__global__ __launch_bounds__(kFinBlock) void k_bin_finish(const uint32_t *__restrict__ key, const int2 *__restrict__ val,
+__global__ __launch_bounds__(kFinBlock, (kFinBlock / 64) * kFinPerCu / 4) void k_bin_finish(const uint32_t *__restrict__ key, const int2 *__restrict__ val,
                                                          const uint32_t *__restrict__ boff, BinGeom g,
                                                          const uint32_t *__restrict__ own, const uint32_t *__restrict__ cnt,
                                                          const uint32_t *__restrict__ bin_base,
