@@ -234,7 +234,7 @@ int peel_grid(int64_t units)
 {
     int64_t g = (units + kPeelBlock - 1) / kPeelBlock;
     if (g < 1) g = 1;
-    if (g > 256) g = 256;                                  // one 1024-thread workgroup per CU (16 waves/CU; more workgroups cost more ticket traffic than they hide latency)
+    if (g > 256 * kPeelPerCu) g = 256 * kPeelPerCu;        // one 1024-thread workgroup per CU (16 waves/CU; more workgroups cost more ticket traffic than they hide latency)
     return (int)g;
 }
 

@@ -37,7 +37,14 @@ namespace komb {
 
 enum : int32_t { MODE_SCAN = 0, MODE_PROCESS = 1 };
 
-constexpr int kPeelBlock = 1024;               // 16 wave64 per workgroup
+#ifndef KOMB_PEEL_BLOCK
+#define KOMB_PEEL_BLOCK 1024
+#endif
+#ifndef KOMB_PEEL_PER_CU
+#define KOMB_PEEL_PER_CU 1
+#endif
+constexpr int kPeelBlock = KOMB_PEEL_BLOCK;     // 16 wave64 per workgroup
+constexpr int kPeelPerCu = KOMB_PEEL_PER_CU;   // workgroups per CU the grid is sized for
 constexpr int kPeelWaves = kPeelBlock / kWave;
 constexpr int kLight = 64;                     // units with <= kLight items are flattened 64 per wave
 constexpr int kChunk = 128;                    // heavy units: one queue entry per kChunk items (= one trip of a wavefront)
@@ -306,7 +313,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 //                                        decrements; ids of triggered units or -1, and their classes
 // (load and apply are split so that the loads of several items are in flight together)
 template <class P>
-__global__ __launch_bounds__(kPeelBlock) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p, int32_t launch)
+__global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p, int32_t launch)
 {
     __shared__ CtrlView sh_cv;
     __shared__ uint32_t sh_w[kPeelWaves][4];           // per-wave counts / bases
