@@ -76,37 +76,71 @@ struct TrussProblem {
     int32_t *sup;
     int32_t *stamp;                      // alive marker, then the sub-round the edge was peeled in: its trussness is
                                          // rlevel[stamp] + 2 (PeelQueues::rlevel, written once per sub-round) -- no result store per edge
+    uint8_t *st8;                        // [units + 16] the stamps' one-byte shadow the triangle visits gather from (peel_dev.h: state_of_round)
+    static constexpr int32_t kRetireEvery = komb::kRetireEvery;
+
+    // RETIRE step: codes of sub-rounds before the current one become ST_GONE, 16 states per lane per trip
+    __device__ __forceinline__ void retire(const CtrlView &cv, uint32_t block, uint32_t nblocks) const
+    {
+        const uint32_t n16 = (units + 15u) / 16u;           // (the allocation is padded; bytes past `units` are never read as states)
+        uint4 *v = reinterpret_cast<uint4 *>(st8);
+        for (uint32_t i = block * (uint32_t)kPeelBlock + threadIdx.x; i < n16; i += nblocks * (uint32_t)kPeelBlock) {
+            uint4 q = v[i];
+            uint32_t *w = &q.x;
+            bool changed = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t out = w[k];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t c = (w[k] >> (8 * b)) & 0xFFu;
+                    if (c > ST_GONE && state_rel(c, cv.round) == REL_GONE) out = (out & ~(0xFFu << (8 * b))) | ((uint32_t)ST_GONE << (8 * b));
+                }
+                changed |= out != w[k];
+                w[k] = out;
+            }
+            if (changed) v[i] = q;
+        }
+    }
 
     __device__ __forceinline__ const int32_t *scan_marker() const { return stamp; }
     __device__ __forceinline__ const int32_t *scan_key() const { return sup; }
-    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const { stamp[e] = cv.round; }
+    __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const { stamp[e] = cv.round; st8[e] = state_of_round(cv.round); }
     __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const
     {
         const uint2 o = off2[e];
         b = o.x;
         len = o.y;
     }
-    struct Loaded { int32_t me, x, y, sx, sy; };
+    struct Loaded { int32_t me, x, y; uint32_t cx, cy; };
     __device__ __forceinline__ Loaded item_load(int32_t me, uint32_t pos, const CtrlView &) const
     {
         Loaded ld;
-        // (an index entry is read once per visit and never again soon: the non-temporal hint keeps it from displacing the stamp
+        // (an index entry is read once per visit and never again soon: the non-temporal hint keeps it from displacing the state
         // and support lines the gathers and atomics reuse -- same box: peel 9.2 -> 9.0 ms; the same hint on the stamp gathers: 10.2)
         const unsigned long long pq = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(inc) + pos);
         const int2 p = make_int2((int)(uint32_t)pq, (int)(uint32_t)(pq >> 32));
         ld.me = me; ld.x = p.x; ld.y = p.y;
-        ld.sx = stamp[p.x]; ld.sy = stamp[p.y];
+        ld.cx = st8[p.x]; ld.cy = st8[p.y];
         return ld;
     }
     __device__ __forceinline__ void item_apply(const Loaded &ld, const CtrlView &cv, int32_t &t0, int32_t &t1, uint32_t &c0, uint32_t &c1) const
     {
         const int32_t r = cv.round, L = cv.level;
-        if (ld.sx < r || ld.sy < r) return;             // an edge of the triangle is already gone
-        const bool xin = (ld.sx == r), yin = (ld.sy == r);
+        const int rx = state_rel(ld.cx, r), ry = state_rel(ld.cy, r);
+        if (rx == REL_GONE || ry == REL_GONE) return;   // an edge of the triangle is already gone
+        const bool xin = (rx == REL_NOW), yin = (ry == REL_NOW);
         const bool decx = !xin && (!yin || ld.me < ld.y);
         const bool decy = !yin && (!xin || ld.me < ld.x);
-        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) { stamp[ld.x] = r + 1; t0 = ld.x; c0 = marker_chunks(ld.sx); }
-        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) { stamp[ld.y] = r + 1; t1 = ld.y; c1 = marker_chunks(ld.sy); }
+        // (a triggered heavy edge's chunk count is in the alive marker its stamp still holds)
+        if (decx && atomicSub(&sup[ld.x], 1) == L + 1) {
+            c0 = ld.cx == ST_ALIVE_HEAVY ? marker_chunks(stamp[ld.x]) : 0u;
+            stamp[ld.x] = r + 1; st8[ld.x] = state_of_round(r + 1); t0 = ld.x;
+        }
+        if (decy && atomicSub(&sup[ld.y], 1) == L + 1) {
+            c1 = ld.cy == ST_ALIVE_HEAVY ? marker_chunks(stamp[ld.y]) : 0u;
+            stamp[ld.y] = r + 1; st8[ld.y] = state_of_round(r + 1); t1 = ld.y;
+        }
     }
 };
 
@@ -686,6 +720,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     const uint32_t sum_supports = (uint32_t)st.triangles * 3u;      // (checked above: below 2^32 - 16) = the index's entries
     int2 *d_inc = nullptr;
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
+    uint8_t *d_st8 = nullptr;                  // the stamps' one-byte shadow (peel_dev.h: state_of_round)
     bool peel_inited = false;                  // the stream layout's finish also writes the peel's initial state
     const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
     if (layout == IDX_STREAM) {
@@ -695,10 +730,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
         KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_st8, (size_t)m + 16));
         KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
         ctx->timer.start(s);
         k_bin_finish<<<grid_for(n_bins, 1, 256 * kFinPerCu), kFinBlock, 0, s>>>(d_reckey, d_recval, d_toff, geom, d_own, d_cnt, d_bintot, d_owndense, d_ownoff, d_inc, m,
-                                                                      d_off2, d_sup, d_stamp, d_grp + kInitOff, d_light0);
+                                                                      d_off2, d_sup, d_stamp, d_st8, d_grp + kInitOff, d_light0);
         st.ms_compact += ctx->timer.stop(s);
         peel_inited = true;
         bufs.release(d_toff); bufs.release(d_bintot); bufs.release((void *)d_recval); bufs.release(d_reckey);
@@ -743,6 +779,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (!peel_inited) {
         KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_stamp, (size_t)m));
+        KOMB_HIP(ctx, bufs.alloc(&d_st8, (size_t)m + 16));
         KOMB_HIP(ctx, bufs.alloc(&d_truss, (size_t)m));
         KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
     }
@@ -759,7 +796,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // at C3).  A sub-round peels at least one edge: m + 2 entries; [0] = level 0 (the triangle-free edges' stamp).
     KOMB_HIP(ctx, bufs.alloc(&Q.rlevel, (size_t)m + 2));
     KOMB_HIP(ctx, hipMemsetAsync(Q.rlevel, 0, 2 * sizeof(int32_t), s));
-    TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp};
+    TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp, d_st8};
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
@@ -851,7 +888,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     ctx->timer.start(s);
     if (!peel_inited) {
         peel_ctrl_pre(s, d_grp);
-        k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_off2, d_sup, d_stamp, d_grp + kInitOff);
+        k_peel_init<<<grid_for(m, kBlock, 1024), kBlock, 0, s>>>(m, d_off, d_off2, d_sup, d_stamp, d_st8, d_grp + kInitOff);
     }
     peel_ctrl_init(s, d_ctrl, d_grp, (uint32_t)m, tail_limit);
     int launches = 0, rc = KOMB_OK;

@@ -35,7 +35,7 @@
 
 namespace komb {
 
-enum : int32_t { MODE_SCAN = 0, MODE_PROCESS = 1 };
+enum : int32_t { MODE_SCAN = 0, MODE_PROCESS = 1, MODE_RETIRE = 2 };   // RETIRE is a flag on top of the step that follows it (problems with byte states)
 
 #ifndef KOMB_PEEL_BLOCK
 #define KOMB_PEEL_BLOCK 1024
@@ -70,6 +70,34 @@ __device__ __forceinline__ int32_t alive_marker(uint32_t len)
 }
 __device__ __forceinline__ bool marker_alive(int32_t m) { return m >= kAliveMin; }
 __device__ __forceinline__ uint32_t marker_chunks(int32_t m) { return (uint32_t)(kAlive - m); }   // 0 = light
+
+// One-byte shadow of a stamp, for the problems whose item visits gather other units' states at random (k-truss: two per
+// triangle visit).  100 MB instead of 400 MB at C3: the gathers' lines come from the L2s / the 256 MB memory-side cache
+// instead of HBM.  A byte says: alive (light / heavy slice), gone, or "entered the frontier of sub-round q" as q mod
+// kStateWindow; state_rel() places such a q relative to the current sub-round r, which is exact while r - q < kStateWindow - 1:
+// codes of sub-rounds that old are rewritten as gone by the engine's RETIRE step (every kRetireEvery sub-rounds).
+enum : uint32_t { ST_ALIVE_LIGHT = 0, ST_ALIVE_HEAVY = 1, ST_GONE = 2, ST_ROUND0 = 3 };
+enum : int { REL_GONE = 0, REL_NOW = 1, REL_LATER = 2 };
+constexpr uint32_t kStateWindow = 253;          // 256 - ST_ROUND0
+#ifndef KOMB_RETIRE_EVERY
+#define KOMB_RETIRE_EVERY 120
+#endif
+constexpr int32_t kRetireEvery = KOMB_RETIRE_EVERY;           // sub-rounds between two RETIRE steps: codes in use span <= 2 * kRetireEvery + 2 < kStateWindow
+static_assert(2 * kRetireEvery + 2 < (int32_t)kStateWindow, "state codes must not wrap between two RETIRE steps");
+__device__ __forceinline__ uint8_t state_of_round(int32_t q) { return (uint8_t)(ST_ROUND0 + (uint32_t)q % kStateWindow); }
+__device__ __forceinline__ uint8_t state_of_stamp(int32_t stamp)      // initial states: stamp = alive marker, 0 (triangle-free: gone) or 1 (first frontier)
+{
+    if (stamp >= kAliveMin) return (uint8_t)(stamp == kAlive ? ST_ALIVE_LIGHT : ST_ALIVE_HEAVY);
+    return stamp == 0 ? (uint8_t)ST_GONE : state_of_round(stamp);
+}
+__device__ __forceinline__ int state_rel(uint32_t c, int32_t r)
+{
+    if (c < ST_GONE) return REL_LATER;
+    if (c == ST_GONE) return REL_GONE;
+    uint32_t d = c - ST_ROUND0 + kStateWindow - (uint32_t)r % kStateWindow;   // (q - r) mod window
+    d = d >= kStateWindow ? d - kStateWindow : d;
+    return d == 0 ? REL_NOW : (d == 1 ? REL_LATER : REL_GONE);
+}
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
@@ -227,6 +255,7 @@ __device__ __forceinline__ uint32_t plan_step(const CtrlView &cv, uint32_t grid,
     bsz = kWave;
     const uint64_t grid_waves = (uint64_t)grid * kPeelWaves;
     while (bsz > 2 && (uint64_t)cv.cur_light < grid_waves * (bsz / 2)) bsz >>= 1;
+    if (cv.mode & MODE_RETIRE) return grid;                 // a sweep over every unit's state byte
     if (cv.mode == MODE_SCAN) return (cv.live_mode != 0 && cv.live_count <= kSmallScan) ? 1u : grid;
     if (cv.cur_light <= kSmallLight && cv.cur_heavy <= kSmallHeavy) {
         // small frontier: one workgroup (its 16 wavefronts share the units) -- cheaper than a
@@ -245,12 +274,16 @@ __device__ __forceinline__ uint32_t plan_step(const CtrlView &cv, uint32_t grid,
 // so they cost one round trip, not seven.  The new state is also left in *out (LDS) so that a
 // single workgroup can go on to the next step without re-reading global memory.
 __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv, uint32_t units, CtrlView *out, uint32_t acc, int32_t launch,
-                                              int32_t *rlevel)
+                                              int32_t *rlevel, int32_t retire_every)
 {
     const int lane = lane_id();
     // from here on the state belongs to the NEXT launch: late workgroups of this one must not act on it
     if (lane == 0) { (void)atomicExch(&ctrl->seq, launch + 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __builtin_amdgcn_wave_barrier();
+    if (cv.mode & MODE_RETIRE) {                            // the state bytes are fresh: on to the step that was due
+        if (lane == 0) { ctrl->mode = cv.mode & ~MODE_RETIRE; *out = cv; out->mode = cv.mode & ~MODE_RETIRE; }
+        return;
+    }
     const bool scan = cv.mode == MODE_SCAN;
     const int sel = cv.cur_sel;
     const bool emitted = scan && (cv.live_mode != 0 || cv.remaining <= units / 2);
@@ -282,6 +315,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
         else level = nmin;                                  // jump to the first populated level
     } else {
         nsel = sel ^ 1; round += 1;
+        const bool retire = retire_every > 0 && round % retire_every == 0;
         if (cur_l + cur_h == 0) {
             if (remaining == 0) done = 1;
             else {
@@ -289,6 +323,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
                 if (remaining <= cv.tail_limit) done = 3;    // the rest goes to the problem's tail kernel
             }
         }
+        if (retire && !done) mode |= MODE_RETIRE;           // state codes of sub-rounds long gone must not wrap around (state_rel)
     }
     ctrl->mode = mode; ctrl->level = level; ctrl->round = round; ctrl->done = done;
     ctrl->cur_sel = nsel; ctrl->cur_light = cur_l; ctrl->cur_heavy = cur_h; ctrl->remaining = remaining;
@@ -312,9 +347,16 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
 //   void item_apply(ld, cv, int32_t &t0, int32_t &t1, uint32_t &c0, uint32_t &c1)
 //                                        decrements; ids of triggered units or -1, and their classes
 // (load and apply are split so that the loads of several items are in flight together)
+//   static constexpr int32_t kRetireEvery (optional) + void retire(cv, block, nblocks)
+//                                        problems with one-byte states (state_of_round): the sweep that rewrites stale codes
+template <class P, class = void> struct PeelRetire { static constexpr int32_t every = 0; };
+template <class P> struct PeelRetire<P, decltype((void)P::kRetireEvery)> { static constexpr int32_t every = P::kRetireEvery; };
+template <class P> __host__ __device__ constexpr int32_t peel_retire_every() { return PeelRetire<P>::every; }
+
 template <class P>
 __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p, int32_t launch)
 {
+    constexpr int32_t retire_every = peel_retire_every<P>();
     __shared__ CtrlView sh_cv;
     __shared__ uint32_t sh_w[kPeelWaves][4];           // per-wave counts / bases
     __shared__ uint32_t sh_base[3];
@@ -366,7 +408,10 @@ __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) voi
     const int L = cv.level;
     const int sel = cv.cur_sel;
 
-    if (cv.mode == MODE_SCAN) {
+    if (cv.mode & MODE_RETIRE) {
+        if constexpr (peel_retire_every<P>() > 0) p.retire(cv, blockIdx.x, nblk);
+        if (threadIdx.x == 0) sh_acc = 0;
+    } else if (cv.mode == MODE_SCAN) {
         // ---- input: every unit, or the compacted live list; survivors are compacted into the
         // other live buffer once at most half of the units is left
         const bool from_list = cv.live_mode != 0;
@@ -681,11 +726,11 @@ __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) voi
 #endif
         last = __shfl(last, 0);
         total = (uint32_t)__shfl((int)total, 0);
-        if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total, launch, Q.rlevel);
+        if (last) finalize_step(ctrl, cv, p.units, &sh_cv, total, launch, Q.rlevel, retire_every);
         return;
     }
     // one workgroup did the whole step: finalise locally, chain the next step if it is small too
-    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc, launch, Q.rlevel);
+    if (threadIdx.x < kWave) finalize_step(ctrl, cv, p.units, &sh_cv, sh_acc, launch, Q.rlevel, retire_every);
     if (P::kSingleStep) return;                        // (shard_dev.h: the next frontier has to be exchanged first)
     __syncthreads();
     cv = sh_cv;

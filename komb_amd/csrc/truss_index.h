@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kFinBlock, (kFinBlock / 64) * kFinPerCu / 4) void k
                                                          const uint32_t *__restrict__ bin_base,
                                                          const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
                                                          int2 *__restrict__ dense, int64_t m,
-                                                         uint2 *__restrict__ off2, int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
+                                                         uint2 *__restrict__ off2, int32_t *__restrict__ sup, int32_t *__restrict__ stamp, uint8_t *__restrict__ st8,
                                                          uint32_t *__restrict__ init, int32_t *__restrict__ light0)
 {
     // init[0] += triangle-free edges; init[1] = the smallest positive support (from k_bin_count) = the peel's first level L1.
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kFinBlock, (kFinBlock / 64) * kFinPerCu / 4) void k
             }
             *reinterpret_cast<int4 *>(sup + e0) = sv;
             *reinterpret_cast<int4 *>(stamp + e0) = mv;
+            *reinterpret_cast<uchar4 *>(st8 + e0) = make_uchar4(state_of_stamp(mv.x), state_of_stamp(mv.y), state_of_stamp(mv.z), state_of_stamp(mv.w));
         } else {
 #pragma unroll
             for (int u = 0; u < kFinE; ++u) if ((uint32_t)u < nin) {
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(kFinBlock, (kFinBlock / 64) * kFinPerCu / 4) void k
                 off2[e] = make_uint2(base + o[u], c[u]);
                 sup[e] = (int32_t)c[u];
                 stamp[e] = first ? 1 : (c[u] ? alive_marker(c[u]) : 0);
+                st8[e] = state_of_stamp(stamp[e]);
                 if (!c[u]) ++zeros;
             }
         }
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kFinBlock, (kFinBlock / 64) * kFinPerCu / 4) void k
 // state from the slice lengths.  Triangle-free edges are peeled here (stamp 0 = sub-round 0 = trussness 2); init[0] counts
 // them and init[1] receives the smallest positive support = the first populated level.
 __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t *__restrict__ off, uint2 *__restrict__ off2,
-                                                      int32_t *__restrict__ sup, int32_t *__restrict__ stamp,
+                                                      int32_t *__restrict__ sup, int32_t *__restrict__ stamp, uint8_t *__restrict__ st8,
                                                       uint32_t *__restrict__ init)
 {
     uint32_t zeros = 0;
@@ -337,8 +339,8 @@ __global__ __launch_bounds__(kBlock) void k_peel_init(int64_t m, const uint32_t 
         const int32_t s0 = (int32_t)(off[e + 1] - b0);
         off2[e] = make_uint2(b0, (uint32_t)s0);
         sup[e] = s0;
-        if (s0 == 0) { stamp[e] = 0; ++zeros; }                     // round 0 (level 0, trussness 2): gone before the first sub-round
-        else { stamp[e] = alive_marker((uint32_t)s0); lmin = min(lmin, s0); }
+        if (s0 == 0) { stamp[e] = 0; st8[e] = (uint8_t)ST_GONE; ++zeros; }                     // round 0 (level 0, trussness 2): gone before the first sub-round
+        else { const int32_t a = alive_marker((uint32_t)s0); stamp[e] = a; st8[e] = state_of_stamp(a); lmin = min(lmin, s0); }
     }
     block_add_min(zeros, lmin, &init[0], (int32_t *)&init[1]);
 }
