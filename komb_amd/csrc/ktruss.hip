@@ -104,6 +104,7 @@ struct TrussProblem {
     }
 
     __device__ __forceinline__ const int32_t *scan_marker() const { return stamp; }
+    __device__ __forceinline__ const uint8_t *scan_state() const { return st8; }
     __device__ __forceinline__ const int32_t *scan_key() const { return sup; }
     __device__ __forceinline__ void mark_scanned(uint32_t e, const CtrlView &cv) const { stamp[e] = cv.round; st8[e] = state_of_round(cv.round); }
     __device__ __forceinline__ void slice(uint32_t e, uint32_t &b, uint32_t &len) const

@@ -90,6 +90,10 @@ __device__ __forceinline__ uint8_t state_of_stamp(int32_t stamp)      // initial
     if (stamp >= kAliveMin) return (uint8_t)(stamp == kAlive ? ST_ALIVE_LIGHT : ST_ALIVE_HEAVY);
     return stamp == 0 ? (uint8_t)ST_GONE : state_of_round(stamp);
 }
+__device__ __forceinline__ int32_t marker_of_state(uint32_t c)         // what SCAN needs of a marker: alive or not, light or heavy
+{
+    return c == ST_ALIVE_LIGHT ? kAlive : (c == ST_ALIVE_HEAVY ? kAlive - 1 : 0);
+}
 __device__ __forceinline__ int state_rel(uint32_t c, int32_t r)
 {
     if (c < ST_GONE) return REL_LATER;
@@ -426,6 +430,9 @@ __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) voi
         // one 16-byte vector each, and stores the four classification bytes as one word.
         const bool vec = !from_list && !Q.scalar_scan;
         const int32_t *s_marker = p.scan_marker(), *s_key = p.scan_key();
+        constexpr bool byte_marker = peel_retire_every<P>() > 0;   // problems with one-byte states are swept through those (1 byte per unit instead of 4)
+        const uint8_t *s_state = nullptr;
+        if constexpr (byte_marker) s_state = p.scan_state();
         uint32_t n_light = 0, n_chunks = 0, n_hits = 0, n_surv = 0;   // per lane until the sums after the sweep
         int32_t lmin = 0x7FFFFFFF;
         const uint64_t tile = (uint64_t)kPeelBlock * kScanU;
@@ -439,7 +446,8 @@ __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) voi
         auto fetch = [&](uint64_t tb) {
             const uint64_t i0 = index_of(tb, 0);
             if (vec && tb < n_in && i0 + kScanU <= n_in) {
-                nm4 = *reinterpret_cast<const int4 *>(s_marker + i0);
+                if constexpr (byte_marker) nm4.x = (int32_t)*reinterpret_cast<const uint32_t *>(s_state + i0);
+                else nm4 = *reinterpret_cast<const int4 *>(s_marker + i0);
                 if (s_key) nk4 = *reinterpret_cast<const int4 *>(s_key + i0);
             }
         };
@@ -451,7 +459,10 @@ __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) voi
             const bool whole = vec && i0 + kScanU <= n_in;
             if (whole) {
                 static_assert(kScanU == 4, "the dense sweep loads int4");
-                mk[0] = nm4.x; mk[1] = nm4.y; mk[2] = nm4.z; mk[3] = nm4.w;
+                if constexpr (byte_marker) {
+#pragma unroll
+                    for (int k = 0; k < kScanU; ++k) mk[k] = marker_of_state(((uint32_t)nm4.x >> (8 * k)) & 0xFFu);
+                } else { mk[0] = nm4.x; mk[1] = nm4.y; mk[2] = nm4.z; mk[3] = nm4.w; }
                 ky[0] = nk4.x; ky[1] = nk4.y; ky[2] = nk4.z; ky[3] = nk4.w;
             }
             fetch(tb + (uint64_t)nblk * tile);
@@ -464,12 +475,17 @@ __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) voi
                     // the dense sweep, sequential ones) instead of a chain of three dependent round trips
                     if (!whole) {
                         const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
-                        mk[k] = s_marker[u];
+                        if constexpr (byte_marker) mk[k] = marker_of_state(s_state[u]);
+                        else mk[k] = s_marker[u];
                         ky[k] = s_key ? s_key[u] : 0;
                     }
                     const bool live = marker_alive(mk[k]);
-                    const uint32_t nch = marker_chunks(mk[k]);
+                    uint32_t nch = marker_chunks(mk[k]);
                     if (live && ky[k] <= L) {
+                        if constexpr (byte_marker) if (nch) {           // (a state byte only says "heavy": the chunk count is the slice's)
+                            const uint32_t u = from_list ? (uint32_t)live_in[idx] : (uint32_t)idx;
+                            uint32_t b, len; p.slice(u, b, len); nch = (len + kChunk - 1) / kChunk;
+                        }
                         if (nch == 0) code[k] = SC_LIGHT;
                         else { n_chunks += nch; code[k] = SC_HEAVY; }
                     } else if (live) { lmin = min(lmin, ky[k]); code[k] = SC_SURVIVOR; }
