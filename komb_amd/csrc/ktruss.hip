@@ -77,7 +77,8 @@ struct TrussProblem {
     int32_t *stamp;                      // alive marker, then the sub-round the edge was peeled in: its trussness is
                                          // rlevel[stamp] + 2 (PeelQueues::rlevel, written once per sub-round) -- no result store per edge
     uint8_t *st8;                        // [units + 16] the stamps' one-byte shadow the triangle visits gather from (peel_dev.h: state_of_round)
-    static constexpr int32_t kRetireEvery = komb::kRetireEvery;
+    static constexpr int32_t kRetireEvery = komb::kRetireEvery;   // (marks the problem as one with byte states: peel_dev.h)
+    int32_t retire_every;                // sub-rounds between two RETIRE steps: kRetireEvery, or less (KOMB_RETIRE_EVERY, tests)
 
     // RETIRE step: codes of sub-rounds before the current one become ST_GONE, 16 states per lane per trip
     __device__ __forceinline__ void retire(const CtrlView &cv, uint32_t block, uint32_t nblocks) const
@@ -797,7 +798,9 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // at C3).  A sub-round peels at least one edge: m + 2 entries; [0] = level 0 (the triangle-free edges' stamp).
     KOMB_HIP(ctx, bufs.alloc(&Q.rlevel, (size_t)m + 2));
     KOMB_HIP(ctx, hipMemsetAsync(Q.rlevel, 0, 2 * sizeof(int32_t), s));
-    TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp, d_st8};
+    int32_t retire_every = kRetireEvery;
+    if (const char *e = getenv("KOMB_RETIRE_EVERY")) retire_every = std::max(1, std::min((int)kRetireEvery, atoi(e)));   // (tests: RETIRE steps on small graphs)
+    TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp, d_st8, retire_every};
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));

@@ -79,10 +79,7 @@ __device__ __forceinline__ uint32_t marker_chunks(int32_t m) { return (uint32_t)
 enum : uint32_t { ST_ALIVE_LIGHT = 0, ST_ALIVE_HEAVY = 1, ST_GONE = 2, ST_ROUND0 = 3 };
 enum : int { REL_GONE = 0, REL_NOW = 1, REL_LATER = 2 };
 constexpr uint32_t kStateWindow = 253;          // 256 - ST_ROUND0
-#ifndef KOMB_RETIRE_EVERY
-#define KOMB_RETIRE_EVERY 120
-#endif
-constexpr int32_t kRetireEvery = KOMB_RETIRE_EVERY;           // sub-rounds between two RETIRE steps: codes in use span <= 2 * kRetireEvery + 2 < kStateWindow
+constexpr int32_t kRetireEvery = 120;           // sub-rounds between two RETIRE steps: codes in use span <= 2 * kRetireEvery + 2 < kStateWindow
 static_assert(2 * kRetireEvery + 2 < (int32_t)kStateWindow, "state codes must not wrap between two RETIRE steps");
 __device__ __forceinline__ uint8_t state_of_round(int32_t q) { return (uint8_t)(ST_ROUND0 + (uint32_t)q % kStateWindow); }
 __device__ __forceinline__ uint8_t state_of_stamp(int32_t stamp)      // initial states: stamp = alive marker, 0 (triangle-free: gone) or 1 (first frontier)
@@ -360,7 +357,8 @@ template <class P> __host__ __device__ constexpr int32_t peel_retire_every() { r
 template <class P>
 __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) void k_peel_step(PeelCtrl *ctrl, uint32_t *grp_done, PeelQueues Q, P p, int32_t launch)
 {
-    constexpr int32_t retire_every = peel_retire_every<P>();
+    int32_t retire_every = 0;                              // sub-rounds between two RETIRE steps (problems with one-byte states only)
+    if constexpr (peel_retire_every<P>() > 0) retire_every = p.retire_every;
     __shared__ CtrlView sh_cv;
     __shared__ uint32_t sh_w[kPeelWaves][4];           // per-wave counts / bases
     __shared__ uint32_t sh_base[3];

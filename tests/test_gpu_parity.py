@@ -421,6 +421,38 @@ def test_wedge_enumeration_paths(K, O, monkeypatch):
             assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr), name
 
 
+def test_edge_state_bytes_and_retire_steps(K, O, monkeypatch):
+    """The truss peel gathers one-byte edge states (peel_dev.h: state_of_round) whose sub-round codes are taken modulo 253 and
+    kept unambiguous by the engine's RETIRE step.  General engine only (KOMB_FINISH=none: every sub-round runs in it, in-kernel
+    chains included) on graphs with hundreds of sub-rounds -- more than the code window -- with the default period, and with a
+    RETIRE step after every 1 / 2 / 7 sub-rounds; the local finish on top for the hand-over from byte states."""
+    iu = np.triu_indices(90, 1)
+    cases = [("hug 100k alpha 2.1", 100000, np.asarray(K.gen_hug_edges(100000, 300000, 2.1, 3)).reshape(-1, 2)),
+             # a path of overlapping cliques of growing size: one level after the other, each a cascade of its own
+             ("clique ladder", 4000, np.concatenate([np.stack(np.triu_indices(k, 1), axis=1) + 37 * i for i, k in enumerate(range(3, 100))]).astype(np.int64)),
+             ("K_90 + tail", 600, np.concatenate([np.stack(iu, axis=1), np.stack([np.arange(89, 599), np.arange(90, 600)], axis=1)]).astype(np.int64))]
+    most = 0
+    for name, nv, uv in cases:
+        uv = np.ascontiguousarray(uv, dtype=np.int64)
+        o_rowptr, o_col = O.simplify(nv, uv)
+        otr = O.trussness(o_rowptr, o_col)
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            rounds = 0
+            for env in ({"KOMB_FINISH": "none"}, {"KOMB_FINISH": "none", "KOMB_RETIRE_EVERY": "1"}, {"KOMB_FINISH": "none", "KOMB_RETIRE_EVERY": "2"},
+                        {"KOMB_FINISH": "none", "KOMB_RETIRE_EVERY": "7"}, {"KOMB_FINISH": "local", "KOMB_RETIRE_EVERY": "3", "KOMB_LOCAL_LIMIT": "200"},
+                        {"KOMB_FINISH": "lds", "KOMB_RETIRE_EVERY": "5"}):
+                for k, v in env.items(): monkeypatch.setenv(k, v)
+                eu, ev, tr = a.run_truss()
+                st = a.stats()
+                for k in env: monkeypatch.delenv(k, raising=False)
+                assert np.array_equal(tr, otr), (name, env)
+                rounds = max(rounds, st["truss_subrounds"])
+            print(name, "sub-rounds", rounds)
+            most = max(most, rounds)
+    assert most > 2 * 253, most                         # the codes did wrap
+
+
 def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
     """A graph whose capacity-bounded slices hold more than 2^32 entries by themselves (dense uniform random, 30 000
     vertices, ~12.5 M edges of degree ~830: sum over edges of d(lower endpoint) - 1 ~ 1e10), so the single pass runs with
