@@ -1,7 +1,7 @@
 """Randomised soak: many graphs of assorted shapes, k-core and k-truss (with support) against the CPU oracle,
 each under a random choice of the finish (local fixed point / LDS tails / none), its hand-over thresholds and item
 limit, and of the index layout (record stream / bounded slices / two pass, 32 / 64-bit slice offsets, dense or block-less
-own-role entries, a dense region or a record stream that runs out), the fixed point's
+own-role entries, a dense region or a record stream that runs out), the period of the engine's RETIRE step, the fixed point's
 notification kernel, and -- one graph in seven -- the sharded peel's engine with one rank (shard_dev.h).
     python tests/manual/soak.py [n_graphs] [seed]"""
 import os, sys, time
@@ -55,7 +55,7 @@ with komb_amd.KombAccel() as a:
             if on: os.environ[k] = "1"
             else: os.environ.pop(k, None)
         os.environ["KOMB_INDEX"] = str(rng.choice(["stream", "stream", "slices", "two_pass"]))
-        for k, choices in (("KOMB_OWN_DENSE_CAP", ["", "", "0", "200", "5000"]), ("KOMB_REC_CAP", ["", "", "", "100", "3000"]),
+        for k, choices in (("KOMB_OWN_DENSE_CAP", ["", "", "0", "200", "5000"]), ("KOMB_REC_CAP", ["", "", "", "100", "3000"]), ("KOMB_RETIRE_EVERY", ["", "", "1", "3", "40"]),
                            ("KOMB_LOCAL_DEFER_CHUNKS", ["", "1"])):
             v = str(rng.choice(choices))
             if v: os.environ[k] = v
@@ -73,7 +73,7 @@ with komb_amd.KombAccel() as a:
                   f"TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
                   f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')} NO_OWN_DENSE={os.environ.get('KOMB_NO_OWN_DENSE')} LOCAL_ITEMS={os.environ.get('KOMB_LOCAL_ITEMS')} "
                   f"INDEX={os.environ.get('KOMB_INDEX')} OWN_DENSE_CAP={os.environ.get('KOMB_OWN_DENSE_CAP')} REC_CAP={os.environ.get('KOMB_REC_CAP')} "
-                  f"DEFER={os.environ.get('KOMB_LOCAL_DEFER_CHUNKS')} SHARD_PEEL={os.environ.get('KOMB_SHARD_PEEL')}", flush=True)
+                  f"DEFER={os.environ.get('KOMB_LOCAL_DEFER_CHUNKS')} SHARD_PEEL={os.environ.get('KOMB_SHARD_PEEL')} RETIRE={os.environ.get('KOMB_RETIRE_EVERY')}", flush=True)
         if g % 100 == 99:
             print(f"{g + 1} graphs, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {n_graphs} graphs, {bad} mismatches, {time.time() - t0:.0f} s")
