@@ -79,6 +79,9 @@ struct TrussProblem {
     uint8_t *st8;                        // [units + 16] the stamps' one-byte shadow the triangle visits gather from (peel_dev.h: state_of_round)
     static constexpr int32_t kRetireEvery = komb::kRetireEvery;   // (marks the problem as one with byte states: peel_dev.h)
     int32_t retire_every;                // sub-rounds between two RETIRE steps: kRetireEvery, or less (KOMB_RETIRE_EVERY, tests)
+#ifdef KOMB_DEBUG_SWITCHES
+    int ablate;                          // KOMB_PEEL_ABLATE (breaks results on purpose; timing of single steps): 1 no decrements, 2 no state gathers, 4 no index loads
+#endif
 
     // RETIRE step: codes of sub-rounds before the current one become ST_GONE, 16 states per lane per trip
     __device__ __forceinline__ void retire(const CtrlView &cv, uint32_t block, uint32_t nblocks) const
@@ -120,6 +123,15 @@ struct TrussProblem {
         Loaded ld;
         // (an index entry is read once per visit and never again soon: the non-temporal hint keeps it from displacing the state
         // and support lines the gathers and atomics reuse -- same box: peel 9.2 -> 9.0 ms; the same hint on the stamp gathers: 10.2)
+#ifdef KOMB_DEBUG_SWITCHES
+        if (ablate & 6) {
+            int2 p = make_int2((int)(((uint32_t)me * 2654435761u) % units), (int)(((uint32_t)me * 40503u + pos) % units));
+            if (!(ablate & 4)) { const unsigned long long pq = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(inc) + pos); p = make_int2((int)(uint32_t)pq, (int)(uint32_t)(pq >> 32)); }
+            ld.me = me; ld.x = p.x; ld.y = p.y;
+            ld.cx = (ablate & 2) ? 0u : st8[p.x]; ld.cy = (ablate & 2) ? 0u : st8[p.y];
+            return ld;
+        }
+#endif
         const unsigned long long pq = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(inc) + pos);
         const int2 p = make_int2((int)(uint32_t)pq, (int)(uint32_t)(pq >> 32));
         ld.me = me; ld.x = p.x; ld.y = p.y;
@@ -132,8 +144,11 @@ struct TrussProblem {
         const int rx = state_rel(ld.cx, r), ry = state_rel(ld.cy, r);
         if (rx == REL_GONE || ry == REL_GONE) return;   // an edge of the triangle is already gone
         const bool xin = (rx == REL_NOW), yin = (ry == REL_NOW);
-        const bool decx = !xin && (!yin || ld.me < ld.y);
-        const bool decy = !yin && (!xin || ld.me < ld.x);
+        bool decx = !xin && (!yin || ld.me < ld.y);
+        bool decy = !yin && (!xin || ld.me < ld.x);
+#ifdef KOMB_DEBUG_SWITCHES
+        if (ablate & 1) { decx = false; decy = false; }
+#endif
         // (a triggered heavy edge's chunk count is in the alive marker its stamp still holds)
         if (decx && atomicSub(&sup[ld.x], 1) == L + 1) {
             c0 = ld.cx == ST_ALIVE_HEAVY ? marker_chunks(stamp[ld.x]) : 0u;
@@ -800,7 +815,11 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, hipMemsetAsync(Q.rlevel, 0, 2 * sizeof(int32_t), s));
     int32_t retire_every = kRetireEvery;
     if (const char *e = getenv("KOMB_RETIRE_EVERY")) retire_every = std::max(1, std::min((int)kRetireEvery, atoi(e)));   // (tests: RETIRE steps on small graphs)
+#ifdef KOMB_DEBUG_SWITCHES
+    TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp, d_st8, retire_every, getenv("KOMB_PEEL_ABLATE") ? atoi(getenv("KOMB_PEEL_ABLATE")) : 0};
+#else
     TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp, d_st8, retire_every};
+#endif
     TailBufs T{};
     if (fin == FIN_LDS && tail_limit) {
         KOMB_HIP(ctx, bufs.alloc(&T.vmap, (size_t)nv));
