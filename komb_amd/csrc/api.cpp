@@ -178,6 +178,16 @@ int komb_truss_run_sharded(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, in
     return truss_run(ctx, vmask, rank, world, allreduce, user);
 }
 
+int komb_truss_run_slice(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world)
+{
+    KOMB_TRY(require_device(ctx));
+    if (world < 1 || rank < 0 || rank >= world) KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_truss_run_slice: bad rank %d / world %d", rank, world);
+    ctx->slice_rank = rank; ctx->slice_world = world;
+    const int rc = truss_run(ctx, vmask, 0, 1, nullptr, nullptr);
+    ctx->slice_rank = 0; ctx->slice_world = 1;
+    return rc;
+}
+
 int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub)
 {
     if (!ctx) return KOMB_ERR_ARG;

@@ -265,6 +265,7 @@ struct komb_ctx {
     int64_t t_ne = -1;                       // edges of the (sub)graph last run
     int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr; // canonical order
     bool truss_done = false;
+    int slice_rank = 0, slice_world = 1;     // komb_truss_run_slice: the canonical edges whose results this run materialises
     bool shard_peel = false;                 // komb_set_shard_peel: sharded runs split the peel too (shard_dev.h)
 
     // ---- pinned host mirrors of the control blocks (double buffered)

@@ -987,7 +987,16 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;          // (not pool blocks: truss_free's put() ignores them)
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-        k_gather_canonical<<<grid_for(m), kBlock, 0, s>>>(ctx->d_canon2e, m, d_res, ctx->d_t_truss, ctx->d_t_sup);
+        // (komb_truss_run_slice: this rank's slice of the canonical edges only, zeros elsewhere)
+        uint32_t k_lo = 0, k_hi = (uint32_t)m;
+        if (ctx->slice_world > 1) {
+            shard_bounds((uint64_t)m, ctx->slice_rank, ctx->slice_world, &k_lo, &k_hi);
+            for (int32_t *out : {ctx->d_t_truss, ctx->d_t_sup}) {
+                if (k_lo) KOMB_HIP(ctx, hipMemsetAsync(out, 0, (size_t)k_lo * sizeof(int32_t), s));
+                if (k_hi < (uint32_t)m) KOMB_HIP(ctx, hipMemsetAsync(out + k_hi, 0, ((size_t)m - k_hi) * sizeof(int32_t), s));
+            }
+        }
+        if (k_hi > k_lo) k_gather_canonical<<<grid_for((int64_t)k_hi - k_lo), kBlock, 0, s>>>(ctx->d_canon2e, (int64_t)k_lo, (int64_t)k_hi, d_res, ctx->d_t_truss, ctx->d_t_sup);
     } else {
         uint32_t *d_junk_rp = nullptr; int32_t *d_eu = nullptr, *d_ev = nullptr;
         unsigned long long *d_kbits = nullptr; uint32_t *d_krank = nullptr;

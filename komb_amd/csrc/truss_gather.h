@@ -30,10 +30,11 @@ __global__ __launch_bounds__(kBlock) void k_truss_resolve(const int32_t *__restr
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ canon2e, int64_t m, const int2 *__restrict__ res,
+// (k_lo, k_hi: the canonical edges this run materialises -- all of them, or the rank's slice of komb_truss_run_slice)
+__global__ __launch_bounds__(kBlock) void k_gather_canonical(const uint32_t *__restrict__ canon2e, int64_t k_lo, int64_t k_hi, const int2 *__restrict__ res,
                                                              int32_t *__restrict__ tr_out, int32_t *__restrict__ sup_out)
 {
-    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < m; k += (int64_t)gridDim.x * kBlock) {
+    for (int64_t k = k_lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < k_hi; k += (int64_t)gridDim.x * kBlock) {
         const int2 r = res[canon2e[k]];
         tr_out[k] = r.x;
         sup_out[k] = r.y;

@@ -90,6 +90,26 @@ def core_run_sharded(acc, group=None):
     acc._check(rc)
 
 
+def truss_run_slice(acc, vmask=None, group=None):
+    """komb_truss_run_slice with this process' rank / world size: every rank peels the whole graph, each materialises its
+    slice of the canonical results; nothing is exchanged (gather_slices() below reassembles them where that is wanted)."""
+    import torch.distributed as dist
+    acc.truss_run_slice(dist.get_rank(group), dist.get_world_size(group), vmask)
+
+
+def gather_slices(arr, group=None):
+    """The whole result from the ranks' slices of komb_truss_run_slice: they are zero outside their slice, so a SUM
+    all-reduce of the fetched host arrays is the concatenation (int32, in place; gloo or RCCL through torch)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(arr)
+    if dist.get_backend(group) == "nccl":
+        d = t.cuda(); dist.all_reduce(d, group=group); t.copy_(d.cpu())
+    else:
+        dist.all_reduce(t, group=group)
+    return arr
+
+
 def truss_run_sharded(acc, vmask=None, group=None, shard_peel=None):
     """komb_truss_run_sharded on this rank's KombAccel; every rank must call it.  shard_peel=True/False switches the
     sharded peel (komb_set_shard_peel) for this and the following runs; None leaves the context as it is."""

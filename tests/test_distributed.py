@@ -74,13 +74,15 @@ def test_processes_sharing_one_gpu(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--same-graph", "--shard"], ["--replicas"], ["--batch"], ["--shard-peel"]])
+@pytest.mark.parametrize("extra", [[], ["--c4-allreduce"], ["--same-graph", "--shard"], ["--replicas"], ["--batch"], ["--shard-peel"]])
 def test_bench_two_ranks_on_one_gpu(built, extra):
     """`python bench.py --gpus 2` started plainly: it spawns its two ranks itself (before anything has touched the GPU) and
-    rank 0 prints the one JSON line.  Both ranks share GPU 0 here (KOMB_BENCH_ONE_DEVICE=1, exchange over gloo).  Default
-    (= BASELINE configs[3]; --same-graph --shard is the older spelling): the same graph on both ranks, the support count
-    sharded + all-reduce, strong scaling; --replicas: no sharding; --batch: one graph per rank, weak scaling, own metric name;
-    --shard-peel: the default plus the peel sharded by edge range (one frontier exchange per sub-round)."""
+    rank 0 prints the one JSON line.  Both ranks share GPU 0 here (KOMB_BENCH_ONE_DEVICE=1, exchange over gloo).  Default:
+    the same graph on both ranks, the whole path on both, each rank's slice of the results (komb_truss_run_slice; verified
+    against a whole run after the timed region), no exchange; --c4-allreduce (= BASELINE configs[3] to the letter;
+    --same-graph --shard is the older spelling): the support count sharded + all-reduce, strong scaling; --replicas: nothing
+    sliced; --batch: one graph per rank, weak scaling, own metric name; --shard-peel: --c4-allreduce plus the peel sharded by
+    edge range (one frontier exchange per sub-round)."""
     import json
     env = dict(os.environ, KOMB_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1",
@@ -96,9 +98,12 @@ def test_bench_two_ranks_on_one_gpu(built, extra):
         assert d["scaling"] == "weak" and "independent graphs" in par and d["metric"].startswith("aggregate peeled edges/sec")
     else:
         assert d["scaling"] == "strong" and d["metric"] == "peeled edges/sec (k-truss)"
-        assert ("replicas" in par) if extra == ["--replicas"] else ("sharded" in par and d["config"]["workload"].startswith("C4"))
-        if extra != ["--replicas"]:
-            assert d["phases_ms"]["ms_allreduce"] > 0
+        if extra == []:
+            assert "slices verified after the timed region: True" in par and d["phases_ms"]["ms_allreduce"] == 0
+        elif extra == ["--replicas"]:
+            assert "replicas" in par
+        else:
+            assert "sharded" in par and d["config"]["workload"].startswith("C4") and d["phases_ms"]["ms_allreduce"] > 0
         if extra == ["--shard-peel"]:                   # the peel by edge range on top: exchanges counted, k-core sharded as well
             assert d["config"]["shard_peel"]["exchanges"] > 0 and "edge range" in d["config"]["workload"] and "sharded" in d["kcore"]
         else:

@@ -26,7 +26,7 @@ def _i64(x):
 
 def test_native_library_is_loaded(K):
     lib = K._lib.load()
-    assert lib.komb_abi_version() == 5
+    assert lib.komb_abi_version() == 6
     with open("/proc/self/maps") as f:
         assert "libkomb_accel.so" in f.read()
 
@@ -451,6 +451,42 @@ def test_edge_state_bytes_and_retire_steps(K, O, monkeypatch):
             print(name, "sub-rounds", rounds)
             most = max(most, rounds)
     assert most > 2 * 253, most                         # the codes did wrap
+
+
+def test_result_slices(K, O):
+    """komb_truss_run_slice (what bench.py --gpus N runs on every rank): the whole path, the results of the rank's slice of
+    the canonical edges, zeros elsewhere -- the slices of 1, 2, 3 and 7 ranks add up to the whole result (trussness and
+    support), the edge list is complete on every rank; with a vertex mask every rank holds the whole (sub)result."""
+    nv = 30000
+    uv = np.asarray(K.gen_hug_edges(nv, 90000, 2.4, 9)).reshape(-1, 2)
+    o_rowptr, o_col = O.simplify(nv, uv)
+    osup, _ = O.support(o_rowptr, o_col)
+    otr = O.trussness(o_rowptr, o_col)
+    ne = len(otr)
+    with K.KombAccel() as a:
+        a.from_edges(nv, uv)
+        eu0, ev0, _ = a.run_truss()
+        for world in (1, 2, 3, 7):
+            tot_tr = np.zeros(ne, np.int64); tot_sup = np.zeros(ne, np.int64)
+            for rank in range(world):
+                a.truss_run_slice(rank, world)
+                eu, ev, tr, sup = a.truss_fetch(with_support=True)
+                lo, hi = ne * rank // world, ne * (rank + 1) // world
+                assert np.array_equal(eu, eu0) and np.array_equal(ev, ev0)
+                assert np.array_equal(tr[lo:hi], otr[lo:hi]) and np.array_equal(sup[lo:hi], osup[lo:hi]), (world, rank)
+                assert not tr[:lo].any() and not tr[hi:].any() and not sup[:lo].any() and not sup[hi:].any(), (world, rank)
+                tot_tr += tr; tot_sup += sup
+            assert np.array_equal(tot_tr, otr) and np.array_equal(tot_sup, osup), world
+        mask = (np.random.default_rng(4).random(nv) < 0.7).astype(np.uint8)
+        weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
+        a.truss_run_slice(1, 3, mask)
+        seu, sev, stra = a.truss_fetch()
+        assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+        for bad in ((3, 3), (-1, 2), (0, 0)):
+            with pytest.raises(Exception):
+                a.truss_run_slice(*bad)
+        eu, ev, tr = a.run_truss()                       # a plain run afterwards is whole again
+        assert np.array_equal(tr, otr)
 
 
 def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
