@@ -208,7 +208,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (barriers, the max over the ranks' times) on gloo; the data exchange on RCCL when every
         # rank can use it -- the choice is made collectively (MIN over the ranks' flags), never rank by rank
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # ranks != 0 wait here for rank 0's build
+        # (gloo announces its connections on fd 1: stdout carries the one JSON line and nothing else)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # ranks != 0 wait here for rank 0's build
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         ok = 0
         why = "one-device rehearsal"
         if not args.shard:
