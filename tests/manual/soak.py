@@ -2,7 +2,8 @@
 each under a random choice of the finish (local fixed point / LDS tails / none), its hand-over thresholds and item
 limit, and of the index layout (record stream / bounded slices / two pass, 32 / 64-bit slice offsets, dense or block-less
 own-role entries, a dense region or a record stream that runs out), the period of the engine's RETIRE step, the fixed point's
-notification kernel, and -- one graph in seven -- the sharded peel's engine with one rank (shard_dev.h).
+notification kernel, -- one graph in seven -- the sharded peel's engine with one rank (shard_dev.h), and -- one in five --
+the sliced results of komb_truss_run_slice for a random rank of a random world size.
     python tests/manual/soak.py [n_graphs] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -66,6 +67,13 @@ with komb_amd.KombAccel() as a:
         eu, ev, tr, sup = a.run_truss(with_support=True)
         ok = (np.array_equal(core, O.coreness(rowptr, col)) and np.array_equal(sup, O.support(rowptr, col)[0])
               and np.array_equal(tr, O.trussness(rowptr, col)))
+        if ok and rng.random() < 0.2 and len(tr):                  # the sliced results of komb_truss_run_slice (bench.py --gpus N)
+            world = int(rng.integers(1, 9)); rank = int(rng.integers(0, world))
+            a.truss_run_slice(rank, world)
+            seu, sev, stra, ssup = a.truss_fetch(with_support=True)
+            lo, hi = len(tr) * rank // world, len(tr) * (rank + 1) // world
+            ok = (np.array_equal(seu, eu) and np.array_equal(sev, ev) and np.array_equal(stra[lo:hi], tr[lo:hi]) and np.array_equal(ssup[lo:hi], sup[lo:hi])
+                  and not stra[:lo].any() and not stra[hi:].any() and not ssup[:lo].any() and not ssup[hi:].any())
         if not ok:
             bad += 1
             np.save(f"gpurun_out/soak_fail_{g}.npy", uv)
