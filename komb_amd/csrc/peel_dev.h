@@ -324,7 +324,9 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
                 if (remaining <= cv.tail_limit) done = 3;    // the rest goes to the problem's tail kernel
             }
         }
-        if (retire && !done) mode |= MODE_RETIRE;           // state codes of sub-rounds long gone must not wrap around (state_rel)
+        // state codes of sub-rounds long gone must not wrap around (state_rel).  Also when the remainder is being offered to a
+        // finish (done = 3): should the finish refuse it, the engine goes on from this state and must not have skipped a RETIRE
+        if (retire && done != 1 && done != 2) mode |= MODE_RETIRE;
     }
     ctrl->mode = mode; ctrl->level = level; ctrl->round = round; ctrl->done = done;
     ctrl->cur_sel = nsel; ctrl->cur_light = cur_l; ctrl->cur_heavy = cur_h; ctrl->remaining = remaining;
