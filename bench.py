@@ -458,6 +458,18 @@ def main():
                                   if phase["ms_tri_fill"] + phase["ms_tri_count"] > 0 else None),
             "whole_step_bytes": sum(v[2] for v in kernels.values()),
             "whole_step_frac": sum(v[2] for v in kernels.values()) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            # SURVEY 8(d)'s secondary ceilings.  The peel engine is bounded by its decrements, not by bytes: a returning atomic on a
+            # per-edge counter costs ~20 ps (50 G/s over the chip, measured by switching them off / adding them in a debug build:
+            # profiles/r04_peel_first_step_ablation.txt; the same with the counters packed into a cache-resident array), and a
+            # triangle owes at most two; k-core: one per (peeled vertex, live neighbour) slot, launches x the ~15 us step floor
+            "secondary_ceilings": {
+                "decrement_rate_G_per_s_measured": 50.0,
+                "truss_decrements_upper_bound": 2 * st["triangles"],
+                "truss_decrement_floor_ms": 2 * st["triangles"] / 50e9 * 1e3,
+                "truss_engine_ms": kernels["k_peel_step<Truss>"][0] if "k_peel_step<Truss>" in kernels else None,
+                "kcore_slot_visits_upper_bound": 2 * ne, "kcore_decrement_floor_ms": 2 * ne / 50e9 * 1e3,
+                "kcore_launches": core_stats["core_launches"], "kcore_ms": core_ms,
+            },
         }
         out = {
             "metric": ("peeled edges/sec (k-truss)" if not args.batch else
