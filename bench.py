@@ -3,27 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full pass of the k-truss path (triangle support, incidence
-index, level-synchronous peel, canonical gather: komb_truss_run) over the
-synthetic power-law unitig graph, with the graph already resident in HBM when
-the timed region starts (the resident graph object includes the oriented CSR in
-(degree,id)-ranked internal ids; nothing a previous komb_truss_run computed is
-reused).  Rank 0 prints ONE JSON line.
+One "step" = one full pass of the k-truss path over the synthetic power-law unitig graph, from the resident simple graph
+(the symmetric CSR igraph_simplify would leave) to per-edge trussness in canonical order -- what igraph_trussness does
+(reference src/graph.cpp:508; SURVEY 8(d): "support computation + full peel, H2D of the CSR excluded"):
+    preparation   (degree,id) renumbering + orientation + canonical edge map + the enumeration's lines and tasks
+                  (truss_prep.hip; komb_stats.ms_prepare),
+    support       triangle enumeration + incidence index,
+    peel          level-synchronous sub-rounds + local fixed point,
+    gather        results in canonical edge order.
+Every timed step starts with komb_truss_unprepare: NOTHING a previous step computed is reused (rounds 1-4 built the
+preparation with the graph, outside the timed region; `value_resident` is that older figure: the same step on a graph whose
+preparation is kept, as a second KOMB call on the same graph would find it).  Rank 0 prints ONE JSON line.
 
-N=1 workload = BASELINE.json configs[2] (|V|=10M, |E|~100M, full k-truss, the
-configuration the metric is quoted on).  --config c2 selects configs[1]
-(|V|=1M, |E|~10M); the k-core time of the same graph is reported alongside.
+N=1 workload = BASELINE.json configs[2] (|V|=10M, |E|~100M, full k-truss, the configuration the metric is quoted on).
+--config c2 selects configs[1] (|V|=1M, |E|~10M); the k-core time of the same graph is reported alongside.
 
-N>1: the SAME graph on every rank ("scaling": "strong", `value` = |E| / the slowest
-rank's time).  Support, index and peel of ONE graph do not shard across GPUs at a
-profit (DESIGN.md section 6 has the byte counts), so every rank runs them whole and
-materialises only ITS slice of the canonical results (komb_truss_run_slice): no
-collective on the data path, never slower than N = 1 by construction.  Opt-in:
---c4-allreduce = BASELINE.json configs[3] to the letter (the triangle support counted
-in shards and summed with one RCCL all-reduce over xGMI, then everything replicated:
-the count is redundant work, 0.80-0.84 x by arithmetic), --shard-peel on top of it,
---replicas (nothing sliced) and --batch (one graph per rank, seed + rank, nothing
-exchanged: weak scaling, its own metric name).
+N>1 (plain `--gpus N`) = BASELINE.json configs[3] / north_star's partition: the SAME graph on every rank ("scaling":
+"strong", `value` = |E| / the slowest rank's time); the triangle support is counted in shards (each rank its range of the
+task table) and summed with one all-reduce of the |E|+1 support words (RCCL over xGMI), and the peel is sharded by edge
+range: rank r owns the live supports of its internal edge ids and the decrements on them, the ranks' parts of the frontier
+are exchanged every sub-round (komb_set_shard_peel).  Opt-in alternatives, each also timed after the region and printed
+beside the headline under `alternatives`: --c4-allreduce (the support all-reduce only, the peel replicated: rounds 1-3's
+default), --replicas-sliced (round 4's default: nothing exchanged, every rank runs the whole path and materialises its slice
+of the canonical results), --replicas (nothing sliced), --batch (one graph per rank, seed + rank: weak scaling, its own
+metric name).
 """
 import argparse
 import json
@@ -42,21 +45,25 @@ CONFIGS = {
     "c2": (1_000_000, 2_450_000, 2.6, 42, "C2: synthetic power-law unitig graph |V|=1M |E|~10M, full k-truss peel"),
     "tiny": (100_000, 245_000, 2.6, 42, "tiny: |V|=100k |E|~1M (debug)"),
 }
-CPU_SAMPLE = (3_000_000, 7_350_000, 2.6, 42)  # ~30M edges: ~80 s of single-thread CPU work, ~13 s on 16 threads (one graph for both)
+CPU_SAMPLE = "c2"              # the single-thread CPU figure is timed on the C2 graph (~25 s); the all-cores one on the workload itself
+PHASES = ("ms_prepare", "ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_sort", "ms_compact", "ms_peel", "ms_tail",
+          "ms_truss_local", "ms_gather", "ms_exchange")
 
 
 def algorithmic_bytes(st):
     """Bytes each phase must move, per step (DESIGN.md 'Algorithmic bytes').
-    E = edges, T = triangles, O = sum over oriented edges of d+(a)+d+(b), R = record positions of the stream."""
-    E, T, O, R = st["ne"], st["triangles"], st["oriented_items"], st["tri_records"]
+    V = vertices, E = edges, T = triangles, O = sum over oriented edges of d+(a)+d+(b), R = record positions of the stream."""
+    V, E, T, O, R = st["nv"], st["ne"], st["triangles"], st["oriented_items"], st["tri_records"]
+    # preparation: the symmetric CSR in once (rowptr + both directions of every edge); out once: oriented targets + sources,
+    # the canonical edge list, the canonical map, one 64-byte line and two id maps per vertex
+    prepare = (4 * V + 8 * E) + 8 * E + 8 * E + 4 * E + 64 * V + 8 * V
     tri_count = 12 * E + 4 * O + 24 * T                 # SURVEY 8(d) B_sup
-    tri_fill = 12 * E + 4 * O + 24 * T + 24 * T         # same reads, 3 cursor RMW + 3 pair stores per triangle
     peel = 8 * E + 24 * T + 24 * T + 16 * T             # truss+stamp per edge; slice entries; two stamps per entry; 2 RMW per triangle
     survey_peel = 8 * E + 4 * st["sum_deg_sq"] + 16 * T # SURVEY 8(d) B_peel (merge re-intersection; not what we do)
     sort = 2 * 2 * 12 * R                               # the passes that run: two radix passes over 12-byte records, read + write
     finish = 16 * E + 48 * T + 4 * R                    # supports and slice pairs; every entry in once (record or block entry), out once
     gather = 20 * E + 20 * E                            # resolve: stamp + slice pair in, (trussness, support) out; gather: map + pair in, two words out
-    return {"tri_count": tri_count, "tri_fill": tri_fill, "peel": peel, "survey_peel": survey_peel,
+    return {"prepare": prepare, "tri_count": tri_count, "peel": peel, "survey_peel": survey_peel,
             "sort": sort, "finish": finish, "gather": gather}
 
 
@@ -68,19 +75,18 @@ def measured_traffic(config, kernel):
     if not files:
         return None, None, None
     data = json.load(open(files[-1]))
-    name = kernel
-    rec = data.get(name)
+    rec = data.get(kernel)
     if not rec:
         return None, None, os.path.basename(files[-1])
     return rec["hbm_bytes_per_launch"], rec.get("hbm_bytes_per_launch_max"), os.path.basename(files[-1])
 
 
-def cpu_baseline():
+def cpu_baseline(workload_csr, workload_ne):
     """The CPU restatement of igraph's trussness (oracle/, test infrastructure) timed on this box's host cores, next to
     the GPU figure: single thread pinned to one core (igraph is single-threaded and the reference calls it from one
-    thread, src/graph.cpp:508) on a bounded sample of the same generator (|E| ~ 30M), and the OpenMP all-cores variant on
-    the same sample.  The library is compiled on this machine for its own instruction set (oracle/Makefile target native)."""
-    import numpy as np  # noqa: F401
+    thread, src/graph.cpp:508) on a bounded sample of the same generator (the C2 graph, |E| ~ 10M), and the OpenMP
+    all-cores variant on the WORKLOAD ITSELF (the full graph the GPU figure is quoted on).  The library is compiled on this
+    machine for its own instruction set (oracle/Makefile target native)."""
     import komb_amd
     from oracle import oracle as O
     model = "unknown"
@@ -94,9 +100,10 @@ def cpu_baseline():
         pass
     native = O.native_lib() is not None
     run1 = (lambda rp, c: O.trussness_native(rp, c, 1)) if native else O.trussness
-    nv, ncl, alpha, seed = CPU_SAMPLE
+    nv, ncl, alpha, seed = CONFIGS[CPU_SAMPLE][:4]
     uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
     rowptr, col = O.simplify(nv, uv)
+    del uv
     ne = len(col) // 2
     cpus = sorted(os.sched_getaffinity(0))
     os.sched_setaffinity(0, {cpus[0]})                    # taskset: one core for the single-thread figure
@@ -108,21 +115,21 @@ def cpu_baseline():
         os.sched_setaffinity(0, set(cpus))
     out = {"value": ne / dt, "unit": "edges/s", "cores": 1, "kind": "port",
            "sample": f"oracle orc_trussness (support + bucket peel, 1 thread pinned to cpu {cpus[0]}, "
-                     f"{'-march=native' if native else 'portable build'}) on |V|={nv} |E|={ne} of the same generator: {dt:.1f} s",
+                     f"{'-march=native' if native else 'portable build'}) on the C2 graph |V|={nv} |E|={ne} of the same generator: {dt:.1f} s",
            "cpu_model": model, "host_cpus": len(cpus),
            "full_graph_recorded": "the full C3 graph (|E|=100.1M) took 335 s = 3.0e5 edges/s on one thread of a GPU box "
                                   "(profiles/r01_c3_full_parity.log)"}
-    if native:
+    if native and workload_csr is not None:
         # the GPU boxes show every CPU of the host in the affinity mask but grant a share of 16 per GPU: more threads
         # than that only thrash (256 threads: 116 s against 15 s on one)
         nthr = min(len(cpus), 16)
-        nv2, ne2 = nv, ne                                  # the same sample graph
+        rp_w, col_w = workload_csr
         t0 = time.perf_counter()
-        O.trussness_native(rowptr, col, nthr)
+        O.trussness_native(rp_w, col_w, nthr)
         dt2 = time.perf_counter() - t0
-        out["all_cores"] = {"value": ne2 / dt2, "unit": "edges/s", "cores": nthr, "kind": "port",
+        out["all_cores"] = {"value": workload_ne / dt2, "unit": "edges/s", "cores": nthr, "kind": "port",
                             "sample": f"oracle orc_trussness_omp (parallel supports + level-synchronous parallel peel, OpenMP, "
-                                      f"{nthr} threads) on |V|={nv2} |E|={ne2}: {dt2:.1f} s"}
+                                      f"{nthr} threads) on the WHOLE workload graph |E|={workload_ne}: {dt2:.1f} s"}
     return out
 
 
@@ -138,33 +145,36 @@ def main():
                          "shape (KOMB.py --file-list); nothing is exchanged, weak scaling, reported under its own metric name")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1, opt-in: the same graph on every rank, every rank runs the whole single-GPU path, no exchange")
+    ap.add_argument("--replicas-sliced", action="store_true",
+                    help="N > 1, opt-in (round 4's default): the same graph on every rank, every rank runs the whole path and materialises "
+                         "only its slice of the canonical results (komb_truss_run_slice); no exchange")
     ap.add_argument("--same-graph", action="store_true", help="(the default for N > 1; accepted for older command lines)")
     ap.add_argument("--c4-allreduce", "--shard", dest="shard", action="store_true",
-                    help="N > 1, opt-in: BASELINE configs[3] to the letter -- the support-counting enumeration split by source-vertex range "
-                         "+ one all-reduce of the |E|+1 support words, then index build, peel and gather replicated (rounds 1-3's default)")
+                    help="N > 1, opt-in: the support-counting enumeration split over the ranks + one all-reduce of the |E|+1 support words, "
+                         "then index build, peel and gather replicated (rounds 1-3's default)")
     ap.add_argument("--shard-peel", action="store_true",
-                    help="N > 1, opt-in, on top of --c4-allreduce (implies it): the peel sharded by edge range too, the ranks' parts of the frontier "
-                         "exchanged every sub-round (SURVEY 8(e)'s partition, komb_set_shard_peel); slower than the replicated peel "
-                         "on one node (DESIGN.md section 6), so never what the plain command runs.  The k-core reported alongside "
-                         "then runs komb_core_run_sharded")
+                    help="(the default for N > 1 since round 5; accepted for older command lines) the support all-reduce AND the peel "
+                         "sharded by edge range, the ranks' parts of the frontier exchanged every sub-round")
+    ap.add_argument("--no-alternatives", action="store_true", help="N > 1: do not time the other flows after the region")
     ap.add_argument("--no-build", action="store_true",
                     help="load the prebuilt libkomb_accel.so, spawn no compiler (use under rocprofv3)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed workload (+ the k-core of the same graph): no runTruss-faithful variant, no first-call "
-                         "figures, no C2 block -- for rocprofv3 runs, whose per-kernel averages should see the timed launches only")
-    ap.add_argument("--faithful", action="store_true", help="(the default since round 4; accepted for older command lines)")
+                         "figures, no C2 block, no CoreA -- for rocprofv3 runs, whose per-kernel averages should see the timed launches only")
+    ap.add_argument("--faithful", action="store_true", help="(accepted for older command lines)")
     args = ap.parse_args()
-    if args.batch and (args.replicas or args.same_graph or args.shard):
-        raise SystemExit("--batch runs one graph per rank: it cannot be combined with --replicas / --same-graph / --shard")
-    if args.replicas and args.shard:
+    picked = [n for n in ("batch", "replicas", "replicas_sliced", "shard") if getattr(args, n)]
+    if args.batch and (args.replicas or args.same_graph or args.shard or args.replicas_sliced or args.shard_peel):
+        raise SystemExit("--batch runs one graph per rank: it cannot be combined with --replicas / --replicas-sliced / --same-graph / --shard")
+    if args.replicas and (args.shard or args.shard_peel):
         raise SystemExit("--replicas runs the unsharded path on every rank: it cannot be combined with --shard")
-    if args.shard_peel and (args.batch or args.replicas or args.gpus < 2):
-        raise SystemExit("--shard-peel shards one graph over N > 1 ranks: it cannot be combined with --batch / --replicas / --gpus 1")
-    args.batch = args.gpus > 1 and args.batch
-    # N > 1: --c4-allreduce = BASELINE configs[3] to the letter (support counting sharded + one all-reduce);
-    # default = every rank peels the whole graph and materialises its slice of the results, no exchange
-    args.shard = args.gpus > 1 and (args.shard or args.shard_peel) and not args.batch and not args.replicas
-    args.slice = args.gpus > 1 and not args.shard and not args.batch and not args.replicas
+    if len(picked) > 1:
+        raise SystemExit(f"pick one flow for N > 1, not {picked}")
+    if args.shard_peel and args.shard:
+        args.shard = False                                  # (--shard-peel implies the all-reduce; it is the default flow)
+    mode = "single"
+    if args.gpus > 1:
+        mode = "batch" if args.batch else "replicas" if args.replicas else "sliced" if args.replicas_sliced else "c4" if args.shard else "sharded"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start one rank per GPU ourselves -- as a CHILD process and
@@ -203,7 +213,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     exchange = "single GPU"
-    data_group = None                       # the group the support vectors are summed over
+    data_group = None                       # the group the support vectors / frontier parts are summed over
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (barriers, the max over the ranks' times) on gloo; the data exchange on RCCL when every
@@ -220,9 +230,9 @@ def main():
             os.close(saved_fd)
         ok = 0
         why = "one-device rehearsal"
-        if not args.shard:
+        if mode in ("batch", "replicas"):
             why = "no exchange on the data path"
-        elif not one_device:
+        elif not one_device:                                # (the sliced flow exchanges nothing either, but its alternatives do)
             try:
                 data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
                 probe = torch.ones(1, dtype=torch.int32, device="cuda")
@@ -236,22 +246,20 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            exchange = "RCCL all-reduce in place on the device buffer"
+            exchange = f"RCCL all-reduce over {world} ranks, in place on the device buffers"
         else:
             data_group = None
             exchange = f"gloo through host memory ({why or 'RCCL unavailable on another rank'})"
-    host_exchange = world > 1
-    if world > 1:
         dist.barrier()
     import komb_amd
 
     nv, ncl, alpha, seed, desc = CONFIGS[args.config]
     t0 = time.perf_counter()
-    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed + (rank if args.batch else 0))
+    uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed + (rank if mode == "batch" else 0))
     t_gen = time.perf_counter() - t0
     acc = komb_amd.KombAccel(device=local_rank)
     t0 = time.perf_counter()
-    acc.from_edges(nv, uv)                       # a1 on the device; the graph stays resident in HBM
+    acc.from_edges(nv, uv)                       # a1 on the device; the symmetric CSR stays resident in HBM (nothing else does)
     t_build = time.perf_counter() - t0
     build_stats = acc.stats()
     extras = rank == 0 and world == 1 and not args.no_extras
@@ -268,51 +276,62 @@ def main():
     if world > 1:
         from komb_amd import distributed as kd
 
-    # N > 1 by default: the same graph on every rank, the whole path on every rank, each rank's slice of the canonical
-    # results materialised (komb_truss_run_slice; no exchange).  --c4-allreduce: the support-counting enumeration split by
-    # source-vertex range + one all-reduce of the |E|+1 support words, then everything replicated (BASELINE configs[3] to
-    # the letter; DESIGN.md section 6 has the arithmetic).  --replicas / --batch are opt-in too.
-    shard = world > 1 and args.shard
-    sliced = world > 1 and args.slice
-
-    def step():
-        if shard:
-            # support phase sharded by vertex range + all-reduce; with --shard-peel the peel by edge range + one exchange per sub-round
-            kd.truss_run_sharded(acc, group=data_group, shard_peel=args.shard_peel)
-        elif sliced:
+    def run_flow(flow, cold):
+        if cold:
+            acc.truss_unprepare()                # nothing of the previous step survives: the preparation is part of the step
+        if flow == "sharded":                    # support all-reduce + the peel by edge range, one frontier exchange per sub-round
+            kd.truss_run_sharded(acc, group=data_group, shard_peel=True)
+        elif flow == "c4":                       # support all-reduce only
+            kd.truss_run_sharded(acc, group=data_group, shard_peel=False)
+        elif flow == "sliced":
             kd.truss_run_slice(acc)
         else:
             acc.truss_run()
 
+    def timed(flow, cold, steps, with_phases=False):
+        barrier_sync()
+        t0 = time.perf_counter()
+        ph = {k: 0.0 for k in PHASES}
+        for _ in range(steps):
+            run_flow(flow, cold)
+            if with_phases:
+                s = acc.stats()
+                for k in ph:
+                    ph[k] += s[k]
+        barrier_sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, {k: v / steps for k, v in ph.items()}
+
+    flow = mode if world > 1 and mode in ("sharded", "c4", "sliced") else "whole"
     for _ in range(args.warmup):
-        step()
-    barrier_sync()
-    t0 = time.perf_counter()
-    phase = {k: 0.0 for k in ("ms_orient", "ms_tri_count", "ms_allreduce", "ms_tri_fill", "ms_sort", "ms_compact", "ms_peel", "ms_tail",
-                              "ms_truss_local", "ms_gather", "ms_exchange")}
-    for _ in range(args.steps):
-        step()
-        s = acc.stats()
-        for k in phase:
-            phase[k] += s[k]
-    barrier_sync()
-    dt = time.perf_counter() - t0
-    ne_total = ne
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if args.batch:                                    # the job's units: the edges of all the ranks' graphs
-            t = torch.tensor([ne], dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            ne_total = int(t.item())
+        run_flow(flow, True)
+    dt, phase = timed(flow, True, args.steps, with_phases=True)
     st = acc.stats()
-    for k in phase:
-        phase[k] /= args.steps
+    ne_total = ne
+    if mode == "batch":                                   # the job's units: the edges of all the ranks' graphs
+        t = torch.tensor([ne], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ne_total = int(t.item())
+    # the same step on a graph whose preparation is resident (what rounds 1-4 reported as the headline)
+    dt_res, phase_res = timed(flow, False, args.steps, with_phases=True)
+    alternatives = None
+    if world > 1 and mode in ("sharded", "c4", "sliced") and not args.no_alternatives:
+        alternatives = {}
+        for name, f in (("shard_peel_and_support_allreduce", "sharded"), ("support_allreduce_only", "c4"), ("replicas_sliced", "sliced")):
+            if f == flow:
+                continue
+            run_flow(f, True)
+            d_alt, _ = timed(f, True, args.steps)
+            alternatives[name] = {"ms_per_step": d_alt / args.steps * 1e3, "value": ne * args.steps / d_alt}
+        acc.set_shard_peel(flow == "sharded")
     slices_ok = None
-    if sliced:
+    if flow == "sliced":
         # outside the timed region: this rank's slice against a whole run of its own (values in the slice, zeros elsewhere)
-        import numpy as np
+        kd.truss_run_slice(acc)
         _, _, tr_s, sup_s = acc.truss_fetch(with_support=True)
         _, _, tr_w, sup_w = acc.run_truss(with_support=True)
         lo, hi = ne * rank // world, ne * (rank + 1) // world
@@ -323,19 +342,37 @@ def main():
         slices_ok = bool(int(t.item()))
         del tr_s, sup_s, tr_w, sup_w
 
+    # the roofline model's graph statistics (sum d^2, oriented items, max degree): a measurement-only call
+    acc.graph_moments()
+    gm = acc.stats()
+    for k in ("sum_deg_sq", "wedge_items", "oriented_items", "max_degree"):
+        st[k] = gm[k]
+
     # k-core of the same graph, reported alongside (BASELINE config C2's op)
-    if shard and args.shard_peel:
+    if flow == "sharded":
         kd.core_run_sharded(acc, group=data_group)
     else:
         acc.core_run()
-    core_ms = acc.stats()["ms_core"]
     core_stats = acc.stats()
+    core_ms = core_stats["ms_core"]
 
-    # the runTruss-faithful variant (reference src/graph.cpp:470-473,502,508): trussness of the subgraph
-    # induced by the max-coreness vertices, reported alongside (after the timed region)
-    faithful = first_call = c2_block = None
+    faithful = first_call = c2_block = corea = None
+    workload_csr = None
     if extras:
         deg_h, core_h = acc.core_fetch()
+        # CoreA on the workload's own degrees / coreness (a9 + a10: komb_corea_scores): device time of the rank kernels, wall time of the call
+        acc.get_anomaly_score(deg_h, core_h)
+        t1 = time.perf_counter()
+        score = acc.get_anomaly_score(deg_h, core_h)
+        t_ca = time.perf_counter() - t1
+        key_bits = int(core_h.max()) * nv + int(deg_h.max())
+        corea = {"ms_device_rank_kernels": acc.stats()["ms_corea"], "ms_call_wall": t_ca * 1e3, "vertices": nv,
+                 "max_score": float(score.max()), "key_max": key_bits,
+                 "reference_int_key_overflows": key_bits >= 2**31,      # src/CoreA.h:122 computes the key in `int`
+                 "alg_bytes_sorts": 2 * (2 * 12 * nv) * 8}               # two sorts of (8-byte key, 4-byte index) pairs, <= 8 radix passes, read + write
+        del score
+        # the runTruss-faithful variant (reference src/graph.cpp:470-473,502,508): trussness of the subgraph
+        # induced by the max-coreness vertices, reported alongside (after the timed region)
         mask = (core_h == core_h.max()).astype(np.uint8)
         acc.truss_run(mask)                       # warm
         torch.cuda.synchronize()
@@ -343,12 +380,14 @@ def main():
         acc.truss_run(mask)
         torch.cuda.synchronize()
         t_f = time.perf_counter() - t1
+        fs = acc.stats()
         feu, fev, ftr = acc.truss_fetch()
         faithful = {"max_core_vertices": int(mask.sum()), "subgraph_edges": int(len(feu)),
-                    "max_trussness": int(ftr.max()) if len(ftr) else 0, "ms": t_f * 1e3}
+                    "max_trussness": int(ftr.max()) if len(ftr) else 0, "ms": t_f * 1e3,
+                    "ms_induce": fs["ms_orient"], "ms_prepare": fs["ms_prepare"]}
         del deg_h, core_h, mask, feu, fev, ftr
         # what KOMB would see: komb2 decomposes a graph ONCE -- a fresh context (every buffer still to be allocated),
-        # graph build, then the first k-core and the first k-truss call
+        # graph build, then the first k-core and the first k-truss call (which makes the preparation)
         # (the timed context stays alive meanwhile: a hipMalloc that follows the hipFree of tens of GB waits for the driver to
         # finish releasing them -- 1.7 s measured -- which a process that decomposes one graph never sees)
         fresh = komb_amd.KombAccel(device=local_rank)
@@ -358,6 +397,7 @@ def main():
         b2 = fresh.stats()
         t1 = time.perf_counter(); fresh.core_run(); torch.cuda.synchronize(); t_c1 = time.perf_counter() - t1
         t1 = time.perf_counter(); fresh.truss_run(); torch.cuda.synchronize(); t_t1 = time.perf_counter() - t1
+        p1 = fresh.stats()["ms_prepare"]
         t1 = time.perf_counter(); fresh.core_run(); torch.cuda.synchronize(); t_c2 = time.perf_counter() - t1
         t1 = time.perf_counter(); fresh.truss_run(); torch.cuda.synchronize(); t_t2 = time.perf_counter() - t1
         fresh.close()
@@ -365,9 +405,12 @@ def main():
                       "graph_build_ms": t_b2 * 1e3,
                       "graph_build_parts_ms": {"h2d": b2["ms_build_h2d"], "renumber_orient_lines": b2["ms_build_relabel"]},
                       "kcore_first_ms": t_c1 * 1e3, "kcore_second_ms": t_c2 * 1e3,
-                      "ktruss_first_ms": t_t1 * 1e3, "ktruss_second_ms": t_t2 * 1e3,
+                      "ktruss_first_ms": t_t1 * 1e3, "ktruss_first_prepare_ms": p1, "ktruss_second_ms_resident": t_t2 * 1e3,
                       "build_plus_first_ktruss_ms": (t_b2 + t_t1) * 1e3}
         del uv
+        if not args.no_cpu_baseline:
+            rp_w, col_w = acc.get_csr()                    # the CPU baseline's all-cores leg runs on this very graph
+            workload_csr = (rp_w, col_w)
         # BASELINE configs[1] (C2: |V|=1M, |E|~10M, k-core only) -- and the k-truss of the same graph
         if args.config != "c2":
             nv2, ncl2, alpha2, seed2, desc2 = CONFIGS["c2"]
@@ -387,47 +430,51 @@ def main():
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(reps):
+                    a2.truss_unprepare()
                     a2.truss_run()
                 torch.cuda.synchronize()
                 c2_truss = (time.perf_counter() - t1) / reps
                 s2 = a2.stats()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    a2.truss_run()
+                torch.cuda.synchronize()
+                c2_truss_res = (time.perf_counter() - t1) / reps
                 bc2 = 16 * nv2 + 24 * a2.ne
                 c2_block = {"workload": "C2: synthetic power-law unitig graph |V|=1M |E|~10M (BASELINE configs[1]: k-core only; k-truss alongside)",
                             "nv": nv2, "ne": a2.ne, "triangles": s2["triangles"],
                             "kcore": {"ms": c2_core * 1e3, "first_call_ms": c2_first * 1e3, "edges_per_s": a2.ne / c2_core,
                                       "levels": s2c["core_levels"], "launches": s2c["core_launches"], "max_coreness": s2c["max_coreness"],
                                       "alg_bytes": bc2, "GBps": bc2 / c2_core / 1e9, "frac_of_hbm_peak": bc2 / c2_core / 1e9 / HBM_PEAK_GBS},
-                            "ktruss": {"ms_per_step": c2_truss * 1e3, "edges_per_s": a2.ne / c2_truss, "max_trussness": s2["max_trussness"],
-                                       "phases_ms": {k: s2[k] for k in ("ms_tri_fill", "ms_sort", "ms_compact", "ms_peel", "ms_truss_local", "ms_gather")}}}
+                            "ktruss": {"ms_per_step": c2_truss * 1e3, "ms_per_step_resident": c2_truss_res * 1e3, "edges_per_s": a2.ne / c2_truss,
+                                       "max_trussness": s2["max_trussness"],
+                                       "phases_ms": {k: s2[k] for k in ("ms_prepare", "ms_tri_fill", "ms_sort", "ms_compact", "ms_peel", "ms_truss_local", "ms_gather")}}}
 
     if rank == 0:
         ab = algorithmic_bytes(st)
+        shard = mode in ("sharded", "c4")
+        sliced = mode == "sliced"
         # the peel = the launches of k_peel_step<Truss> (all of them, including the no-op launches of the last blind
         # batch, as rocprofv3 counts them) + the single-workgroup LDS tail (setup kernels + k_truss_tail)
-        kernels = {"k_peel_step<Truss>": (phase["ms_peel"] - phase["ms_tail"] - phase["ms_truss_local"], st["truss_launches"], ab["peel"])}
+        kernels = {"k_peel_step<Truss>": (phase["ms_peel"] - phase["ms_tail"] - phase["ms_truss_local"] - phase["ms_exchange"], st["truss_launches"], ab["peel"])}
+        kernels["truss preparation (k_prep_* + vertex sort + scans)"] = (phase["ms_prepare"], 16, ab["prepare"])
         if st["truss_tail_runs"]:
             kernels["k_truss_tail"] = (phase["ms_tail"], st["truss_tail_runs"], 0)
         if st["truss_local_units"]:
             kernels["local finish (number + collect + k_local_step sweeps)"] = (phase["ms_truss_local"], st["truss_local_sweeps"], 0)
         if phase["ms_tri_count"] > 0:            # the counting enumeration (sharded runs: this rank's share; two-pass: all of it)
-            kernels["k_triangles<count>"] = (phase["ms_tri_count"], 1, ab["tri_count"] // (world if shard else 1))
+            kernels["k_wedges<count>" if shard else "k_triangles<count>"] = (phase["ms_tri_count"], 1, ab["tri_count"] // (world if shard else 1))
         layout = st["index_layout"]
         if layout == 0:                          # ONE enumeration: dense own-role blocks + record stream, sort, merge
             # the enumeration is priced at SURVEY 8(d)'s B_sup verbatim (its stores -- 8 bytes per own-role entry, 12 per
             # record -- are not counted); the sort at the 2 radix passes it runs over 12-byte records, read + write
-            enum_name = "k_triangles<stream>" if os.environ.get("KOMB_ENUM") == "probe" else "k_wedges<stream>"
-            kernels[enum_name] = (phase["ms_tri_fill"], 1, ab["tri_count"])
+            kernels["k_wedges<stream>"] = (phase["ms_tri_fill"], 1, ab["tri_count"])
             kernels["record sort (rocPRIM radix, by bin: 2 passes)"] = (phase["ms_sort"], 1, ab["sort"])
             kernels["k_bin_offsets + k_bin_count + k_bin_finish"] = (phase["ms_compact"], 3, ab["finish"])
-        elif layout == 1:                        # ONE enumeration into bounded slices + dense compaction
-            kernels["k_triangles<single>"] = (phase["ms_tri_fill"], 1, ab["tri_count"])
-            kernels["k_compact_inc"] = (phase["ms_compact"], 1, 16 * st["ne"] + 48 * st["triangles"])
         else:
             kernels["k_triangles<single> (exact slices)"] = (phase["ms_tri_fill"], 1, ab["tri_count"])
         # (sliced runs: the resolve pass covers every edge, the gather this rank's slice)
         kernels["k_truss_resolve + k_gather_canonical"] = (phase["ms_gather"], 2, ab["gather"] // 2 + ab["gather"] // 2 // (world if sliced else 1))
-        if phase["ms_orient"] > 0.01:               # induced-subgraph runs only: the slot filter + the subgraph's vertex lines
-            kernels["k_slot_filter<PredMask> + k_vertex_lines"] = (phase["ms_orient"], 3, 0)
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, nbytes = kernels[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -437,7 +484,7 @@ def main():
         bl_ms, bl_n, bl_bytes = kernels[by_launch]
         roofline = {
             "bound": "hbm", "kernel": dom,
-            "dominant_rule": "the kernel symbol with the largest time per step (all its launches together), as in rounds 1-3; "
+            "dominant_rule": "the kernel symbol with the largest time per step (all its launches together), as in rounds 1-4; "
                              "by_launch names the kernel with the longest single launch",
             "by_launch": {"kernel": by_launch, "avg_launch_us": bl_ms * 1e3 / max(bl_n, 1), "launches_per_step": bl_n,
                           "achieved": (bl_bytes / (bl_ms * 1e-3) / 1e9 if bl_ms > 0 else 0.0),
@@ -451,86 +498,103 @@ def main():
             "per_kernel": {k: {"ms_per_step": v[0], "launches": v[1], "alg_bytes": v[2],
                                "GBps": (v[2] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in kernels.items()},
             "survey_formula_peel_bytes": ab["survey_peel"],
-            # SURVEY 8(d) verbatim: B_sup over the enumeration kernel's own event time (since round 3 the headline figure is
-            # priced the same way), and the whole step's algorithmic bytes over the whole step
+            # SURVEY 8(d) verbatim: B_sup over the enumeration kernel's own event time, and the whole step's algorithmic bytes
+            # (the preparation's included) over the whole step
             "survey_B_sup_bytes": ab["tri_count"],
             "survey_B_sup_frac": (ab["tri_count"] / ((phase["ms_tri_fill"] + phase["ms_tri_count"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
                                   if phase["ms_tri_fill"] + phase["ms_tri_count"] > 0 else None),
             "whole_step_bytes": sum(v[2] for v in kernels.values()),
             "whole_step_frac": sum(v[2] for v in kernels.values()) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-            # SURVEY 8(d)'s secondary ceilings.  The peel engine is bounded by its decrements, not by bytes: a returning atomic on a
-            # per-edge counter costs ~20 ps (50 G/s over the chip, measured by switching them off / adding them in a debug build:
-            # profiles/r04_peel_first_step_ablation.txt; the same with the counters packed into a cache-resident array), and a
-            # triangle owes at most two; k-core: one per (peeled vertex, live neighbour) slot, launches x the ~15 us step floor
+            # SURVEY 8(d)'s secondary ceilings.  The peel engines are bounded by their decrements, not by bytes: the chip performs
+            # ~27 G scattered 32-bit atomics per second -- one memory-side request per 64-byte line a wave instruction touches,
+            # returning or not, whatever the table's size (4 MB .. 400 MB): scripts/calib/atomic_rate.hip,
+            # profiles/r05_atomic_rate.txt; lanes that share a line share the request, which is how the truss engine reaches
+            # ~50 G decrements/s on slices whose edges are neighbours (profiles/r04_peel_first_step_ablation.txt).  A triangle
+            # owes at most two decrements; k-core one per (peeled vertex, live neighbour) slot.
             "secondary_ceilings": {
-                "decrement_rate_G_per_s_measured": 50.0,
+                "atomic_line_requests_G_per_s_calibrated": 27.0,
+                "truss_decrement_rate_G_per_s_calibrated": 50.0,
+                "calibration": "profiles/r05_atomic_rate.txt (this round), profiles/r04_peel_first_step_ablation.txt",
                 "truss_decrements_upper_bound": 2 * st["triangles"],
                 "truss_decrement_floor_ms": 2 * st["triangles"] / 50e9 * 1e3,
-                "truss_engine_ms": kernels["k_peel_step<Truss>"][0] if "k_peel_step<Truss>" in kernels else None,
-                "kcore_slot_visits_upper_bound": 2 * ne, "kcore_decrement_floor_ms": 2 * ne / 50e9 * 1e3,
+                "truss_engine_ms": kernels["k_peel_step<Truss>"][0],
+                "kcore_slot_visits_upper_bound": 2 * ne, "kcore_decrement_floor_ms": 2 * ne / 27e9 * 1e3,
                 "kcore_launches": core_stats["core_launches"], "kcore_ms": core_ms,
             },
         }
+        par = {
+            "single": "single",
+            "batch": f"batch: {world} independent graphs (seed + rank), one per GPU, no exchange on the data path",
+            "replicas": f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange",
+            "sliced": (f"same graph on {world} ranks: preparation, support, index and peel on every rank, the canonical results gathered in "
+                       f"{world} slices, one per rank; no exchange on the data path (slices verified after the timed region: {slices_ok})"),
+            "c4": (f"same graph on {world} ranks: triangle-support counting sharded by task range + one all-reduce of the per-edge support "
+                   f"vector ({exchange}); preparation, incidence fill, peel and gather replicated on every rank"),
+            "sharded": (f"same graph on {world} ranks, edge-range partition: triangle-support counting sharded by task range + one all-reduce of "
+                        f"the per-edge support vector; peel: live supports owned by internal-edge-id range, every rank walks the whole exchanged "
+                        f"frontier and applies the decrements it owns, {st['shard_exchanges']} exchanges per step ({exchange}); preparation, "
+                        f"incidence fill and gather replicated"),
+        }[mode]
+        workload = desc if world == 1 else {
+            "batch": f"{world} x [{desc}] (one graph per rank)",
+            "replicas": f"{world} x [{desc}] (replicas of one graph)",
+            "sliced": f"the same graph as [{desc}] on {world} GPUs: every rank runs the whole k-truss path and materialises its slice of the canonical results",
+            "c4": f"C4: the same graph as [{desc}] on {world} GPUs, k-truss with the triangle support sharded + all-reduce",
+            "sharded": f"C4: the same graph as [{desc}] on {world} GPUs, k-truss with the triangle support sharded + all-reduce, the peel sharded by edge range + one frontier exchange per sub-round",
+        }[mode]
         out = {
-            "metric": ("peeled edges/sec (k-truss)" if not args.batch else
+            "metric": ("peeled edges/sec (k-truss)" if mode != "batch" else
                        f"aggregate peeled edges/sec (k-truss) over {world} independent graphs"),
             "value": ne_total * args.steps / dt,
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if args.batch else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": desc if world == 1 else
-                       (f"C4: the same graph as [{desc}] on {world} GPUs, k-truss with the triangle support sharded + all-reduce"
-                        + (", the peel sharded by edge range + one frontier exchange per sub-round" if args.shard_peel else "") if shard else
-                        (f"the same graph as [{desc}] on {world} GPUs: every rank runs the whole k-truss path and materialises its slice of the canonical results"
-                         if sliced else f"{world} x [{desc}] ({'one graph per rank' if args.batch else 'replicas of one graph'})")),
+            "scaling": "weak" if mode == "batch" else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            # the same step with the graph's preparation resident (rounds 1-4's headline definition)
+            "value_resident": ne_total * args.steps / dt_res, "ms_per_step_resident": dt_res / args.steps * 1e3,
+            "step_definition": "komb_truss_unprepare + komb_truss_run per step: preparation ((degree,id) renumbering, orientation, canonical "
+                               "map, lines, tasks) + support + index + peel + gather, from the resident symmetric CSR; *_resident: "
+                               "komb_truss_run on a graph that kept its preparation",
+            "config": {"workload": workload,
                        "nv": nv, "ne": ne, "triangles": st["triangles"], "alpha": alpha, "seed": seed,
                        "max_degree": st["max_degree"], "max_trussness": st["max_trussness"],
                        "max_coreness": core_stats["max_coreness"],
                        "truss_levels": st["truss_levels"], "truss_subrounds": st["truss_subrounds"],
                        "truss_scans": st["truss_scans"], "truss_launches": st["truss_launches"],
-                       "index_layout": ["record stream", "bounded slices", "exact two-pass"][st["index_layout"]],
-                       "tri_records": st["tri_records"],
-                       **({"shard_peel": {"exchanges": st["shard_exchanges"], "exchange_words": st["exchange_words"]}} if args.shard_peel else {}),
+                       "index_layout": {0: "record stream", 2: "exact two-pass"}[st["index_layout"]],
+                       "tri_records": st["tri_records"], "engine_flags": st["engine_flags"],
+                       **({"shard_peel": {"exchanges": st["shard_exchanges"], "exchange_words": st["exchange_words"]}} if mode == "sharded" else {}),
                        "truss_local": {"edges": st["truss_local_units"], "index_entries": st["truss_local_items"],
                                        "sweeps": st["truss_local_sweeps"]},
-                       "parallelism": "single" if world == 1 else
-                       (f"batch: {world} independent graphs (seed + rank), one per GPU, no exchange on the data path" if args.batch else
-                        (f"same graph on {world} ranks: triangle-support counting sharded by source-vertex range + one all-reduce of the "
-                         f"per-edge support vector ({exchange}); incidence fill"
-                         + (", gather replicated; peel: supports owned by edge range, every rank walks the whole exchanged frontier and applies "
-                            f"its own decrements, {st['shard_exchanges']} exchanges per step" if args.shard_peel else ", peel and gather replicated on every rank")) if shard else
-                        (f"same graph on {world} ranks: support, index and peel on every rank (they do not shard at a profit: DESIGN.md section 6), "
-                         f"the canonical results gathered in {world} slices, one per rank; no exchange on the data path (slices verified after the timed region: {slices_ok})"
-                         if sliced else f"same graph on {world} ranks, replicas: every rank runs the whole single-GPU path, no exchange"))},
-            "phases_ms": phase,
+                       "parallelism": par},
+            "phases_ms": phase, "phases_ms_resident": phase_res,
+            **({"alternatives": alternatives,
+                "multi_gpu_note": "never measured on more than one GPU by the builder (the pool grants one); DESIGN.md section 6 has the predicted N = 2/4/8 times"}
+               if world > 1 else {}),
             "kcore": {"ms": core_ms, "edges_per_s": ne / (core_ms * 1e-3) if core_ms > 0 else None,
                       "levels": core_stats["core_levels"], "launches": core_stats["core_launches"],
                       **({"sharded": {"exchanges": core_stats["shard_exchanges"], "ms_exchange": core_stats["ms_exchange"],
-                                      "exchange_words": core_stats["exchange_words"]}} if shard and args.shard_peel else {}),
+                                      "exchange_words": core_stats["exchange_words"]}} if mode == "sharded" else {}),
                       "local": {"vertices": core_stats["core_local_units"], "index_entries": core_stats["core_local_items"],
                                 "sweeps": core_stats["core_local_sweeps"], "ms": core_stats["ms_core_local"]},
                       "alg_bytes": 16 * nv + 24 * ne,
-                      "GBps": (16 * nv + 24 * ne) / (core_ms * 1e-3) / 1e9 if core_ms > 0 else None},
-            # every KOMB_* switch the run saw (none changes a result; some change which engine runs, e.g. KOMB_SHARD_PEEL, KOMB_ENUM)
-            "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("KOMB_")},
+                      "GBps": (16 * nv + 24 * ne) / (core_ms * 1e-3) / 1e9 if core_ms > 0 else None,
+                      "frac_of_hbm_peak": (16 * nv + 24 * ne) / (core_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if core_ms > 0 else None},
+            "corea": corea,
+            # the library reads no environment variable (ABI 7): its switches are per-context options nobody sets here
+            "library_options_set": [],
             "runtruss_faithful": faithful,
             "first_call": first_call,
-            # nothing a k-truss / k-core call computes is skipped after the first call: the graph moments (sum d^2, max degree, ...)
-            # that rounds 1-3 computed on the first call only are made with the graph since round 4
-            "statistics_skipped_after_first_call": [],
             "c2": c2_block,
             "setup_s": {"generate": t_gen, "graph_build_incl_h2d": t_build, "device_build_ms": build_stats["ms_build"],
-                        "h2d_ms": build_stats["ms_build_h2d"], "renumber_orient_lines_ms": build_stats["ms_build_relabel"],
+                        "h2d_ms": build_stats["ms_build_h2d"],
                         "note": "first graph build of the process: includes the HIP runtime's first large allocations and first launches of "
-                                "every build kernel (komb_create has loaded the code object and made the pinned staging buffers); "
-                                "first_call.graph_build_ms is a second build in the same process.  The graph object holds the "
-                                "(degree,id)-renumbered oriented CSR, the canonical edge map, the per-vertex lines of the enumeration and the "
-                                "graph moments (all functions of the graph alone, built once with it); no k-truss / k-core call reuses "
-                                "anything a previous call computed"},
+                                "every build kernel (komb_create has loaded the code object); first_call.graph_build_ms is a second build in the "
+                                "same process.  The graph object holds the symmetric CSR only; the k-truss preparation is made inside the first "
+                                "k-truss call (and inside every timed step here)"},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed at N=1 only
-            out["cpu_baseline"] = cb = cpu_baseline()
+            out["cpu_baseline"] = cb = cpu_baseline(workload_csr, ne)
             # context, not credit: the GPU figure over the CPU port's, edges/s against edges/s (north_star asks for >= 10x)
             cb["gpu_over_cpu"] = {"1_thread": out["value"] / cb["value"],
                                   **({"all_cores": out["value"] / cb["all_cores"]["value"]} if "all_cores" in cb else {})}

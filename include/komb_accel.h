@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KOMB_ACCEL_ABI_VERSION 6
+#define KOMB_ACCEL_ABI_VERSION 7
 
 typedef enum komb_status {
     KOMB_OK          =  0,
@@ -41,9 +41,13 @@ typedef struct komb_ctx komb_ctx;
 
 typedef struct komb_opts {
     int32_t device;        /* HIP device ordinal (LOCAL_RANK for one process per GPU) */
-    int32_t verbosity;     /* 0 silent, 1 progress on stderr                          */
-    int32_t reserved[2];
+    int32_t verbosity;     /* 0 silent, 1 progress on stderr, 2 + phase times of create / graph build */
+    int32_t reserved[2];   /* [0]: KOMB_CREATE_* flags below; [1]: 0                  */
 } komb_opts;
+/* komb_opts.reserved[0] (ABI version 7; until then the library read KOMB_NULL_STREAM / KOMB_NO_WARMUP from the environment) */
+#define KOMB_CREATE_NULL_STREAM 1   /* work on the legacy default stream instead of a stream of the context's own      */
+#define KOMB_CREATE_NO_WARMUP   2   /* do not load the code object (a first kernel launch) inside komb_create           */
+#define KOMB_CREATE_WARM_UPLOAD 4   /* make the pinned staging buffers of a >= 64 MB graph upload inside komb_create   */
 
 typedef struct komb_stats {
     int64_t nv, ne;                 /* simple graph: vertices, undirected edges      */
@@ -85,24 +89,38 @@ typedef struct komb_stats {
     int64_t exchange_words;         /* 32-bit words they carried                                                 */
     /* graph build (ABI version 5): host wall-clock parts of ms_build (which is now wall-clock too: upload + device work) */
     double  ms_build_h2d;           /* staged host -> device copy of the raw pairs / the CSR                      */
-    double  ms_build_relabel;       /* (degree,id) renumbering, internal CSR, oriented half, canonical edge map   */
+    double  ms_build_relabel;       /* 0 since ABI version 7: the k-truss side is no longer made with the graph (ms_prepare) */
+    /* k-truss preparation (ABI version 7): (degree,id) renumbering, oriented CSR, canonical edge map, the enumeration's lines
+     * and tasks -- made by the first komb_truss_* call of a graph (or komb_truss_prepare), inside that call */
+    double  ms_prepare;             /* device time of the preparation the last k-truss call (or komb_truss_prepare) made; 0 when it found one */
+    int32_t truss_prepared;         /* 1 when the last k-truss call made a preparation (whole graph or induced subgraph)      */
+    int32_t engine_flags;           /* which engines the last k-core / k-truss call ran: KOMB_ENGINE_* below                  */
 } komb_stats;
+#define KOMB_ENGINE_LOCAL_FINISH 1   /* a remainder went to the local fixed point (local_dev.h)            */
+#define KOMB_ENGINE_LDS_TAIL     2   /* ... to the single-workgroup LDS tail                                */
+#define KOMB_ENGINE_SHARD_PEEL   4   /* the peel ran sharded by unit range (shard_dev.h)                    */
+#define KOMB_ENGINE_TWO_PASS     8   /* the incidence index was built by the exact two-pass fallback        */
 
 /* ---- lifetime ---------------------------------------------------------- */
 komb_ctx   *komb_create(const komb_opts *opts);      /* NULL only on host OOM      */
 void        komb_destroy(komb_ctx *ctx);
 const char *komb_last_error(const komb_ctx *ctx);    /* "" when no error           */
 int         komb_abi_version(void);
+/* Tuning / test switches of one context (ABI version 7; until then KOMB_* environment variables, which the library no
+ * longer reads: ambient environment cannot change which engine a drop-in runs).  None changes a result.  name: FINISH
+ * (local | lds | none), LOCAL_LIMIT, LOCAL_ITEMS, LOCAL_DENSITY, LOCAL_DEFER_CHUNKS, TAIL, CORE_TAIL, INDEX (stream |
+ * two_pass), REC_CAP, OWN_DENSE_CAP, NO_OWN_DENSE, NO_REC_SCRATCH, NO_FIRST_QUEUE, RETIRE_EVERY, SHARD_ENGINE, and the
+ * stderr traces TRI_DEBUG, POOL_DEBUG, BUILD_DEBUG, LOCAL_DEBUG, TAIL_DEBUG.  value NULL unsets. */
+int         komb_set_option(komb_ctx *ctx, const char *name, const char *value);
 
 /* ---- graph construction ------------------------------------------------ */
 /* Replaces igraph_create + igraph_simplify(multiple=true, loops=true)
  * (src/graph.cpp:418, src/graph.cpp:438): n_raw (u,v) pairs exactly as
  * generateGraph leaves them in `edges` (src/graph.cpp:379-389), vertex ids in
  * [0,nv).  Removes loops and parallel edges on the device and keeps the graph
- * resident in HBM: the symmetric CSR (rows ascending, the caller's ids) and, for
- * the k-truss path, the oriented CSR in (degree,id)-ranked internal ids with the
- * map back to the canonical edge order.  Every result is
- * reported in the caller's vertex ids. */
+ * resident in HBM as a symmetric CSR (rows ascending, the caller's ids).  What
+ * only the k-truss path needs is made by the first k-truss call (below).
+ * Every result is reported in the caller's vertex ids. */
 int komb_graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw,
                           const int64_t *uv_pairs);
 
@@ -142,6 +160,15 @@ int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness);
  * komb_truss_run computes on the device (timed region); komb_truss_fetch
  * copies (eu,ev,truss)[ne_sub] out.  Trussness of a triangle-free edge is 2. */
 int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
+/* What igraph_trussness does to its argument before it lists a triangle (src/graph.cpp:508: vertices ordered by degree,
+ * every edge oriented from its lower to its higher endpoint) is the k-truss PREPARATION here: (degree,id)-ranked internal
+ * ids, the oriented CSR in them, the map back to the canonical edge order, the enumeration's per-vertex lines and task
+ * table.  The first k-truss call of a graph makes it, inside the call and its time
+ * (komb_stats.ms_prepare), and it stays with the graph: later calls find it.  komb_truss_prepare makes it ahead of time
+ * (a no-op when it exists); komb_truss_unprepare drops it together with the last k-truss result (bench.py times
+ * unprepare + komb_truss_run: nothing of a previous call is reused).  A vmask run prepares its induced subgraph every time. */
+int komb_truss_prepare(komb_ctx *ctx);
+int komb_truss_unprepare(komb_ctx *ctx);
 /* One process per GPU, every rank holding the same graph: the triangle-support
  * phase is sharded by source-vertex range [rank/world) and the partial support
  * vectors (|E|+1 words) are summed across ranks by `allreduce` -- an in-place SUM
@@ -198,6 +225,10 @@ int komb_densest_block(komb_ctx *ctx, const double *suspiciousness, int32_t *ord
 
 /* ---- instrumentation --------------------------------------------------- */
 int komb_get_stats(komb_ctx *ctx, komb_stats *out);
+/* Measurement only: fills komb_stats.sum_deg_sq / wedge_items / max_degree / oriented_items of the resident graph (the
+ * inputs of the roofline model's algorithmic bytes; makes the k-truss preparation if absent).  No product path calls it
+ * (until ABI version 7 every graph build ran this 2.2 ms kernel). */
+int komb_graph_moments(komb_ctx *ctx);
 
 /* ---- synthetic workload (host code, no device) ------------------------- */
 /* Power-law "hybrid unitig graph" generator of SURVEY.md section 8(d): a union

@@ -44,13 +44,20 @@ class KombStats(ctypes.Structure):
         ("index_layout", ctypes.c_int32), ("shard_exchanges", ctypes.c_int32),
         ("ms_exchange", ctypes.c_double), ("exchange_words", ctypes.c_int64),
         ("ms_build_h2d", ctypes.c_double), ("ms_build_relabel", ctypes.c_double),
+        ("ms_prepare", ctypes.c_double), ("truss_prepared", ctypes.c_int32), ("engine_flags", ctypes.c_int32),
     ]
+
+KOMB_CREATE_NULL_STREAM, KOMB_CREATE_NO_WARMUP, KOMB_CREATE_WARM_UPLOAD = 1, 2, 4
 
 
 # every symbol include/komb_accel.h declares: name -> (restype, argtypes)
 _vp, _i64, _i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 SIGNATURES = {
     "komb_abi_version": (_i32, []),
+    "komb_set_option": (_i32, [_vp, ctypes.c_char_p, ctypes.c_char_p]),
+    "komb_truss_prepare": (_i32, [_vp]),
+    "komb_truss_unprepare": (_i32, [_vp]),
+    "komb_graph_moments": (_i32, [_vp]),
     "komb_create": (_vp, [ctypes.POINTER(KombOpts)]),
     "komb_destroy": (None, [_vp]),
     "komb_last_error": (ctypes.c_char_p, [_vp]),

@@ -8,6 +8,7 @@ igraph_trussness (src/graph.cpp:502,508), `get_anomaly_score` where
 CombineCoreA::run calls CoreA::getAnomalyScore (src/CombineCoreA.h:30).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -33,16 +34,46 @@ def gen_hug_edges(nv, n_cliques, alpha=2.6, seed=42):
     return uv
 
 
+# The library reads no KOMB_* environment variable (ABI 7): its tuning / test switches are per-context options
+# (komb_set_option).  The TESTS still say what they want through the environment (monkeypatch.setenv("KOMB_FINISH", "lds")):
+# with FORWARD_ENV_OPTIONS on (tests/conftest.py turns it on; bench.py never does) this plumbing hands those variables to
+# komb_set_option before every compute call -- the forwarding is test infrastructure, the option mechanism is the ABI's.
+FORWARD_ENV_OPTIONS = False
+OPTION_NAMES = ("FINISH", "LOCAL_LIMIT", "LOCAL_ITEMS", "LOCAL_DENSITY", "LOCAL_DEFER_CHUNKS", "TAIL", "CORE_TAIL", "INDEX",
+                "REC_CAP", "OWN_DENSE_CAP", "NO_OWN_DENSE", "NO_REC_SCRATCH", "NO_FIRST_QUEUE", "RETIRE_EVERY", "SHARD_ENGINE",
+                "TRI_DEBUG", "POOL_DEBUG", "BUILD_DEBUG", "LOCAL_DEBUG", "TAIL_DEBUG")
+
+
 class KombAccel:
-    def __init__(self, device=0, verbosity=0):
+    def __init__(self, device=0, verbosity=0, flags=0):
         self._lib = _lib.load()
         opts = KombOpts(device=device, verbosity=verbosity)
+        opts.reserved[0] = flags
         self._ctx = self._lib.komb_create(ctypes.byref(opts))
         if not self._ctx:
             raise MemoryError("komb_create failed")
         self.device = device
         self.nv = -1
         self.ne = 0
+        self._forwarded = {}
+
+    def set_option(self, name, value):
+        """komb_set_option: a tuning / test switch of this context (None unsets).  No option changes a result."""
+        v = None if value is None else str(value).encode()
+        self._check(self._lib.komb_set_option(self._ctx, name.encode(), v))
+
+    def _sync_env_options(self):
+        if not FORWARD_ENV_OPTIONS:
+            return
+        for name in OPTION_NAMES:
+            v = os.environ.get("KOMB_" + name)
+            if name == "INDEX" and os.environ.get("KOMB_TWO_PASS"):
+                v = "two_pass"
+            if name == "SHARD_ENGINE" and v is None:
+                v = os.environ.get("KOMB_SHARD_PEEL")
+            if self._forwarded.get(name) != v:
+                self.set_option(name, v)
+                self._forwarded[name] = v
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -89,6 +120,7 @@ class KombAccel:
 
     # ---- k-core (a2 + a3)
     def core_run(self):
+        self._sync_env_options()
         self._check(self._lib.komb_core_run(self._ctx))
 
     def set_shard_peel(self, on=True):
@@ -112,6 +144,7 @@ class KombAccel:
             vmask = as_c(vmask, np.uint8)
             if len(vmask) != self.nv:
                 raise ValueError("vmask must have nv entries")
+        self._sync_env_options()
         self._check(self._lib.komb_truss_run(self._ctx, ptr(vmask)))
 
     def truss_run_slice(self, rank, world, vmask=None):
@@ -121,7 +154,20 @@ class KombAccel:
             vmask = as_c(vmask, np.uint8)
             if len(vmask) != self.nv:
                 raise ValueError("vmask must have nv entries")
+        self._sync_env_options()
         self._check(self._lib.komb_truss_run_slice(self._ctx, ptr(vmask), int(rank), int(world)))
+
+    def truss_prepare(self):
+        """komb_truss_prepare: the k-truss side of the resident graph, made now (a no-op when it exists)."""
+        self._check(self._lib.komb_truss_prepare(self._ctx))
+
+    def truss_unprepare(self):
+        """komb_truss_unprepare: drop the preparation and the last k-truss result (the next k-truss call rebuilds it)."""
+        self._check(self._lib.komb_truss_unprepare(self._ctx))
+
+    def graph_moments(self):
+        """komb_graph_moments (measurement only): fills stats sum_deg_sq / wedge_items / max_degree / oriented_items."""
+        self._check(self._lib.komb_graph_moments(self._ctx))
 
     def truss_fetch(self, with_support=False):
         n = ctypes.c_int64()

@@ -58,9 +58,10 @@ komb_ctx *komb_create(const komb_opts *opts)
     // there -- still orders with it, while two contexts (two host threads, or a host's RCCL stream beside the library) no
     // longer serialise on one queue.  (Round 2 tried a non-blocking stream before the peel's launches carried their sequence
     // word and saw stale control blocks with two processes on one GPU; with the sequence word the engine no longer depends
-    // on launch-order visibility)  KOMB_NULL_STREAM=1 puts the context back on the default stream.
+    // on launch-order visibility)  KOMB_CREATE_NULL_STREAM in komb_opts.reserved[0] puts the context
+    // back on the default stream.
     ctx->stream = nullptr;
-    if (e == hipSuccess && !getenv("KOMB_NULL_STREAM")) { e = hipStreamCreate(&ctx->stream); ctx->own_stream = e == hipSuccess; }
+    if (e == hipSuccess && !(ctx->opts.reserved[0] & KOMB_CREATE_NULL_STREAM)) { e = hipStreamCreate(&ctx->stream); ctx->own_stream = e == hipSuccess; }
     if (e == hipSuccess && !ctx->timer.init()) e = hipErrorUnknown;
     if (e != hipSuccess) {
         ctx->err = std::string("device initialisation failed: ") + hipGetErrorString(e);
@@ -68,10 +69,10 @@ komb_ctx *komb_create(const komb_opts *opts)
     }
     ctx->device_ok = true;
     // One-time costs of a process' first use of the library -- loading its code object onto the device (the first kernel
-    // launch), the pinned staging buffers of the graph upload -- are paid here, not by the first graph build: komb2 creates
-    // its context on a second thread beside the SAM parse, so they leave its critical path (komb_amd/host/komb2.cpp).
-    // KOMB_NO_WARMUP=1 skips it.
-    if (!getenv("KOMB_NO_WARMUP")) warm_up(ctx);
+    // launch) and, for a caller that asks (KOMB_CREATE_WARM_UPLOAD), the pinned staging buffers of the graph upload -- are
+    // paid here, not by the first graph build: komb2 creates its context on a second thread beside the SAM parse, so they
+    // leave its critical path (komb_amd/host/komb2.cpp).  KOMB_CREATE_NO_WARMUP skips it.
+    if (!(ctx->opts.reserved[0] & KOMB_CREATE_NO_WARMUP)) warm_up(ctx);
     return ctx;
 }
 
@@ -163,6 +164,42 @@ int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness)
 {
     KOMB_TRY(komb_core_run(ctx));
     return komb_core_fetch(ctx, degree, coreness);
+}
+
+int komb_set_option(komb_ctx *ctx, const char *name, const char *value)
+{
+    if (!ctx || !name || !*name) return KOMB_ERR_ARG;
+    if (value) ctx->options[name] = value; else ctx->options.erase(name);
+    return KOMB_OK;
+}
+
+int komb_truss_prepare(komb_ctx *ctx)
+{
+    KOMB_TRY(require_device(ctx));
+    if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_prepare: no graph loaded");
+    if (ctx->prep.valid || ctx->nv == 0 || ctx->ne == 0) return KOMB_OK;
+    KOMB_TRY(prep_ensure(ctx));
+    ctx->stats.ms_prepare = ctx->prep.ms;
+    return KOMB_OK;
+}
+
+int komb_truss_unprepare(komb_ctx *ctx)
+{
+    KOMB_TRY(require_device(ctx));
+    truss_free(ctx);                                     // (a result's endpoint arrays are the preparation's)
+    prep_free(ctx, &ctx->prep);
+    return KOMB_OK;
+}
+
+int komb_graph_moments(komb_ctx *ctx)
+{
+    KOMB_TRY(require_device(ctx));
+    if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_graph_moments: no graph loaded");
+    int64_t mom[5] = {0, 0, 0, 0, 0};
+    if (ctx->nv > 0 && ctx->ne > 0) KOMB_TRY(graph_moments(ctx, mom));
+    ctx->stats.sum_deg_sq = mom[0]; ctx->stats.wedge_items = mom[1];
+    ctx->stats.max_degree = (int32_t)mom[2]; ctx->stats.oriented_items = mom[4];
+    return KOMB_OK;
 }
 
 int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask)

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -94,51 +95,13 @@ struct LocalCtrl {
 };
 static_assert(sizeof(LocalCtrl) == 64, "LocalCtrl layout");
 
-// debug builds only: the dense SCAN without its vector loads (KOMB_SCAN_SCALAR)
-inline int scan_scalar_switch()
-{
-#ifdef KOMB_DEBUG_SWITCHES
-    return getenv("KOMB_SCAN_SCALAR") ? 1 : 0;
-#else
-    return 0;
-#endif
-}
-
-// How a peel ends (KOMB_FINISH): "local" hands the remainder to the h-index fixed point of local_dev.h once at
-// most KOMB_LOCAL_LIMIT units (default: a fraction of all units) are left at a level boundary and it has at most
-// KOMB_LOCAL_ITEMS items (else it is refused and offered again later); "lds" uses the single-workgroup LDS tails
-// (truss_tail.h, core_tail.h; thresholds KOMB_TAIL / KOMB_CORE_TAIL); "none" keeps the whole peel in the general
+// How a peel ends (option FINISH, komb_set_option): "local" hands the remainder to the h-index fixed point of local_dev.h
+// once at most LOCAL_LIMIT units (default: a fraction of all units) are left at a level boundary and it has at most
+// LOCAL_ITEMS items (else it is refused and offered again later); "lds" uses the single-workgroup LDS tails
+// (truss_tail.h, core_tail.h; thresholds TAIL / CORE_TAIL); "none" keeps the whole peel in the general
 // engine.  None of them changes a result.  Default for both peels: "local" (MI355X: k-core |V| = 1M 5.3 -> 3.0 ms,
 // |V| = 10M 16.8 -> 10.7 ms; k-truss peel |E| = 10M 3.7 -> 2.9 ms, |E| = 100M 13.0 -> 11.1 ms against "lds").
 enum FinishMode : int { FIN_LOCAL = 0, FIN_LDS = 1, FIN_NONE = 2 };
-inline FinishMode finish_mode(FinishMode dflt)
-{
-    const char *e = getenv("KOMB_FINISH");
-    if (e && !strcmp(e, "local")) return FIN_LOCAL;
-    if (e && !strcmp(e, "lds")) return FIN_LDS;
-    if (e && !strcmp(e, "none")) return FIN_NONE;
-    return dflt;
-}
-// The fixed point costs ~ sweeps x items, the peel ~ its items once + a latency per sub-round: a remainder with more items
-// than this is not handed over (the peel goes on and offers a smaller one).  KOMB_LOCAL_ITEMS overrides.
-inline uint64_t local_item_limit(uint64_t dflt)
-{
-    if (const char *e = getenv("KOMB_LOCAL_ITEMS")) return strtoull(e, nullptr, 10);
-    return dflt;
-}
-inline uint32_t local_density_limit(uint32_t dflt)          // items per unit above which a remainder stays with the peel (0 = no rule)
-{
-    if (const char *e = getenv("KOMB_LOCAL_DENSITY")) return (uint32_t)strtoul(e, nullptr, 10);
-    return dflt;
-}
-inline uint32_t local_limit(uint64_t units, uint64_t divisor)
-{
-    uint64_t l = units / divisor;
-    if (l < 4096) l = 4096;                  // small inputs go to the fixed point whole
-    if (const char *e = getenv("KOMB_LOCAL_LIMIT")) l = strtoull(e, nullptr, 10);
-    if (l > units) l = units;
-    return (uint32_t)l;
-}
 
 struct Timer {                               // HIP-event stopwatch on one stream
     hipEvent_t a = nullptr, b = nullptr;
@@ -227,6 +190,26 @@ struct DevPool {
     }
 };
 
+// Everything the k-truss path derives from a symmetric CSR before it enumerates a triangle (truss_prep.hip): the
+// (degree,id) renumbering, the oriented CSR in those INTERNAL ids, the canonical edge list and the internal edge id of
+// every canonical edge, the per-vertex lines and the task table of the enumeration.  Built on the first k-truss call
+// of a graph (or by komb_truss_prepare), kept until the graph goes (or komb_truss_unprepare); an induced subgraph
+// gets a temporary one of its own.  Every array is a block of the context's pool.
+struct TrussPrep {
+    bool valid = false;
+    int64_t nv = 0, ne = 0;
+    int32_t  *o2i = nullptr, *i2o = nullptr; // [nv] original -> internal id (rank in (degree, original id) order) and back
+    uint32_t *orow = nullptr;                // [nv+1]  oriented CSR, INTERNAL ids, rows ascending (source below target): internal edge id = oriented slot
+    int32_t  *ocol = nullptr, *osrc = nullptr;   // [ne + 8], [ne] target / source of every oriented slot
+    int32_t  *ceu = nullptr, *cev = nullptr; // [ne] canonical edge list: ORIGINAL ids, (min,max) lexicographic
+    uint32_t *canon2e = nullptr;             // [ne] internal edge id of every canonical edge
+    uint4    *vline = nullptr;               // [4*nv] one 64-byte line per vertex: start, length, pivots and signature of its oriented row (truss_line.h)
+    void     *wtasks = nullptr;              // [n_wtasks] task descriptors of the triangle enumeration (truss_line.h)
+    int64_t   n_wtasks = 0;
+    int64_t   own_bound = 0;                 // sum over the vertices of d+ (d+ - 1): bound on the own-role index entries (capacities of a k-truss run)
+    double    ms = 0.0;                      // device time of the build (HIP events)
+};
+
 struct komb_ctx {
     komb_opts opts{};
     DevPool pool;
@@ -236,34 +219,25 @@ struct komb_ctx {
     hipStream_t stream = nullptr;            // the context's own blocking stream (api.cpp)
     bool own_stream = false;
     komb::Timer timer;
+    std::map<std::string, std::string> options;   // komb_set_option: tuning / test switches (none changes a result)
 
-    // ---- resident simple graph.  Two id spaces:
-    //   ORIGINAL ids -- what the caller passed and what every result is reported in;
-    //   INTERNAL ids -- rank of a vertex in (degree, original id) order, used by the k-truss path: its (degree,id)
-    //   orientation is then simply "lower id -> higher id", and comes with the graph (graph_build.hip).
+    // ---- resident simple graph: the symmetric CSR in the caller's (ORIGINAL) vertex ids, rows ascending -- what every result
+    // is reported in, what k-core peels on, what komb_graph_get_csr returns
     int64_t nv = -1, ne = 0;
-    uint32_t *d_o_rowptr = nullptr;          // [nv+1]  symmetric CSR, ORIGINAL ids, rows ascending (komb_graph_get_csr, merge.hip)
+    uint32_t *d_o_rowptr = nullptr;          // [nv+1]
     int32_t  *d_o_col = nullptr;             // [2*ne]
-    int32_t  *d_o2i = nullptr, *d_i2o = nullptr;   // [nv] original -> internal id and back
-    int32_t  *d_deg_i = nullptr;             // [nv] degree by INTERNAL id
-    uint32_t *d_orow = nullptr;              // [nv+1]  oriented CSR, INTERNAL ids, rows ascending (source below target): internal edge id = oriented slot
-    int32_t  *d_ocol = nullptr, *d_osrc = nullptr; // [ne (+8)] target / source of every oriented slot
-    int32_t  *d_ceu = nullptr, *d_cev = nullptr;   // [ne] canonical edge list: ORIGINAL ids, (min,max) lexicographic
-    uint32_t *d_canon2e = nullptr;           // [ne] internal edge id of every canonical edge
-    void     *d_wtasks = nullptr;            // [n_wtasks] task descriptors of the triangle enumeration (truss_wedge.h)
-    int64_t   n_wtasks = 0;
-    uint4    *d_vline = nullptr;             // [4*nv] one 64-byte line per vertex: start, length, pivots and signature of its oriented row (truss_wedge.h)
-    int64_t g_own_bound = 0;                 // sum over the vertices of d+ (d+ - 1): bound on the own-role index entries (capacities of a k-truss run)
-    int64_t g_mom[5] = {0, 0, 0, 0, 0};      // graph moments of the whole graph (k_graph_moments), computed with the graph
+    // ---- the k-truss side of the graph, made when a k-truss call first needs it
+    TrussPrep prep;
 
     // ---- k-core results
     int32_t *d_deg = nullptr;                // [nv] degree (a2), ORIGINAL ids
     int32_t *d_core = nullptr;               // [nv] coreness (a3), ORIGINAL ids
     bool core_done = false;
 
-    // ---- k-truss results (internal edge id = oriented slot)
+    // ---- k-truss results (canonical order)
     int64_t t_ne = -1;                       // edges of the (sub)graph last run
-    int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr; // canonical order
+    int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr;
+    bool t_own_edges = false;                // d_t_eu / d_t_ev are pool blocks of their own (induced subgraph), not the preparation's list
     bool truss_done = false;
     int slice_rank = 0, slice_world = 1;     // komb_truss_run_slice: the canonical edges whose results this run materialises
     bool shard_peel = false;                 // komb_set_shard_peel: sharded runs split the peel too (shard_dev.h)
@@ -276,6 +250,49 @@ struct komb_ctx {
 
     komb_stats stats{};
 };
+
+// ---- options (komb_set_option): what the library used to read from KOMB_* environment variables.  The drop-in never sets
+// any; tests and measurements do, explicitly, per context.
+inline const char *ctx_opt(const komb_ctx *ctx, const char *name)
+{
+    const auto it = ctx->options.find(name);
+    return it == ctx->options.end() ? nullptr : it->second.c_str();
+}
+inline bool ctx_flag(const komb_ctx *ctx, const char *name)
+{
+    const char *v = ctx_opt(ctx, name);
+    return v && strcmp(v, "0") != 0;
+}
+namespace komb {
+inline FinishMode finish_mode(const komb_ctx *ctx, FinishMode dflt)
+{
+    const char *e = ctx_opt(ctx, "FINISH");
+    if (e && !strcmp(e, "local")) return FIN_LOCAL;
+    if (e && !strcmp(e, "lds")) return FIN_LDS;
+    if (e && !strcmp(e, "none")) return FIN_NONE;
+    return dflt;
+}
+// The fixed point costs ~ sweeps x items, the peel ~ its items once + a latency per sub-round: a remainder with more items
+// than this is not handed over (the peel goes on and offers a smaller one).  Option LOCAL_ITEMS overrides.
+inline uint64_t local_item_limit(const komb_ctx *ctx, uint64_t dflt)
+{
+    if (const char *e = ctx_opt(ctx, "LOCAL_ITEMS")) return strtoull(e, nullptr, 10);
+    return dflt;
+}
+inline uint32_t local_density_limit(const komb_ctx *ctx, uint32_t dflt)          // items per unit above which a remainder stays with the peel (0 = no rule)
+{
+    if (const char *e = ctx_opt(ctx, "LOCAL_DENSITY")) return (uint32_t)strtoul(e, nullptr, 10);
+    return dflt;
+}
+inline uint32_t local_limit(const komb_ctx *ctx, uint64_t units, uint64_t divisor)
+{
+    uint64_t l = units / divisor;
+    if (l < 4096) l = 4096;                  // small inputs go to the fixed point whole
+    if (const char *e = ctx_opt(ctx, "LOCAL_LIMIT")) l = strtoull(e, nullptr, 10);
+    if (l > units) l = units;
+    return (uint32_t)l;
+}
+} // namespace komb
 
 // Scratch buffers of one stage: everything still owned goes back to the context's pool on scope exit.
 struct DevBufs {
@@ -371,12 +388,17 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
 void graph_free(komb_ctx *ctx);
 void stager_free(komb_ctx *ctx);
 void warm_up(komb_ctx *ctx);                 // graph_build.hip: first kernel launch of the library + the upload's staging buffers
-// sum d^2, sum min(d,d), max d, (unused), sum d+ + d+ of an oriented graph (ktruss.hip; the build calls it once per graph)
-int build_tasks(komb_ctx *ctx, const uint32_t *orow, int64_t nv, bool resident, void **tasks, int64_t *ntasks);   // ktruss.hip
-int own_bound(komb_ctx *ctx, const uint32_t *orow, int64_t nv, int64_t *out);                                  // ktruss.hip (k_own_bound)
-int vertex_lines(komb_ctx *ctx, const uint32_t *orow, const int32_t *ocol, int64_t nv, void *lines);   // ktruss.hip (k_vertex_lines)
-int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *osrc, const int32_t *ocol, int64_t m,
-                  const uint32_t *orow, int64_t out[5]);
+// truss_prep.hip: the k-truss side of a symmetric CSR (device pointers; nv vertices, ns = 2 |E| slots)
+int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_t nv, int64_t ns, TrussPrep *out);
+void prep_free(komb_ctx *ctx, TrussPrep *p);
+int prep_ensure(komb_ctx *ctx);              // the resident graph's preparation, built if absent (ctx->prep)
+// sum d^2, sum min(d,d), max d, (unused), sum d+ + d+ of the resident graph: the roofline model's inputs (measurement only)
+int graph_moments(komb_ctx *ctx, int64_t out[5]);
+// the subgraph induced by a vertex mask as a symmetric CSR of its own (new ids = ranks among the kept vertices)
+struct InducedCsr { int64_t nv = 0, ns = 0; uint32_t *rowptr = nullptr; int32_t *col = nullptr; int32_t *vold = nullptr; };
+int induce_csr(komb_ctx *ctx, const uint8_t *vmask_host, InducedCsr *out);
+void induced_free(komb_ctx *ctx, InducedCsr *g);
+int map_edges(komb_ctx *ctx, const int32_t *vold, const int32_t *eu, const int32_t *ev, int64_t m, int32_t *out_u, int32_t *out_v);
 void truss_free(komb_ctx *ctx);
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done);
 void peel_collect_ctrl(hipStream_t s, PeelCtrl *d_collect, const PeelCtrl *d_from);

@@ -3,28 +3,22 @@
 // (reference src/graph.cpp:418, src/graph.cpp:438), built on the device and
 // left resident in HBM.
 //
-// What stays resident (common.h, komb_ctx):
-//   * the symmetric CSR in ORIGINAL ids, rows ascending (komb_graph_get_csr; the canonical edge order of every result);
-//   * the ORIENTED graph of the k-truss path in INTERNAL ids = rank of a vertex in (degree, original id) order: every edge
-//     once, from its lower to its higher endpoint, as a CSR with ascending rows plus the source of every slot -- the
-//     internal edge id is the oriented slot.  In degree order the (degree,id) orientation is an id compare, so no run has
-//     to orient anything;
-//   * the canonical edge list (original ids, (min,max)-lexicographic) and, for every canonical edge, its internal edge id;
-//   * one 64-byte line per vertex describing its oriented row to the triangle enumeration, and that enumeration's task
-//     table (truss_wedge.h).
+// What stays resident (common.h, komb_ctx): the symmetric CSR in the caller's (ORIGINAL) vertex ids, rows ascending --
+// komb_graph_get_csr, the k-core peel, the canonical edge order of every result.  Nothing else: what only the k-truss path
+// reads (the (degree,id) renumbering, the oriented CSR, the canonical edge map, the enumeration's lines and tasks) is made
+// by the first k-truss call of the graph, inside that call (truss_prep.hip) -- rounds 1-4 built it here.
 //
 // How: both directions of every raw pair as 64-bit keys (src << vb | dst, vb = bits of a vertex id), radix-sorted on the
-// 2*vb significant bits and uniqued -> original CSR.  Vertices are radix-sorted (stably) by degree -> the renumbering.
-// Every canonical edge then emits its oriented internal slot as a (key, canonical id) record; one more radix sort puts the
-// records in oriented CSR order, and one pass splits them into targets, sources and the canonical -> internal map (the only
-// scattered store of the build: one 4-byte word per edge).  k-core keeps working on the original-id CSR (kcore.hip says why).
+// 2*vb significant bits and uniqued -> the CSR.
 //
 // The raw pairs arrive in pageable host memory (1.8 GB at |E| = 100M): they are staged through pinned buffers by a few
 // host threads (a single-threaded staging copy runs at 8-12 GB/s, a third of what the link takes).
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <system_error>
 #include <thread>
 
 // ---------------------------------------------------------------- host -> device staging
@@ -86,26 +80,41 @@ hipError_t h2d_staged(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
     hipError_t err[H2DStager::kThreads];
     std::thread th[H2DStager::kThreads];
     const int dev = ctx->device;
+    // thread t copies chunks t, t + started, ...: `started` is how many threads could be created (a process at its thread
+    // limit gets fewer, or none: then this thread does the staged copy alone -- an exception must not cross the C ABI)
+    auto work = [=, &err](int t, int stride) {
+        hipError_t e = hipSetDevice(dev);
+        size_t turn = 0;
+        for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += (size_t)stride, ++turn) {
+            const int b = (int)(turn % H2DStager::kBufs);
+            if (turn >= (size_t)H2DStager::kBufs) e = hipEventSynchronize(g->ev[t][b]);      // the buffer's previous copy has left it
+            if (e != hipSuccess) break;
+            const size_t off = c * H2DStager::kChunk, len = std::min(H2DStager::kChunk, bytes - off);
+            memcpy(g->pin[t][b], (const char *)src + off, len);
+            e = hipMemcpyAsync((char *)dst + off, g->pin[t][b], len, hipMemcpyHostToDevice, g->st[t]);
+            if (e == hipSuccess) e = hipEventRecord(g->ev[t][b], g->st[t]);
+        }
+        const hipError_t e2 = hipStreamSynchronize(g->st[t]);
+        err[t] = e != hipSuccess ? e : e2;
+    };
+    // how many threads can be had is known only by trying: the stride is fixed before the first one starts copying
+    int started = 0;
+    struct Gate { std::atomic<int> stride{0}; } gate;
     for (int t = 0; t < H2DStager::kThreads; ++t) {
         err[t] = hipSuccess;
-        th[t] = std::thread([=, &err]() {
-            hipError_t e = hipSetDevice(dev);
-            size_t turn = 0;
-            for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += H2DStager::kThreads, ++turn) {
-                const int b = (int)(turn % H2DStager::kBufs);
-                if (turn >= (size_t)H2DStager::kBufs) e = hipEventSynchronize(g->ev[t][b]);      // the buffer's previous copy has left it
-                if (e != hipSuccess) break;
-                const size_t off = c * H2DStager::kChunk, len = std::min(H2DStager::kChunk, bytes - off);
-                memcpy(g->pin[t][b], (const char *)src + off, len);
-                e = hipMemcpyAsync((char *)dst + off, g->pin[t][b], len, hipMemcpyHostToDevice, g->st[t]);
-                if (e == hipSuccess) e = hipEventRecord(g->ev[t][b], g->st[t]);
-            }
-            const hipError_t e2 = hipStreamSynchronize(g->st[t]);
-            err[t] = e != hipSuccess ? e : e2;
-        });
+        try {
+            th[t] = std::thread([&gate, &work, t]() {
+                int stride;
+                while ((stride = gate.stride.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+                if (stride > 0) work(t, stride);
+            });
+            ++started;
+        } catch (const std::system_error &) { break; }
     }
+    if (started == 0) { work(0, 1); return err[0]; }
+    gate.stride.store(started, std::memory_order_release);
     hipError_t e = hipSuccess;
-    for (int t = 0; t < H2DStager::kThreads; ++t) { th[t].join(); if (err[t] != hipSuccess) e = err[t]; }
+    for (int t = 0; t < started; ++t) { th[t].join(); if (err[t] != hipSuccess) e = err[t]; }
     return e;
 }
 
@@ -137,17 +146,15 @@ __global__ __launch_bounds__(kBlock) void k_make_keys(const int64_t *__restrict_
     }
 }
 
-// uniq[0..ns) sorted by (src,dst): col[j] = dst, src[j] = src, rowptr[v] = first slot with src >= v
+// uniq[0..ns) sorted by (src,dst): col[j] = dst, rowptr[v] = first slot with src >= v
 __global__ __launch_bounds__(kBlock) void k_keys_to_csr(const uint64_t *__restrict__ uniq, int64_t ns, int64_t nv, int vb,
-                                                        uint32_t *__restrict__ rowptr, int32_t *__restrict__ col,
-                                                        int32_t *__restrict__ src)
+                                                        uint32_t *__restrict__ rowptr, int32_t *__restrict__ col)
 {
     const uint64_t mask = (1ull << vb) - 1ull;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
         const uint64_t k = uniq[j];
         const int64_t s = (int64_t)(k >> vb);
         col[j] = (int32_t)(k & mask);
-        src[j] = (int32_t)s;
         const int64_t p = (j == 0) ? -1 : (int64_t)(uniq[j - 1] >> vb);
         for (int64_t v = p + 1; v <= s; ++v) rowptr[v] = (uint32_t)j;
         if (j == ns - 1)
@@ -191,94 +198,6 @@ __global__ __launch_bounds__(kBlock) void k_validate_csr(const uint32_t *__restr
     }
 }
 
-// src[j] = row of slot j, for a caller-supplied CSR (one wavefront per row, once per graph)
-__global__ __launch_bounds__(kBlock) void k_fill_src(const uint32_t *__restrict__ rowptr, int64_t nv, int32_t *__restrict__ src)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    for (int64_t v = wave; v < nv; v += nwaves)
-        for (uint32_t j = rowptr[v] + (uint32_t)lane; j < rowptr[v + 1]; j += 64) src[j] = (int32_t)v;
-}
-
-// ---- the renumbering
-// sort records of the vertices: (degree, original id); first slot of the upper half (column above row) of every original
-// row and its length (the canonical edges the row owns)
-__global__ __launch_bounds__(kBlock) void k_vertex_keys(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
-                                                        uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
-                                                        uint32_t *__restrict__ first_upper, uint32_t *__restrict__ upper_cnt)
-{
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) {
-        if (v == nv) { upper_cnt[v] = 0u; continue; }
-        const uint32_t b = rowptr[v], e = rowptr[v + 1];
-        dkey[v] = e - b;
-        dval[v] = (uint32_t)v;
-        uint32_t lo = b, hi = e;                                  // first slot with col > v (rows hold no loops)
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (col[mid] < (int32_t)v) lo = mid + 1; else hi = mid;
-        }
-        first_upper[v] = lo;
-        upper_cnt[v] = e - lo;
-    }
-}
-
-// i2o[i] = the vertex with the i-th smallest (degree, id); o2i its inverse
-__global__ __launch_bounds__(kBlock) void k_invert(const uint32_t *__restrict__ sorted_ids, int64_t nv, int32_t *__restrict__ i2o, int32_t *__restrict__ o2i)
-{
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
-        const uint32_t v = sorted_ids[i];
-        i2o[i] = (int32_t)v;
-        o2i[v] = (int32_t)i;
-    }
-}
-
-// every upper slot (u < v) of the original CSR = canonical edge k = ebase[u] + (j - first_upper[u]): its endpoints, and its
-// oriented internal slot as a sort record (key = lower internal id << vb | higher internal id, value = k)
-__global__ __launch_bounds__(kBlock) void k_emit_records(const int32_t *__restrict__ src, const int32_t *__restrict__ col, int64_t ns,
-                                                         const uint32_t *__restrict__ first_upper, const uint32_t *__restrict__ ebase,
-                                                         const int32_t *__restrict__ o2i, int vb,
-                                                         int32_t *__restrict__ ceu, int32_t *__restrict__ cev,
-                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < ns; j += (int64_t)gridDim.x * kBlock) {
-        const int32_t u = src[j], v = col[j];
-        if (v < u) continue;
-        const uint32_t k = ebase[u] + ((uint32_t)j - first_upper[u]);
-        const uint64_t a = (uint64_t)(uint32_t)o2i[u], b = (uint64_t)(uint32_t)o2i[v];
-        ceu[k] = u; cev[k] = v;
-        keys[k] = a < b ? (a << vb) | b : (b << vb) | a;
-        vals[k] = k;
-    }
-}
-
-// oriented row pointers: orow[a] = first sorted record whose source is >= a (one thread per row, binary search: the rows
-// without out-edges -- isolated vertices, local maxima -- need no gap filling)
-__global__ __launch_bounds__(kBlock) void k_orow_search(const uint64_t *__restrict__ keys, int64_t ne, int64_t nv, int vb, uint32_t *__restrict__ orow)
-{
-    for (int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x; a <= nv; a += (int64_t)gridDim.x * kBlock) {
-        int64_t lo = 0, hi = ne;
-        while (lo < hi) {
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            if ((int64_t)(keys[mid] >> vb) < a) lo = mid + 1; else hi = mid;
-        }
-        orow[a] = (uint32_t)lo;
-    }
-}
-
-// the sorted records -> targets and sources of the oriented slots, and the canonical -> internal edge map
-__global__ __launch_bounds__(kBlock) void k_split_records(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t ne, int vb,
-                                                          int32_t *__restrict__ ocol, int32_t *__restrict__ osrc, uint32_t *__restrict__ canon2e)
-{
-    const uint64_t mask = (1ull << vb) - 1ull;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ne; e += (int64_t)gridDim.x * kBlock) {
-        const uint64_t k = keys[e];
-        ocol[e] = (int32_t)(k & mask);
-        osrc[e] = (int32_t)(k >> vb);
-        canon2e[vals[e]] = (uint32_t)e;
-    }
-}
-
 struct Scratch {                                   // device scratch of one build: freed on every way out
     std::vector<void *> v;
     template <class T> hipError_t get(T **out, size_t count)
@@ -301,65 +220,6 @@ inline int id_bits(int64_t nv)
     return vb;
 }
 
-// From the original CSR (ctx->d_o_rowptr / d_o_col, with the row of every slot in d_src_o) to everything else that stays
-// resident.  d_k0 / d_k1: two scratch key buffers of at least ns / 2 entries each (or null: allocated here).
-int finish_graph(komb_ctx *ctx, Scratch &sc, const int32_t *d_src_o, int64_t nv, int64_t ns, int vb, uint64_t *d_k0, uint64_t *d_k1)
-{
-    hipStream_t s = ctx->stream;
-    const int64_t ne = ns / 2;
-    const int gv = grid_for(nv + 1), gs = grid_for(ns);
-    KOMB_HIP(ctx, resident(&ctx->d_o2i, (size_t)nv));
-    KOMB_HIP(ctx, resident(&ctx->d_i2o, (size_t)nv));
-    KOMB_HIP(ctx, resident(&ctx->d_deg_i, (size_t)nv));
-    KOMB_HIP(ctx, resident(&ctx->d_orow, (size_t)nv + 1));
-    KOMB_HIP(ctx, resident(&ctx->d_ocol, (size_t)ne + 8));              // + 8: the triangle enumeration reads 16 bytes at a time, past the end of the last row
-    KOMB_HIP(ctx, resident(&ctx->d_osrc, (size_t)ne));
-    KOMB_HIP(ctx, resident(&ctx->d_ceu, (size_t)ne));
-    KOMB_HIP(ctx, resident(&ctx->d_cev, (size_t)ne));
-    KOMB_HIP(ctx, resident(&ctx->d_canon2e, (size_t)ne));
-    KOMB_HIP(ctx, resident(&ctx->d_vline, 4 * (size_t)nv));
-    KOMB_HIP(ctx, hipMemsetAsync(ctx->d_ocol + ne, 0, 8 * sizeof(int32_t), s));
-
-    // ---- vertices by (degree, original id)
-    uint32_t *d_dk[2] = {nullptr, nullptr}, *d_dv[2] = {nullptr, nullptr}, *d_fu = nullptr, *d_uc = nullptr, *d_ebase = nullptr;
-    for (int i = 0; i < 2; ++i) { KOMB_HIP(ctx, sc.get(&d_dk[i], (size_t)nv)); KOMB_HIP(ctx, sc.get(&d_dv[i], (size_t)nv)); }
-    KOMB_HIP(ctx, sc.get(&d_fu, (size_t)nv + 1));
-    KOMB_HIP(ctx, sc.get(&d_uc, (size_t)nv + 1));
-    KOMB_HIP(ctx, sc.get(&d_ebase, (size_t)nv + 1));
-    k_vertex_keys<<<gv, kBlock, 0, s>>>(ctx->d_o_rowptr, ctx->d_o_col, nv, d_dk[0], d_dv[0], d_fu, d_uc);
-    uint32_t *sk = nullptr, *sv = nullptr;
-    KOMB_TRY(prim_sort_pairs_u32_u32(ctx, d_dk[0], d_dk[1], d_dv[0], d_dv[1], nv, 32, &sk, &sv));
-    if (nv > 0) {
-        k_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, nv, ctx->d_i2o, ctx->d_o2i);
-        KOMB_HIP(ctx, hipMemcpyAsync(ctx->d_deg_i, sk, (size_t)nv * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // degrees by internal id
-    }
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_uc, d_ebase, nv + 1));
-
-    // ---- canonical edges -> sort records -> oriented CSR in internal ids, canonical -> internal map
-    if (ne > 0) {
-        uint32_t *d_v0 = nullptr, *d_v1 = nullptr;
-        if (!d_k0) KOMB_HIP(ctx, sc.get(&d_k0, (size_t)ne));
-        if (!d_k1) KOMB_HIP(ctx, sc.get(&d_k1, (size_t)ne));
-        KOMB_HIP(ctx, sc.get(&d_v0, (size_t)ne));
-        KOMB_HIP(ctx, sc.get(&d_v1, (size_t)ne));
-        k_emit_records<<<gs, kBlock, 0, s>>>(d_src_o, ctx->d_o_col, ns, d_fu, d_ebase, ctx->d_o2i, vb, ctx->d_ceu, ctx->d_cev, d_k0, d_v0);
-        uint64_t *skeys = nullptr; uint32_t *svals = nullptr;
-        KOMB_TRY(prim_sort_pairs_u64_u32(ctx, d_k0, d_k1, d_v0, d_v1, ne, 2 * vb, &skeys, &svals));
-        k_orow_search<<<gv, kBlock, 0, s>>>(skeys, ne, nv, vb, ctx->d_orow);
-        k_split_records<<<grid_for(ne), kBlock, 0, s>>>(skeys, svals, ne, vb, ctx->d_ocol, ctx->d_osrc, ctx->d_canon2e);
-    } else {
-        k_fill_u32<<<gv, kBlock, 0, s>>>(ctx->d_orow, nv + 1, 0u);
-    }
-    // ---- the oriented rows' lines for the triangle enumeration (truss_wedge.h)
-    KOMB_TRY(vertex_lines(ctx, ctx->d_orow, ctx->d_ocol, nv, ctx->d_vline));
-    KOMB_TRY(build_tasks(ctx, ctx->d_orow, nv, true, &ctx->d_wtasks, &ctx->n_wtasks));
-    KOMB_TRY(own_bound(ctx, ctx->d_orow, nv, &ctx->g_own_bound));
-    // ---- graph moments for the roofline model (properties of the graph, not results of the path)
-    KOMB_TRY(graph_moments(ctx, ctx->d_deg_i, nv, ctx->d_osrc, ctx->d_ocol, ne, ctx->d_orow, ctx->g_mom));
-    KOMB_HIP(ctx, hipStreamSynchronize(s));
-    return KOMB_OK;
-}
-
 double wall_ms(std::chrono::steady_clock::time_point t0)
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -371,15 +231,13 @@ void publish_stats(komb_ctx *ctx, int64_t nv, int64_t ne)
     ctx->ne = ne;
     ctx->stats = komb_stats{};
     ctx->stats.nv = nv; ctx->stats.ne = ne;
-    ctx->stats.sum_deg_sq = ctx->g_mom[0]; ctx->stats.wedge_items = ctx->g_mom[1];
-    ctx->stats.max_degree = (int32_t)ctx->g_mom[2]; ctx->stats.oriented_items = ctx->g_mom[4];
 }
 
 } // namespace
 
 void warm_up(komb_ctx *ctx)
 {
-    const bool dbg = getenv("KOMB_BUILD_DEBUG") != nullptr;
+    const bool dbg = ctx->opts.verbosity > 1;
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t *d = nullptr;
     if (hipMalloc(&d, 256) == hipSuccess) {
@@ -388,24 +246,24 @@ void warm_up(komb_ctx *ctx)
         (void)hipFree(d);
     }
     if (dbg) fprintf(stderr, "komb warm-up: first kernel launch %.1f ms\n", wall_ms(t0));
-    const auto t1 = std::chrono::steady_clock::now();
-    (void)stager_get(ctx);
-    if (dbg) fprintf(stderr, "komb warm-up: staging buffers %.1f ms\n", wall_ms(t1));
+    // the upload's pinned staging buffers + streams (128 MB, 60 ms): only for a caller that says it will upload a big graph
+    // (komb2 does, beside its SAM parse); everyone else gets them on the first upload of 64 MB or more
+    if (ctx->opts.reserved[0] & KOMB_CREATE_WARM_UPLOAD) {
+        const auto t1 = std::chrono::steady_clock::now();
+        (void)stager_get(ctx);
+        if (dbg) fprintf(stderr, "komb warm-up: staging buffers %.1f ms\n", wall_ms(t1));
+    }
     (void)hipGetLastError();
 }
 
 void graph_free(komb_ctx *ctx)
 {
-    void *all[] = {ctx->d_o_rowptr, ctx->d_o_col, ctx->d_o2i, ctx->d_i2o, ctx->d_deg_i, ctx->d_orow, ctx->d_ocol, ctx->d_osrc,
-                   ctx->d_ceu, ctx->d_cev, ctx->d_canon2e, ctx->d_vline, ctx->d_wtasks, ctx->d_deg, ctx->d_core};
-    truss_free(ctx);                                     // (its canonical endpoint arrays may BE d_ceu / d_cev: released first)
+    void *all[] = {ctx->d_o_rowptr, ctx->d_o_col, ctx->d_deg, ctx->d_core};
+    truss_free(ctx);                                     // (its canonical endpoint arrays may BE the preparation's: released first)
+    prep_free(ctx, &ctx->prep);
     for (void *p : all) if (p) (void)hipFree(p);
-    ctx->d_o_rowptr = nullptr; ctx->d_o_col = nullptr; ctx->d_o2i = ctx->d_i2o = nullptr;
-    ctx->d_deg_i = nullptr; ctx->d_orow = nullptr; ctx->d_ocol = ctx->d_osrc = nullptr;
-    ctx->d_ceu = ctx->d_cev = nullptr; ctx->d_canon2e = nullptr; ctx->d_vline = nullptr; ctx->d_wtasks = nullptr; ctx->n_wtasks = 0; ctx->d_deg = nullptr; ctx->d_core = nullptr;
+    ctx->d_o_rowptr = nullptr; ctx->d_o_col = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
-    for (auto &m : ctx->g_mom) m = 0;
-    ctx->g_own_bound = 0;
     ctx->pool.clear();                                   // scratch sized for the old graph
 }
 
@@ -426,8 +284,8 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
     Scratch sc;
     KOMB_HIP(ctx, resident(&ctx->d_o_rowptr, (size_t)nv + 1));
     int64_t ns = 0;
-    int32_t *d_src_o = nullptr;
     uint64_t *d_k0 = nullptr, *d_k1 = nullptr;
+    const bool dbg = ctx->opts.verbosity > 1 || ctx_flag(ctx, "BUILD_DEBUG");
     if (n_raw > 0) {
         int64_t *d_uv = nullptr; int *d_bad = nullptr;
         const int64_t nk = 2 * n_raw;
@@ -436,7 +294,6 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
         KOMB_HIP(ctx, sc.get(&d_k1, (size_t)nk));
         KOMB_HIP(ctx, sc.get(&d_bad, 1));
         KOMB_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), s));
-        const bool dbg = getenv("KOMB_BUILD_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "komb build: allocations %.1f ms\n", wall_ms(t_all));
         const auto t_st = std::chrono::steady_clock::now();
         (void)stager_get(ctx);
@@ -466,24 +323,19 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
         if (ns > 0xFFFFFFF0ll) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld slots; limit is 2^32-16", (long long)ns);
         if (ns / 2 > INT32_MAX - 16) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "graph has %lld edges; limit is 2^31-16", (long long)(ns / 2));
         KOMB_HIP(ctx, resident(&ctx->d_o_col, (size_t)ns));
-        KOMB_HIP(ctx, sc.get(&d_src_o, (size_t)ns));
-        if (ns > 0) k_keys_to_csr<<<grid_for(ns), kBlock, 0, s>>>(other, ns, nv, vb, ctx->d_o_rowptr, ctx->d_o_col, d_src_o);
+        if (ns > 0) k_keys_to_csr<<<grid_for(ns), kBlock, 0, s>>>(other, ns, nv, vb, ctx->d_o_rowptr, ctx->d_o_col);
         else k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_o_rowptr, nv + 1, 0u);
     } else {
         KOMB_HIP(ctx, resident(&ctx->d_o_col, 1));
         k_fill_u32<<<grid_for(nv + 1), kBlock, 0, s>>>(ctx->d_o_rowptr, nv + 1, 0u);
     }
     KOMB_HIP(ctx, hipStreamSynchronize(s));
-    if (getenv("KOMB_BUILD_DEBUG")) fprintf(stderr, "komb build: original CSR done at %.1f ms\n", wall_ms(t_all));
-    const auto t_rel = std::chrono::steady_clock::now();
-    KOMB_TRY(finish_graph(ctx, sc, d_src_o, nv, ns, vb, d_k0, d_k1));
-    const double ms_rel = wall_ms(t_rel);
-    if (getenv("KOMB_BUILD_DEBUG")) fprintf(stderr, "komb build: renumbering + oriented CSR %.1f ms\n", ms_rel);
+    if (dbg) fprintf(stderr, "komb build: CSR done at %.1f ms\n", wall_ms(t_all));
     fail.armed = false;
     publish_stats(ctx, nv, ns / 2);
     ctx->stats.ms_build = wall_ms(t_all);
     ctx->stats.ms_build_h2d = ms_h2d;
-    ctx->stats.ms_build_relabel = ms_rel;
+    ctx->stats.ms_build_relabel = 0.0;                   // (rounds 1-4: the k-truss side was built here; now truss_prep.hip, stats.ms_prepare)
     return KOMB_OK;
 }
 
@@ -501,10 +353,9 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
     const auto t_all = std::chrono::steady_clock::now();
     struct Fail { komb_ctx *c; bool armed = true; ~Fail() { if (armed) graph_free(c); } } fail{ctx};
     Scratch sc;
-    int64_t *d_rp64 = nullptr; int *d_bad = nullptr; int32_t *d_src_o = nullptr;
+    int64_t *d_rp64 = nullptr; int *d_bad = nullptr;
     KOMB_HIP(ctx, resident(&ctx->d_o_rowptr, (size_t)nv + 1));
     KOMB_HIP(ctx, resident(&ctx->d_o_col, (size_t)ns));
-    KOMB_HIP(ctx, sc.get(&d_src_o, (size_t)ns));
     KOMB_HIP(ctx, sc.get(&d_rp64, (size_t)nv + 1));
     KOMB_HIP(ctx, sc.get(&d_bad, 1));
     KOMB_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), s));
@@ -516,20 +367,17 @@ int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32
     k_rowptr_narrow<<<grid_for(nv + 1), kBlock, 0, s>>>(d_rp64, nv + 1, ctx->d_o_rowptr, d_bad);
     KOMB_HIP(ctx, d2h(ctx, &bad, d_bad, sizeof(int)));
     if (!bad && nv > 0) {                                        // rowptr is sane: rows can be walked safely
-        k_fill_src<<<grid_for(nv * 16), kBlock, 0, s>>>(ctx->d_o_rowptr, nv, d_src_o);
         k_validate_csr<<<grid_for(nv), kBlock, 0, s>>>(ctx->d_o_rowptr, ctx->d_o_col, nv, d_bad);
         KOMB_HIP(ctx, d2h(ctx, &bad, d_bad, sizeof(int)));
     }
     if (bad) KOMB_FAIL(ctx, KOMB_ERR_ARG, "graph_from_csr: CSR is not simple, symmetric and row-sorted");
     sc.drop(d_rp64);
-    const auto t_rel = std::chrono::steady_clock::now();
-    KOMB_TRY(finish_graph(ctx, sc, d_src_o, nv, ns, id_bits(nv), nullptr, nullptr));
-    const double ms_rel = wall_ms(t_rel);
+    KOMB_HIP(ctx, hipStreamSynchronize(s));
     fail.armed = false;
     publish_stats(ctx, nv, ns / 2);
     ctx->stats.ms_build = wall_ms(t_all);
     ctx->stats.ms_build_h2d = ms_h2d;
-    ctx->stats.ms_build_relabel = ms_rel;
+    ctx->stats.ms_build_relabel = 0.0;
     return KOMB_OK;
 }
 

@@ -252,8 +252,9 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
     stt.core_levels = stt.core_subrounds = stt.core_launches = 0;
     stt.max_coreness = 0; stt.ms_core = 0.0;
     stt.core_local_units = 0; stt.core_local_sweeps = 0; stt.core_local_items = 0; stt.ms_core_local = 0.0;
-    if (getenv("KOMB_SHARD_PEEL")) sharded = true;               // (one rank: the sharded engine without a collective -- a test of its logic)
+    if (ctx_flag(ctx, "SHARD_ENGINE")) sharded = true;          // (one rank: the sharded engine without a collective -- a test of its logic)
     stt.shard_exchanges = 0; stt.ms_exchange = 0.0; stt.exchange_words = 0;
+    stt.engine_flags = sharded ? KOMB_ENGINE_SHARD_PEEL : 0;
     if (nv == 0) { ctx->core_done = true; return KOMB_OK; }
 
     Range r_all("komb_core_run");
@@ -261,7 +262,7 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
     const size_t heavy_cap = (size_t)(2 * ctx->ne) / 32 + 64;    // sum over units with > kLight items of ceil(items / kChunk) <= 3/128 of all items
     int32_t *d_degw = nullptr; PeelCtrl *d_ctrl = nullptr; uint32_t *d_grp = nullptr;
     CoreTailBufs T{};
-    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, scan_scalar_switch()};
+    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, 0};
     KOMB_HIP(ctx, bufs.alloc(&d_degw, (size_t)nv));
     for (int i = 0; i < 2; ++i) {
         KOMB_HIP(ctx, bufs.alloc(&Q.light[i], (size_t)nv));
@@ -272,13 +273,13 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
     KOMB_HIP(ctx, bufs.alloc(&d_ctrl, 1));
     KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
     // how the peel ends (common.h): local fixed point (default), LDS tail, or the general engine alone
-    const FinishMode fin = finish_mode(FIN_LOCAL);
+    const FinishMode fin = finish_mode(ctx, FIN_LOCAL);
     uint32_t tail_limit = 0;
     const size_t live_words = ((size_t)nv + 63) / 64;
     unsigned long long *d_livebits = nullptr;
     if (fin == FIN_LDS) {
         tail_limit = kCoreTailV;
-        if (const char *tl = getenv("KOMB_CORE_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
+        if (const char *tl = ctx_opt(ctx, "CORE_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
         if (tail_limit > kCoreTailV) tail_limit = kCoreTailV;
         if (tail_limit) {
             KOMB_HIP(ctx, bufs.alloc(&T.livebits, live_words));
@@ -288,7 +289,7 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
             KOMB_HIP(ctx, bufs.alloc(&T.rows, (size_t)kCoreTailV * kCoreTailWords));
         }
     } else if (fin == FIN_LOCAL) {
-        tail_limit = local_limit((uint64_t)nv, 16);
+        tail_limit = local_limit(ctx, (uint64_t)nv, 16);
         if (tail_limit) KOMB_HIP(ctx, bufs.alloc(&d_livebits, live_words));
     }
 
@@ -323,7 +324,7 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
         KOMB_HIP(ctx, hipMemsetAsync(d_livebits, 0, live_words * sizeof(unsigned long long), s));
         LocalStats ls;
         const int rc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)nv, ctx->d_core, d_degw, Q.live[hc.live_sel],
-            (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), local_item_limit(std::max<uint64_t>(kCoreLocalItems, (uint64_t)ctx->ne / 3)), 0u, false, 0, ctx->d_core,
+            (uint32_t)kWave * CoreLocal::kU, sizeof(uint32_t), local_item_limit(ctx, std::max<uint64_t>(kCoreLocalItems, (uint64_t)ctx->ne / 3)), 0u, false, 0, ctx->d_core,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 CoreCollect C{(uint32_t)nv, ctx->d_o_rowptr, ctx->d_o_col, ctx->d_core, d_livebits, num, lg.off, lg.cur, (uint32_t *)items};
                 k_peel_step<CoreCollect><<<grid, kPeelBlock, 0, s>>>(d_cctrl, d_grp, Q, C, launch);
@@ -396,6 +397,8 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
 #endif
     KOMB_TRY(st);
     if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-core peel ended in an inconsistent state");
+    if (stt.core_local_units) stt.engine_flags |= KOMB_ENGINE_LOCAL_FINISH;
+    else if (fin == FIN_LDS && tail_limit) stt.engine_flags |= KOMB_ENGINE_LDS_TAIL;
     stt.core_levels = ctx->h_ctrl[0].n_levels;
     stt.core_subrounds = ctx->h_ctrl[0].n_rounds;
     stt.core_launches = launches;

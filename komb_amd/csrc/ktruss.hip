@@ -6,15 +6,17 @@
 //
 // MI355X-first design (no intersections inside the peel loop):
 //   1. every edge points from its lower to its higher (degree,id) endpoint.  The
-//      k-truss side of the graph is resident in INTERNAL ids = (degree,id) ranks
-//      (graph_build.hip), so that oriented CSR (orow/ocol) comes with the graph;
-//      an induced subgraph is an ordered stream compaction of its slots
-//      (k_slot_filter).  The internal edge id is the oriented slot.  On power-law
+//      k-truss side of a graph -- INTERNAL ids = (degree,id) ranks, the oriented
+//      CSR in those ids (orow/ocol), the canonical edge map, the enumeration's
+//      lines and tasks -- is made by truss_prep.hip when the first k-truss call of
+//      a graph needs it (inside the call and its time) and kept with the graph; an
+//      induced subgraph is first made a symmetric CSR of its own and then prepared
+//      like any graph.  The internal edge id is the oriented slot.  On power-law
 //      unitig graphs the oriented rows are tiny (max ~10^2), whatever the hub
 //      degrees are.
 //   2. enumerate every triangle once and build the incidence index: for every
 //      edge, the pairs of the other two edges of its triangles (24 bytes per
-//      triangle).  Enumeration by WEDGES (truss_wedge.h, round 4): the slots of
+//      triangle).  Enumeration by WEDGES (truss_wedge.h): the slots of
 //      the LDS-staged row of a behind edge a->b are tested against a 64-byte line
 //      of b (pivots + Bloom signature), survivors looked up in N+(b) with one
 //      trip to memory.  ONE pass: the entries of a task's own edges leave it as a
@@ -23,10 +25,9 @@
 //      BIN (64-edge chunks dealt round-robin, truss_index.h) and one workgroup per
 //      bin assembles its window of the index in LDS (k_bin_count, k_bin_finish),
 //      which also writes the slices' (start, length) pairs, the peel's initial
-//      state and the first level's frontier.  Round 3's probe enumeration
-//      (KOMB_ENUM=probe, truss_tri.h), round 2's bounded slices
-//      (KOMB_INDEX=slices) and the exact count-scan-fill two-pass layout
-//      (KOMB_INDEX=two_pass, the fallback) are kept and tested.
+//      state and the first level's frontier.  The exact count-scan-fill two-pass
+//      layout over rounds 1-3's probe enumeration (truss_tri.h) is the fallback
+//      when the stream does not fit (option INDEX=two_pass forces it).
 //   3. peel: level-synchronous sub-rounds driven by the device control block
 //      (peel_dev.h).  A frontier edge walks its incidence slice; a triangle
 //      whose other two edges are both still present loses one support on each
@@ -36,7 +37,7 @@
 //      never touches the adjacency again.
 //   4. gather results into canonical (min,max)-lexicographic edge order with
 //      ORIGINAL vertex ids -- the identity the C ABI promises.  No search: the
-//      graph carries the internal edge id of every canonical edge.
+//      preparation carries the internal edge id of every canonical edge.
 #include "peel_dev.h"
 #include "truss_tail.h"
 #include "local_dev.h"
@@ -46,7 +47,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "truss_orient.h"
+#include "truss_line.h"
 #include "truss_tri.h"
 #include "truss_wedge.h"
 #include "truss_index.h"
@@ -274,69 +275,13 @@ struct TrussLocal {
 
 } // namespace
 
-int graph_moments(komb_ctx *ctx, const int32_t *deg, int64_t nv, const int32_t *osrc, const int32_t *ocol, int64_t m,
-                  const uint32_t *orow, int64_t out[5])
-{
-    unsigned long long *d_mom = nullptr, h[5] = {0, 0, 0, 0, 0};
-    DevBufs bufs(ctx);
-    KOMB_HIP(ctx, bufs.alloc(&d_mom, 5));
-    KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 5 * sizeof(unsigned long long), ctx->stream));
-    k_graph_moments<<<1024, kBlock, 0, ctx->stream>>>(deg, nv, osrc, ocol, m, orow, d_mom);
-    KOMB_HIP(ctx, d2h(ctx, h, d_mom, sizeof(h)));
-    for (int i = 0; i < 5; ++i) out[i] = (int64_t)h[i];
-    return KOMB_OK;
-}
-
-// the task table of the wedge enumeration for an oriented CSR (truss_wedge.h); *tasks is a pool block (bufs) or, with
-// resident = true, a hipMalloc'd array the caller keeps
-int build_tasks(komb_ctx *ctx, const uint32_t *orow, int64_t nv, bool resident, void **tasks, int64_t *ntasks)
-{
-    // light vertices per task: kWedgeV, fewer when that leaves the chip without enough tasks (>= 4 per resident wavefront)
-    const int group = (int)std::max<int64_t>(1, std::min<int64_t>(kWedgeV, nv / (256 * KOMB_WEDGE_EU * kTriWaves * 4)));
-    DevBufs bufs(ctx);
-    hipStream_t s = ctx->stream;
-    uint32_t *d_cnt = nullptr, *d_toff = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)nv + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)nv + 1));
-    k_task_count<<<grid_for(nv + 1), kBlock, 0, s>>>(orow, nv, group, d_cnt);
-    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_toff, nv + 1));
-    uint32_t n = 0;
-    KOMB_HIP(ctx, d2h(ctx, &n, d_toff + nv, sizeof(uint32_t)));
-    uint2 *d_t = nullptr;
-    if (resident) KOMB_HIP(ctx, hipMalloc((void **)&d_t, ((size_t)n + 1) * sizeof(uint2)));
-    else KOMB_HIP(ctx, ctx->pool.get((void **)&d_t, ((size_t)n + 1) * sizeof(uint2)));
-    if (nv > 0) k_task_fill<<<grid_for(nv), kBlock, 0, s>>>(orow, nv, group, d_toff, d_t);
-    KOMB_HIP(ctx, hipStreamSynchronize(s));                          // (d_toff goes back to the pool when this returns)
-    *tasks = d_t; *ntasks = (int64_t)n;
-    return KOMB_OK;
-}
-
-int own_bound(komb_ctx *ctx, const uint32_t *orow, int64_t nv, int64_t *out)
-{
-    unsigned long long *d_b = nullptr, h = 0;
-    DevBufs bufs(ctx);
-    KOMB_HIP(ctx, bufs.alloc(&d_b, 1));
-    KOMB_HIP(ctx, hipMemsetAsync(d_b, 0, sizeof(unsigned long long), ctx->stream));
-    k_own_bound<<<grid_for(nv), kBlock, 0, ctx->stream>>>(orow, nv, d_b);
-    KOMB_HIP(ctx, d2h(ctx, &h, d_b, sizeof(h)));
-    *out = (int64_t)h;
-    return KOMB_OK;
-}
-
-int vertex_lines(komb_ctx *ctx, const uint32_t *orow, const int32_t *ocol, int64_t nv, void *lines)
-{
-    if (nv > 0) k_vertex_lines<<<grid_for(nv), kBlock, 0, ctx->stream>>>(orow, ocol, nv, (uint4 *)lines);
-    KOMB_HIP(ctx, hipGetLastError());
-    return KOMB_OK;
-}
-
 void truss_free(komb_ctx *ctx)
 {
-    ctx->pool.put(ctx->d_t_eu);
-    ctx->pool.put(ctx->d_t_ev);
+    if (ctx->t_own_edges) { ctx->pool.put(ctx->d_t_eu); ctx->pool.put(ctx->d_t_ev); }
     ctx->pool.put(ctx->d_t_truss);
     ctx->pool.put(ctx->d_t_sup);
     ctx->d_t_eu = ctx->d_t_ev = ctx->d_t_truss = ctx->d_t_sup = nullptr;
+    ctx->t_own_edges = false;
     ctx->t_ne = -1; ctx->truss_done = false;
 }
 
@@ -348,85 +293,54 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_FAIL(ctx, KOMB_ERR_ARG, "komb_truss_run_sharded: bad rank %d / world %d / callback", rank, world);
     if (ctx->nv < 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_run: no graph loaded");
     truss_free(ctx);
-    const int64_t nv = ctx->nv;
     hipStream_t s = ctx->stream;
     komb_stats &st = ctx->stats;
     st.triangles = 0; st.truss_levels = st.truss_subrounds = st.truss_launches = 0;
     st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = st.ms_allreduce = st.ms_compact = 0.0;
-    st.truss_scans = 0;
-    if (nv == 0 || ctx->ne == 0) {
+    st.truss_scans = 0; st.ms_prepare = 0.0; st.truss_prepared = 0;
+    auto empty_result = [&]() -> int {
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, 4));
-        ctx->t_ne = 0; ctx->truss_done = true;
+        ctx->t_own_edges = true; ctx->t_ne = 0; ctx->truss_done = true;
         return KOMB_OK;
-    }
+    };
+    if (ctx->nv == 0 || ctx->ne == 0) return empty_result();
     Range r_all("komb_truss_run");
     DevBufs bufs(ctx);
-    const int gv = grid_for(nv);
 
-    // ---- a5 + orientation: the oriented CSR of the whole graph is resident (graph_build.hip: internal ids are (degree, id) ranks,
-    // so "lower -> higher (degree,id)" is the upper half of every row); a subgraph induced by vmask is an ordered filter of
-    // its slots.  The internal edge id is the oriented slot.
-    Range phase("truss: orientation");
-    const uint32_t *d_orow = ctx->d_orow;
-    const int32_t *d_ocol = ctx->d_ocol, *d_osrc = ctx->d_osrc;
-    int64_t m = ctx->ne;
-    const int32_t *d_deg = ctx->d_deg_i;                             // degrees in the (sub)graph, internal ids
-    uint8_t *d_mask_o = nullptr;                                     // vmask by original id (kept for the gather)
-    unsigned long long *d_obits = nullptr;                           // vmask: bit e = oriented slot e of the whole graph is kept
-    uint32_t *d_wrank = nullptr;                                     // ... and the kept slots before each 64-slot word
-    ctx->timer.start(s);
+    // ---- a5 + the k-truss side of the graph (truss_prep.hip).  The whole graph's is made on its first k-truss call and kept;
+    // a subgraph induced by vmask becomes a symmetric CSR of its own (new ids = ranks among the kept vertices: monotone, so
+    // its canonical edge order is the whole graph's restricted) and gets a temporary preparation like any graph's.
+    Range phase("truss: preparation");
+    InducedCsr sub;
+    TrussPrep sub_prep;
+    struct SubGuard { komb_ctx *c; InducedCsr *g; TrussPrep *p; ~SubGuard() { prep_free(c, p); induced_free(c, g); } } sub_guard{ctx, &sub, &sub_prep};
+    const TrussPrep *tp = &ctx->prep;
     if (vmask_host) {
-        uint8_t *d_mask_i = nullptr; uint32_t *d_rp = nullptr; int32_t *d_c = nullptr, *d_s = nullptr;
-        KOMB_HIP(ctx, bufs.alloc(&d_mask_o, (size_t)nv));
-        KOMB_HIP(ctx, bufs.alloc(&d_mask_i, (size_t)nv));
-        KOMB_HIP(ctx, bufs.alloc(&d_rp, (size_t)nv + 1));
-        KOMB_HIP(ctx, hipMemcpyAsync(d_mask_o, vmask_host, (size_t)nv, hipMemcpyHostToDevice, s));
-        k_mask_internal<<<gv, kBlock, 0, s>>>(d_mask_o, ctx->d_i2o, nv, d_mask_i);
-        int64_t m_sub = 0;
-        KOMB_TRY(compact_slots(ctx, bufs, ctx->d_osrc, ctx->d_ocol, m, nv, PredMask{d_mask_i}, d_rp, &d_c, &d_s, &m_sub, &d_obits, &d_wrank));
-        bufs.release(d_mask_i);
-        d_orow = d_rp; d_ocol = d_c; d_osrc = d_s; m = m_sub;
-        if (m_sub == 0) {
-            KOMB_HIP(ctx, hipStreamSynchronize(s));
-            KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
-            KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, 4));
-            ctx->t_ne = 0; ctx->truss_done = true;
-            return KOMB_OK;
-        }
-        int32_t *d_deg_sub = nullptr;
-        KOMB_HIP(ctx, bufs.alloc(&d_deg_sub, (size_t)nv));
-        KOMB_HIP(ctx, hipMemsetAsync(d_deg_sub, 0, (size_t)nv * sizeof(int32_t), s));
-        k_sub_degree<<<grid_for(m), kBlock, 0, s>>>(d_osrc, d_ocol, m, d_deg_sub);
-        d_deg = d_deg_sub;
+        ctx->timer.start(s);
+        KOMB_TRY(induce_csr(ctx, vmask_host, &sub));
+        st.ms_orient = ctx->timer.stop(s);
+        if (sub.ns == 0) return empty_result();
+        KOMB_TRY(prep_build(ctx, sub.rowptr, sub.col, sub.nv, sub.ns, &sub_prep));
+        st.ms_prepare = sub_prep.ms; st.truss_prepared = 1;
+        tp = &sub_prep;
+    } else if (!ctx->prep.valid) {
+        KOMB_TRY(prep_ensure(ctx));
+        st.ms_prepare = ctx->prep.ms; st.truss_prepared = 1;
     }
-    // the enumeration by wedges (truss_wedge.h; the default) reads one 64-byte line per target vertex: start and length of its
-    // oriented row, pivots and a signature of the row's elements.  The whole graph's lines come with the graph (graph_build.hip),
-    // a subgraph's are made here.  KOMB_ENUM=probe selects round 3's enumeration (truss_tri.h).
-    const bool wedge = !(getenv("KOMB_ENUM") && !strcmp(getenv("KOMB_ENUM"), "probe"));
-    const uint4 *d_line = ctx->d_vline;
-    if (wedge && vmask_host) {
-        uint4 *d_line_sub = nullptr;
-        KOMB_HIP(ctx, bufs.alloc(&d_line_sub, 4 * (size_t)nv));
-        k_vertex_lines<<<grid_for(nv), kBlock, 0, s>>>(d_orow, d_ocol, nv, d_line_sub);
-        d_line = d_line_sub;
-    }
-    // ... and its tasks (runs of light vertices, single heavy rows, parts of rows too long to stage: truss_wedge.h)
-    const uint2 *d_wtasks = (const uint2 *)ctx->d_wtasks;
-    int64_t n_wtasks = ctx->n_wtasks;
-    if (wedge && vmask_host) {
-        void *t = nullptr;
-        KOMB_TRY(build_tasks(ctx, d_orow, nv, false, &t, &n_wtasks));
-        bufs.owned.push_back(t);                                     // (a pool block: back to the pool with the rest)
-        d_wtasks = (const uint2 *)t;
-    }
+    const int64_t nv = tp->nv;
+    const int64_t m = tp->ne;
+    const uint32_t *d_orow = tp->orow;
+    const int32_t *d_ocol = tp->ocol, *d_osrc = tp->osrc;
+    const uint4 *d_line = tp->vline;
+    const uint2 *d_wtasks = (const uint2 *)tp->wtasks;
+    const int64_t n_wtasks = tp->n_wtasks;
     const int gw = grid_for(n_wtasks, kTriWaves);
-    st.ms_orient = ctx->timer.stop(s);
     phase.next("truss: triangles + incidence index");
 
     // ---- triangle support + incidence index
     const int ge = grid_for(m);
-    // vertices per enumeration task: kTriV, fewer when that leaves the chip without enough tasks (>= 4 per resident wavefront)
+    // vertices per task of the two-pass fallback's enumeration: kTriV, fewer when that leaves the chip without enough tasks (>= 4 per resident wavefront)
     const int tri_tv = (int)std::max<int64_t>(1, std::min<int64_t>(kTriV, nv / (256 * KOMB_TRI_EU * kTriWaves * 4)));
     const int64_t ntasks = (nv + tri_tv - 1) / tri_tv;
     const int gt = grid_for(ntasks, kTriWaves);
@@ -437,46 +351,39 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&d_cnt, (size_t)m + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_off2, (size_t)m + 4));
     unsigned long long *d_mom = nullptr;
-    KOMB_HIP(ctx, bufs.alloc(&d_mom, 12));                           // [0..4] graph moments, [5] sum of supports, [6,7] capacity bounds, [8] sharded-check mismatches
+    KOMB_HIP(ctx, bufs.alloc(&d_mom, 12));                           // [5] sum of supports, [8] sharded-check mismatches
     KOMB_HIP(ctx, hipMemsetAsync(d_mom, 0, 12 * sizeof(unsigned long long), s));
     st.ms_allreduce = 0.0;
 
-    // Three layouts of the index build:
-    //   stream   (default) ONE enumeration; own-role entries leave a task as dense blocks, everything else as records of one
-    //            stream that is then sorted by destination edge and merged with the blocks -- no atomic and no scattered
-    //            store per triangle, no slices sized by a bound.  KOMB_INDEX=stream.
-    //   slices   ONE enumeration into slices sized by the bound sup(a->b) <= d(a)-1 (~26 GB at |E|=100M), third-role
-    //            entries through one returning atomic + one scattered store each, then a compaction.  KOMB_INDEX=slices.
-    //   two_pass count, scan, second enumeration into exact slices: the fallback when the others do not fit in memory.
-    //            KOMB_INDEX=two_pass (or KOMB_TWO_PASS=1).
-    // A sharded run (world > 1) first counts the supports of its own source-vertex range and sums them over the ranks
+    // Two layouts of the index build:
+    //   stream   (default) ONE enumeration by wedges; own-role entries leave a task as dense blocks, everything else as records
+    //            of one stream that is then sorted by destination bin and merged with the blocks -- no atomic and no scattered
+    //            store per triangle, no slices sized by a bound.
+    //   two_pass count, scan, second enumeration into exact slices (the probe enumeration of truss_tri.h): the fallback when
+    //            the stream does not fit in memory or runs out; option INDEX=two_pass forces it.
+    // A sharded run (world > 1) first counts the supports of its own range of the task table and sums them over the ranks
     // (fn: the RCCL all-reduce), then builds the index whole with the layout above; the summed supports must equal the
     // supports the build finds.
     // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
-    const FinishMode fin = finish_mode(FIN_LOCAL);
+    const FinishMode fin = finish_mode(ctx, FIN_LOCAL);
     uint32_t tail_limit = 0;
     if (fin == FIN_LDS) {
         tail_limit = kTailEdges;
-        if (const char *tl = getenv("KOMB_TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
+        if (const char *tl = ctx_opt(ctx, "TAIL")) tail_limit = (uint32_t)strtoul(tl, nullptr, 10);
         if (tail_limit > kTailMaxEdges) tail_limit = kTailMaxEdges;
-    } else if (fin == FIN_LOCAL) tail_limit = local_limit((uint64_t)m, 32);
+    } else if (fin == FIN_LOCAL) tail_limit = local_limit(ctx, (uint64_t)m, 32);
     // (a graph small enough for the finish to take the whole peel is handed over before any step: no frontier may be queued)
     const bool whole_peel_finish = tail_limit && (uint64_t)m <= tail_limit;
-    // the peel sharded by edge range, one exchange per sub-round (shard_dev.h): komb_set_shard_peel, or KOMB_SHARD_PEEL=1 (with
-    // one rank: the same engine without a collective -- a test of its logic)
-    const bool shard_peel_on = (ctx->shard_peel && world > 1) || getenv("KOMB_SHARD_PEEL") != nullptr;
-    enum { IDX_STREAM = 0, IDX_SLICES = 1, IDX_TWO_PASS = 2 };
+    // the peel sharded by edge range, one exchange per sub-round (shard_dev.h): komb_set_shard_peel; option SHARD_ENGINE=1 runs
+    // the same engine with one rank and no collective -- a test of its logic
+    const bool shard_peel_on = (ctx->shard_peel && world > 1) || ctx_flag(ctx, "SHARD_ENGINE");
+    enum { IDX_STREAM = 0, IDX_TWO_PASS = 2 };
     int layout = IDX_STREAM;
-    if (const char *ix = getenv("KOMB_INDEX")) {
-        if (!strcmp(ix, "slices")) layout = IDX_SLICES;
-        else if (!strcmp(ix, "two_pass")) layout = IDX_TWO_PASS;
-        else if (strcmp(ix, "stream")) KOMB_FAIL(ctx, KOMB_ERR_ARG, "KOMB_INDEX=%s: expected stream, slices or two_pass", ix);
+    if (const char *ix = ctx_opt(ctx, "INDEX")) {
+        if (!strcmp(ix, "two_pass")) layout = IDX_TWO_PASS;
+        else if (strcmp(ix, "stream")) KOMB_FAIL(ctx, KOMB_ERR_ARG, "option INDEX=%s: expected stream or two_pass", ix);
     }
-    if (getenv("KOMB_TWO_PASS")) layout = IDX_TWO_PASS;
-    uint32_t *d_cap = nullptr, *d_offc = nullptr;
-    unsigned long long *d_offc64 = nullptr;    // the same offsets in 64 bits when the slices exceed 2^32 entries (KOMB_OFF64=1 forces them)
-    int2 *d_sparse = nullptr;
-    int2 *d_owndense = nullptr;                // own-role entries as compact per-task blocks (see k_triangles, DENSE)
+    int2 *d_owndense = nullptr;                // own-role entries as compact per-task blocks (truss_wedge.h)
     unsigned long long *d_ownoff = nullptr, *d_dcur = nullptr;
     uint32_t *d_cnt_ref = nullptr;             // world > 1: the all-reduced supports, kept to check the build against
     uint32_t *d_toff = nullptr;                // stream: first sorted record of every bin
@@ -496,18 +403,14 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     st.ms_sort = 0.0; st.tri_records = 0; st.ms_compact = 0.0; st.ms_tri_count = 0.0; st.ms_tri_fill = 0.0;
     st.index_layout = layout;
     auto zero_counts = [&]() -> hipError_t { return hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s); };
-    // (the stream build on one GPU never touches the third-role counters: half the fill)
-    // (the wedge enumeration writes own[] of every edge it owns, and the stream build never touches the third-role counters: no fill at all;
-    // round 3's kernel leaves the own[] of its unstaged rows to the fill)
-    if (world == 1 && layout == IDX_STREAM) { if (!wedge) KOMB_HIP(ctx, hipMemsetAsync(d_own, 0, ((size_t)m + 1) * sizeof(uint32_t), s)); }
-    else KOMB_HIP(ctx, zero_counts());
+    // (the wedge enumeration writes own[] of every edge it owns, and the stream build on one GPU never touches the third-role
+    // counters: no fill at all)
+    if (!(world == 1 && layout == IDX_STREAM)) KOMB_HIP(ctx, zero_counts());
     bool have_counts = false;                  // d_cnt holds the supports (and d_mom[5] their sum)
     if (world > 1) {
-        const int64_t nt = wedge ? n_wtasks : ntasks;
-        const int64_t task_lo = nt * rank / world, task_hi = nt * (rank + 1) / world;
+        const int64_t task_lo = n_wtasks * rank / world, task_hi = n_wtasks * (rank + 1) / world;
         ctx->timer.start(s);
-        if (wedge) k_wedges<TRI_COUNT><<<gw, kBlock, 0, s>>>(d_orow, d_ocol, d_line, d_wtasks, task_lo, task_hi, d_own, d_other, nullptr, nullptr, 0ull, nullptr, no_stream, nullptr, ablate);
-        else k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, task_lo, task_hi, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
+        k_wedges<TRI_COUNT><<<gw, kBlock, 0, s>>>(d_orow, d_ocol, d_line, d_wtasks, task_lo, task_hi, d_own, d_other, nullptr, nullptr, 0ull, nullptr, no_stream, nullptr, ablate);
         st.ms_tri_count = ctx->timer.stop(s);
         k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
         // sum the partial support vectors over the ranks (|E|+1 int32), then recompute the 64-bit total
@@ -529,21 +432,16 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     if (layout == IDX_STREAM) {
         // capacities: T <= sum_a C(d+(a), 2) triangles, at most three records each (a triangle of a task without a dense
         // block), plus what the chunked claims leave unused; with less memory than that, a stream that runs out falls back
-        // (sum over the vertices of d+ (d+ - 1): of the whole graph it comes with the graph, graph_build.hip)
-        unsigned long long bound = (unsigned long long)ctx->g_own_bound;
-        if (vmask_host) {
-            unsigned long long *d_bound = d_mom + 6;
-            k_own_bound<<<gv, kBlock, 0, s>>>(d_orow, nv, d_bound);
-            KOMB_HIP(ctx, d2h(ctx, &bound, d_bound, sizeof(bound)));
-        }
-        const int gts = std::min(gt, 256 * KOMB_TRI_EU);             // resident workgroups only: every wavefront ends with one partly used claim
-        const unsigned long long slack = (unsigned long long)gts * kTriWaves * kRecChunk + kRecChunk;
-        unsigned long long own_cap = bound + bound / 8 + (unsigned long long)gts * kTriWaves * kOwnChunk + kOwnChunk;
-        if (const char *oc = getenv("KOMB_OWN_DENSE_CAP")) own_cap = strtoull(oc, nullptr, 10) + 1;      // (tests: a region that runs out)
-        if (getenv("KOMB_NO_OWN_DENSE")) own_cap = 1;                // (tests: every entry a record)
+        // (sum over the vertices of d+ (d+ - 1): it comes with the preparation)
+        const unsigned long long bound = (unsigned long long)tp->own_bound;
+        const int gws = std::min(gw, 256 * KOMB_WEDGE_EU);           // resident workgroups only: every wavefront ends with one partly used claim
+        const unsigned long long slack = (unsigned long long)gws * kTriWaves * kRecChunk + kRecChunk;
+        unsigned long long own_cap = bound + bound / 8 + (unsigned long long)gws * kTriWaves * kOwnChunk + kOwnChunk;
+        if (const char *oc = ctx_opt(ctx, "OWN_DENSE_CAP")) own_cap = strtoull(oc, nullptr, 10) + 1;      // (tests: a region that runs out)
+        if (ctx_flag(ctx, "NO_OWN_DENSE")) own_cap = 1;              // (tests: every entry a record)
         unsigned long long t_bound = bound / 2;
         unsigned long long rec_cap = 3 * t_bound + (3 * t_bound) / 14 + slack;
-        if (const char *rc = getenv("KOMB_REC_CAP")) rec_cap = strtoull(rc, nullptr, 10) + 1;            // (tests: a stream that runs out)
+        if (const char *rc = ctx_opt(ctx, "REC_CAP")) rec_cap = strtoull(rc, nullptr, 10) + 1;            // (tests: a stream that runs out)
         // (what the pool holds unused counts as free: the choice must not depend on what an earlier call left cached)
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -558,31 +456,28 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                   bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess && bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess &&
                   bufs.alloc(&d_dcur, 4) == hipSuccess;
         // the wedge enumeration's wave-private record scratch (truss_wedge.h); without the memory for it a sub-range whose
-        // records outgrow the LDS buffer gives up its dense block, as in round 3
-        const int gws = std::min(gw, 256 * KOMB_WEDGE_EU);
+        // records outgrow the LDS buffer gives up its dense block
         uint2 *d_scratch = nullptr;
-        if (ok && wedge && !getenv("KOMB_NO_REC_SCRATCH") && bufs.alloc(&d_scratch, (size_t)gws * kTriWaves * kScratchRec) != hipSuccess) { (void)hipGetLastError(); d_scratch = nullptr; }
+        if (ok && !ctx_flag(ctx, "NO_REC_SCRATCH") && bufs.alloc(&d_scratch, (size_t)gws * kTriWaves * kScratchRec) != hipSuccess) { (void)hipGetLastError(); d_scratch = nullptr; }
         unsigned long long n_claimed = 0;
         if (ok) {
             KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 4 * sizeof(unsigned long long), s));
             const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel, geom.nb - 1u, kChunkBits};
             ctx->timer.start(s);
-            if (wedge) k_wedges<TRI_SINGLE><<<gws, kBlock, 0, s>>>(d_orow, d_ocol, d_line, d_wtasks, 0, n_wtasks, d_own, d_other, d_owndense, d_dcur, own_cap, d_ownoff, ts, d_scratch, ablate);
-            else k_triangles<TRI_SINGLE, uint32_t, false, true, true><<<gts, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr,
-                                                                                      d_owndense, d_dcur, own_cap, d_ownoff, ablate, ts, tri_tv);
+            k_wedges<TRI_SINGLE><<<gws, kBlock, 0, s>>>(d_orow, d_ocol, d_line, d_wtasks, 0, n_wtasks, d_own, d_other, d_owndense, d_dcur, own_cap, d_ownoff, ts, d_scratch, ablate);
             st.ms_tri_fill = ctx->timer.stop(s);
             unsigned long long dc[4] = {0, 0, 0, 0};
             KOMB_HIP(ctx, d2h(ctx, dc, d_dcur, sizeof(dc)));
             n_claimed = dc[2];
             bufs.release(d_scratch);
-            if (getenv("KOMB_TRI_DEBUG"))
+            if (ctx_flag(ctx, "TRI_DEBUG"))
                 fprintf(stderr, "komb triangles: stream build: %llu record positions claimed of %llu, dense own-role region %llu entries claimed of %llu, %llu task ranges overflowed their record buffer\n",
                         dc[2], rec_cap, dc[0], own_cap, dc[1]);
             if (n_claimed > rec_cap) ok = false;                     // the stream ran out: records were dropped
         } else (void)hipGetLastError();
         uint32_t *d_skey = nullptr;
         if (ok) {
-            // sort the records by destination edge
+            // sort the records by destination bin
             uint32_t *d_key2 = nullptr; unsigned long long *d_val2 = nullptr;
             ok = bufs.alloc(&d_key2, (size_t)n_claimed + 1) == hipSuccess && bufs.alloc(&d_val2, (size_t)n_claimed + 1) == hipSuccess;
             if (ok) {
@@ -598,7 +493,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 KOMB_HIP(ctx, bufs.alloc(&d_toff, (size_t)n_bins + 2));
                 KOMB_HIP(ctx, bufs.alloc(&d_bintot, (size_t)n_bins + 2));
                 KOMB_HIP(ctx, bufs.alloc(&d_grp, (size_t)kInitOff + 4));
-                if (!whole_peel_finish && !shard_peel_on && !getenv("KOMB_NO_FIRST_QUEUE")) KOMB_HIP(ctx, bufs.alloc(&d_light0, (size_t)m));
+                if (!whole_peel_finish && !shard_peel_on && !ctx_flag(ctx, "NO_FIRST_QUEUE")) KOMB_HIP(ctx, bufs.alloc(&d_light0, (size_t)m));
                 ctx->timer.start(s);
                 peel_ctrl_pre(s, d_grp);
                 KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
@@ -619,80 +514,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             layout = IDX_TWO_PASS;
         }
     }
-
-    if (layout == IDX_SLICES) {
-        // every edge gets a slice sized by the bound sup(a->b) <= d(a)-1; ~26 GB at |E|=100M, which the 288 GB of HBM afford
-        bool single = true;
-        KOMB_HIP(ctx, bufs.alloc(&d_cap, (size_t)m + 1));
-        KOMB_HIP(ctx, bufs.alloc(&d_offc, (size_t)m + 1));
-        KOMB_HIP(ctx, hipMemsetAsync(d_cap + m, 0, sizeof(uint32_t), s));
-        ctx->timer.start(s);
-        k_slice_caps<<<ge, kBlock, 0, s>>>(d_osrc, d_deg, d_orow, m, d_cap, d_mom + 6);
-        unsigned long long cap_both[2] = {0, 0};
-        KOMB_HIP(ctx, d2h(ctx, cap_both, d_mom + 6, sizeof(cap_both)));
-        const unsigned long long cap_total = cap_both[0];
-        // dense own-role region: the bound, + what the wavefronts' chunked claims can leave unused
-        unsigned long long own_cap = cap_both[1] + cap_both[1] / 8 + (unsigned long long)gt * kTriWaves * kOwnChunk + kOwnChunk;
-        if (const char *oc = getenv("KOMB_OWN_DENSE_CAP")) own_cap = strtoull(oc, nullptr, 10) + 1;      // (tests: a region that runs out)
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        if (cap_total * sizeof(int2) > (unsigned long long)(free_b * 0.8)) single = false;
-        const bool wide = cap_total > 0xFFFFFFF0ull || getenv("KOMB_OFF64") != nullptr;
-        if (single) {
-            if (wide) {
-                bufs.release(d_offc); d_offc = nullptr;
-                if (bufs.alloc(&d_offc64, (size_t)m + 1) != hipSuccess) { (void)hipGetLastError(); single = false; }
-                else KOMB_TRY(prim_exclusive_sum_u32_u64(ctx, d_cap, d_offc64, m + 1));
-            } else KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cap, d_offc, m + 1));
-            if (single && bufs.alloc(&d_sparse, (size_t)cap_total) != hipSuccess) { (void)hipGetLastError(); single = false; }
-            // the dense own-role region is an optimisation: without the memory for it the slices take those entries too
-            if (single && !getenv("KOMB_NO_OWN_DENSE")) {
-                (void)hipMemGetInfo(&free_b, &total_b);
-                if (own_cap * sizeof(int2) + (size_t)m * 8 < (unsigned long long)(free_b * 0.8) &&
-                    bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess && bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess &&
-                    bufs.alloc(&d_dcur, 2) == hipSuccess) {
-                    KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 2 * sizeof(unsigned long long), s));
-                } else {
-                    (void)hipGetLastError();
-                    bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
-                    d_owndense = nullptr; d_ownoff = nullptr; d_dcur = nullptr;
-                }
-            }
-        }
-        if (single) {
-            if (d_offc64) {
-                if (d_owndense) k_triangles<TRI_SINGLE, unsigned long long, false, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream, tri_tv);
-                else k_triangles<TRI_SINGLE, unsigned long long><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc64, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
-            } else {
-                k_back_cursors<<<ge, kBlock, 0, s>>>(d_offc, m, d_other);
-                if (d_owndense) k_triangles<TRI_SINGLE, uint32_t, true, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, d_owndense, d_dcur, own_cap, d_ownoff, ablate, no_stream, tri_tv);
-                else k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_offc, d_sparse, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
-            }
-            st.ms_tri_fill = ctx->timer.stop(s);
-            KOMB_HIP(ctx, hipMemsetAsync(d_mom + 5, 0, sizeof(unsigned long long), s));
-            k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, d_offc64 ? nullptr : d_offc, m + 1, d_cnt, d_mom + 5);
-        } else {
-            (void)ctx->timer.stop(s);
-            bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64); d_offc64 = nullptr;
-            bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur); d_owndense = nullptr; d_ownoff = nullptr; d_dcur = nullptr;
-            layout = IDX_TWO_PASS;
-        }
-    }
-#ifdef KOMB_TRI_PROFILE
-    if (layout != IDX_TWO_PASS) {
-        std::vector<unsigned long long> pr(2 * 16384);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_tri_prof), pr.size() * sizeof(unsigned long long));
-        unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> dur, endt;
-        const int nwv = gt * kTriWaves < 16384 ? gt * kTriWaves : 16384;
-        for (int i = 0; i < nwv; ++i) { if (pr[2 * i] < t0) t0 = pr[2 * i]; if (pr[2 * i + 1] > t1) t1 = pr[2 * i + 1]; }
-        for (int i = 0; i < nwv; ++i) { dur.push_back((pr[2 * i + 1] - pr[2 * i]) / 100.0); endt.push_back((pr[2 * i + 1] - t0) / 100.0); }
-        std::sort(dur.begin(), dur.end()); std::sort(endt.begin(), endt.end());
-        auto q = [&](std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-        fprintf(stderr, "komb tri profile: %d waves, span %.0f us; wave busy time us: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; end time us: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f\n",
-                nwv, (t1 - t0) / 100.0, dur.front(), q(dur, .1), q(dur, .5), q(dur, .9), q(dur, .99), dur.back(), q(endt, .1), q(endt, .5), q(endt, .9), q(endt, .99), endt.back());
-    }
-#endif
     if (layout != IDX_TWO_PASS && d_cnt_ref) {
         // sharded run: the supports summed over the ranks must be the supports the whole build has just found
         k_count_mismatch<<<ge, kBlock, 0, s>>>(d_cnt, d_cnt_ref, m + 1, d_mom + 8);
@@ -704,26 +525,15 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             k_total_u32<<<ge, kBlock, 0, s>>>(d_cnt, m + 1, d_mom + 5);
         } else if (!have_counts) {
             ctx->timer.start(s);
-            k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, (const uint32_t *)nullptr, nullptr, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
+            k_triangles<TRI_COUNT><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, nullptr, nullptr, ablate, tri_tv);
             st.ms_tri_count = ctx->timer.stop(s);
             k_sum_counts<<<ge, kBlock, 0, s>>>(d_own, d_other, nullptr, m + 1, d_cnt, d_mom + 5);
         }
     }
     st.index_layout = layout;
-    // graph statistics for the roofline model (sum d^2, sum min(d,d), max d, sum d+ + d+): properties of the graph, not
-    // results of the path -- the whole graph's come with the graph (graph_build.hip), a subgraph's are computed here
-    const bool want_moments = vmask_host != nullptr;
-    if (want_moments) k_graph_moments<<<1024, kBlock, 0, s>>>(d_deg, nv, d_osrc, d_ocol, m, d_orow, d_mom);
     {
         unsigned long long mom[9];
         KOMB_HIP(ctx, d2h(ctx, mom, d_mom, sizeof(mom)));
-        if (want_moments) {
-            st.sum_deg_sq = (int64_t)mom[0]; st.wedge_items = (int64_t)mom[1]; st.max_degree = (int32_t)mom[2];
-            st.oriented_items = (int64_t)mom[4];
-        } else {
-            st.sum_deg_sq = ctx->g_mom[0]; st.wedge_items = ctx->g_mom[1]; st.max_degree = (int32_t)ctx->g_mom[2];
-            st.oriented_items = ctx->g_mom[4];
-        }
         st.triangles = (int64_t)(mom[5] / 3);
         bufs.release(d_mom);
         if (mom[8] != 0)
@@ -739,7 +549,6 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     int32_t *d_sup = nullptr, *d_stamp = nullptr, *d_truss = nullptr;
     uint8_t *d_st8 = nullptr;                  // the stamps' one-byte shadow (peel_dev.h: state_of_round)
     bool peel_inited = false;                  // the stream layout's finish also writes the peel's initial state
-    const int gc = grid_for((m + kWave - 1) / kWave, kBlock / kWave);
     if (layout == IDX_STREAM) {
         // every bin's window of the index from the scan of the per-bin totals (the slice offsets themselves are a workgroup scan inside k_bin_finish)
         KOMB_TRY(prim_exclusive_sum_u32(ctx, d_bintot, d_bintot, n_bins + 1));
@@ -757,32 +566,17 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         bufs.release(d_toff); bufs.release(d_bintot); bufs.release((void *)d_recval); bufs.release(d_reckey);
         bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
     } else {
-        // (bounded slices, exact two-pass: the slices follow each other in edge order; the pairs are made with the peel's initial state)
+        // exact two-pass: the slices follow each other in edge order; the (start, length) pairs are made with the peel's initial
+        // state; second enumeration, into the EXACT slices: own-role entries from the front and third-role entries from the
+        // back meet precisely -- no compaction
         KOMB_HIP(ctx, bufs.alloc(&d_off, (size_t)m + 1));
         KOMB_TRY(prim_exclusive_sum_u32(ctx, d_cnt, d_off, m + 1));
         KOMB_HIP(ctx, d2h(ctx, &total, d_off + m, sizeof(uint32_t)));
         KOMB_HIP(ctx, bufs.alloc(&d_inc, (size_t)total));
-    }
-    if (layout == IDX_SLICES) {
-        ctx->timer.start(s);
-        if (d_offc64) k_compact_inc<unsigned long long><<<gc, kBlock, 0, s>>>(d_offc64, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
-        else k_compact_inc<uint32_t><<<gc, kBlock, 0, s>>>(d_offc, d_own, d_off, d_sparse, d_owndense, d_ownoff, d_inc, m);
-        st.ms_compact = ctx->timer.stop(s);
-        if (d_dcur && getenv("KOMB_TRI_DEBUG")) {
-            unsigned long long dc[2] = {0, 0};
-            KOMB_HIP(ctx, d2h(ctx, dc, d_dcur, sizeof(dc)));
-            fprintf(stderr, "komb triangles: dense own-role region: %llu entries claimed (%llu would be exact for all), %llu task ranges overflowed their record buffer\n",
-                    dc[0], 2ull * (unsigned long long)total / 3ull, dc[1]);
-        }
-        bufs.release(d_sparse); bufs.release(d_cap); bufs.release(d_offc); bufs.release(d_offc64);
-        bufs.release(d_owndense); bufs.release(d_ownoff); bufs.release(d_dcur);
-    } else if (layout == IDX_TWO_PASS) {
-        // second enumeration, same writer as the single-pass layouts but into the EXACT slices: own-role
-        // entries from the front and third-role entries from the back meet precisely -- no compaction
         ctx->timer.start(s);
         KOMB_HIP(ctx, zero_counts());
         k_back_cursors<<<ge, kBlock, 0, s>>>(d_off, m, d_other);
-        k_triangles<TRI_SINGLE, uint32_t, true><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, nullptr, nullptr, 0ull, nullptr, ablate, no_stream, tri_tv);
+        k_triangles<TRI_SINGLE><<<gt, kBlock, 0, s>>>(d_orow, d_ocol, nv, 0, ntasks, d_own, d_other, d_off, d_inc, ablate, tri_tv);
         st.ms_tri_fill = ctx->timer.stop(s);
     }
     st.ms_support = st.ms_tri_count + st.ms_tri_fill + st.ms_sort + st.ms_compact;
@@ -791,7 +585,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // ---- peel
     phase.next("truss: peel");
     PeelCtrl *d_ctrl = nullptr;
-    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, scan_scalar_switch()};
+    PeelQueues Q{nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, 0};
     const size_t heavy_cap = (size_t)total / 32 + 64;             // see kcore.hip
     if (!peel_inited) {
         KOMB_HIP(ctx, bufs.alloc(&d_sup, (size_t)m));
@@ -814,7 +608,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     KOMB_HIP(ctx, bufs.alloc(&Q.rlevel, (size_t)m + 2));
     KOMB_HIP(ctx, hipMemsetAsync(Q.rlevel, 0, 2 * sizeof(int32_t), s));
     int32_t retire_every = kRetireEvery;
-    if (const char *e = getenv("KOMB_RETIRE_EVERY")) retire_every = std::max(1, std::min((int)kRetireEvery, atoi(e)));   // (tests: RETIRE steps on small graphs)
+    if (const char *e = ctx_opt(ctx, "RETIRE_EVERY")) retire_every = std::max(1, std::min((int)kRetireEvery, atoi(e)));   // (tests: RETIRE steps on small graphs)
 #ifdef KOMB_DEBUG_SWITCHES
     TrussProblem P{(uint32_t)m, d_off2, d_inc, d_sup, d_stamp, d_st8, retire_every, getenv("KOMB_PEEL_ABLATE") ? atoi(getenv("KOMB_PEEL_ABLATE")) : 0};
 #else
@@ -844,7 +638,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         const int g = grid_for(n_in, kBlock, 256);
         // KOMB_TAIL_DEBUG=1: one line per hand-over on stderr (HIP-event times; building with -DKOMB_TAIL_TIMERS
         // adds the kernel's own per-phase stopwatch)
-        const bool dbg = getenv("KOMB_TAIL_DEBUG") != nullptr;
+        const bool dbg = ctx_flag(ctx, "TAIL_DEBUG");
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
         for (auto &e : ev) (void)hipEventCreate(&e);
         (void)hipEventRecord(ev[0], s);
@@ -882,7 +676,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         (void)hipEventRecord(ev[0], s);
         LocalStats ls;
         const int lrc = local_finish(ctx, bufs, hc, d_ctrl, (uint32_t)m, d_stamp, d_sup, Q.live[hc.live_sel],
-            (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), local_item_limit(kTrussLocalItems), local_density_limit(kTrussLocalDensity), true, 2, d_truss,
+            (uint32_t)kWave * TrussLocal::kU, sizeof(uint2), local_item_limit(ctx, kTrussLocalItems), local_density_limit(ctx, kTrussLocalDensity), true, 2, d_truss,
             [&](const LocalGraph &lg, const int32_t *num, void *items, PeelCtrl *d_cctrl, int32_t launch) {
                 TrussCollect C{(uint32_t)m, d_off2, d_inc, d_stamp, num, lg.off, lg.cur, (uint2 *)items};
                 PeelQueues Qc = Q;
@@ -965,6 +759,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     }
 #endif
     if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss peel ended in an inconsistent state");
+    st.engine_flags = (layout == IDX_TWO_PASS ? KOMB_ENGINE_TWO_PASS : 0) | (shard_peel_on ? KOMB_ENGINE_SHARD_PEEL : 0) |
+                      (st.truss_local_units ? KOMB_ENGINE_LOCAL_FINISH : 0) | (st.truss_tail_runs ? KOMB_ENGINE_LDS_TAIL : 0);
     st.truss_levels = ctx->h_ctrl[0].n_levels;
     st.truss_subrounds = ctx->h_ctrl[0].n_rounds;
     st.truss_launches = launches;
@@ -974,21 +770,22 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     bufs.release(Q.code);
     bufs.release(d_sup); bufs.release(d_inc);
 
-    // ---- canonical-order results with original vertex ids: the graph carries its canonical edge list and the internal edge
-    // id of every canonical edge (graph_build.hip), so the whole-graph gather is one pass; a subgraph's results are the
-    // kept canonical edges in order, each reading its kept oriented slot's values
+    // ---- canonical-order results with original vertex ids: the preparation carries the canonical edge list and the internal
+    // edge id of every canonical edge (truss_prep.hip), so the gather is one pass.  An induced subgraph's canonical order is the
+    // whole graph's restricted to it (its ids are monotone): the same pass, and its endpoints mapped back to the original ids.
     phase.next("truss: canonical gather");
     ctx->timer.start(s);
     // the peeled edges' trussness from their sub-round stamps, packed with the initial support (one coalesced pass; see Q.rlevel above)
     int2 *d_res = nullptr;                                           // (trussness, initial support) by internal edge id
     KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
     k_truss_resolve<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, d_off2, d_res, m);
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+    uint32_t k_lo = 0, k_hi = (uint32_t)m;
     if (!vmask_host) {
-        ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;          // (not pool blocks: truss_free's put() ignores them)
-        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
-        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+        ctx->d_t_eu = tp->ceu; ctx->d_t_ev = tp->cev;                // (the preparation's arrays: they stay with the graph)
+        ctx->t_own_edges = false;
         // (komb_truss_run_slice: this rank's slice of the canonical edges only, zeros elsewhere)
-        uint32_t k_lo = 0, k_hi = (uint32_t)m;
         if (ctx->slice_world > 1) {
             shard_bounds((uint64_t)m, ctx->slice_rank, ctx->slice_world, &k_lo, &k_hi);
             for (int32_t *out : {ctx->d_t_truss, ctx->d_t_sup}) {
@@ -996,26 +793,20 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
                 if (k_hi < (uint32_t)m) KOMB_HIP(ctx, hipMemsetAsync(out + k_hi, 0, ((size_t)m - k_hi) * sizeof(int32_t), s));
             }
         }
-        if (k_hi > k_lo) k_gather_canonical<<<grid_for((int64_t)k_hi - k_lo), kBlock, 0, s>>>(ctx->d_canon2e, (int64_t)k_lo, (int64_t)k_hi, d_res, ctx->d_t_truss, ctx->d_t_sup);
     } else {
-        uint32_t *d_junk_rp = nullptr; int32_t *d_eu = nullptr, *d_ev = nullptr;
-        unsigned long long *d_kbits = nullptr; uint32_t *d_krank = nullptr;
-        int64_t n_sub = 0;
-        KOMB_HIP(ctx, bufs.alloc(&d_junk_rp, (size_t)nv + 1));
-        KOMB_TRY(compact_slots(ctx, bufs, ctx->d_ceu, ctx->d_cev, ctx->ne, nv, PredMask{d_mask_o}, d_junk_rp, &d_ev, &d_eu, &n_sub, &d_kbits, &d_krank));
-        if (n_sub != m) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss gather: %lld canonical edges kept, %lld oriented slots", (long long)n_sub, (long long)m);
-        bufs.detach(d_eu); bufs.detach(d_ev);                        // they stay with the context until the next run
-        ctx->d_t_eu = d_eu; ctx->d_t_ev = d_ev;
-        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
-        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-        k_gather_sub<<<grid_for(ctx->ne), kBlock, 0, s>>>(ctx->d_canon2e, ctx->ne, d_kbits, d_krank, d_obits, d_wrank, d_res, ctx->d_t_truss, ctx->d_t_sup);
+        ctx->t_own_edges = true;
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
+        KOMB_TRY(map_edges(ctx, sub.vold, tp->ceu, tp->cev, m, ctx->d_t_eu, ctx->d_t_ev));
     }
+    if (k_hi > k_lo) k_gather_canonical<<<grid_for((int64_t)k_hi - k_lo), kBlock, 0, s>>>(tp->canon2e, (int64_t)k_lo, (int64_t)k_hi, d_res, ctx->d_t_truss, ctx->d_t_sup);
     st.ms_gather = ctx->timer.stop(s);
-    if (getenv("KOMB_POOL_DEBUG")) {
+    if (ctx_flag(ctx, "POOL_DEBUG")) {
         size_t held = 0;
         for (const auto &b : ctx->pool.blocks) held += b.bytes;
         fprintf(stderr, "komb pool: %zu blocks, %.2f GB held, %zu hipMalloc calls so far (%.1f ms inside them), %zu trims\n", ctx->pool.blocks.size(), held / 1e9, ctx->pool.n_malloc, ctx->pool.ms_malloc, ctx->pool.n_trim);
     }
+    if (vmask_host) KOMB_HIP(ctx, hipStreamSynchronize(s));         // (the subgraph's arrays go back to the pool on return)
     ctx->t_ne = m;
     ctx->truss_done = true;
     return KOMB_OK;

@@ -802,13 +802,13 @@ int local_fixpoint(komb_ctx *ctx, LocalCtrl *d_ctrl, uint32_t *d_cnt, const Loca
     int launches = 0, slot = 0, status = KOMB_OK;
     bool have_prev = false, finished = false, stuck = false;
     int32_t k = 0, seen_iters = -1;
-    // KOMB_LOCAL_DEBUG=2: an event after every launch, the per-sweep times on stderr
+    // option LOCAL_DEBUG=2: an event after every launch, the per-sweep times on stderr
     // notifications are skipped (and the next sweep is full) while a sweep changes at least an eighth of the units (measured at C3: n/2 .. n/16 within 4%, never = +20%)
     uint32_t full_thr = g.n / 8u + 1u;
 #ifdef KOMB_DEBUG_SWITCHES
     if (const char *e = getenv("KOMB_LOCAL_FULL")) { const long d = atol(e); full_thr = d > 0 ? g.n / (uint32_t)d + 1u : 0xFFFFFFFFu; }   // n / d; 0 = never
 #endif
-    const char *dbg_env = getenv("KOMB_LOCAL_DEBUG");
+    const char *dbg_env = ctx_opt(ctx, "LOCAL_DEBUG");
     const bool per_sweep = dbg_env && atoi(dbg_env) >= 2;
     std::vector<hipEvent_t> sw;
     if (per_sweep) { sw.resize(1); if (evs.make(&sw[0]) == hipSuccess) (void)hipEventRecord(sw[0], s); }
@@ -881,8 +881,8 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     hipStream_t s = ctx->stream;
     const uint32_t n = hc.remaining;
     if (n == 0) KOMB_FAIL(ctx, KOMB_ERR_STATE, "local finish: nothing left to hand over");
-    // KOMB_LOCAL_DEBUG=1: one stderr line per hand-over with the phase times (HIP events)
-    const bool dbg = getenv("KOMB_LOCAL_DEBUG") != nullptr;
+    // option LOCAL_DEBUG=1: one stderr line per hand-over with the phase times (HIP events)
+    const bool dbg = ctx_opt(ctx, "LOCAL_DEBUG") != nullptr;
     EventSet evs;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (dbg) for (auto &e : ev) (void)evs.make(&e);
@@ -972,7 +972,7 @@ int local_finish(komb_ctx *ctx, DevBufs &bufs, const PeelCtrl &hc, PeelCtrl *d_c
     // groups have a single marked unit); the notification kernel pays where hubs are many (k-core at C3: 235 of them in
     // ~600 chunks, -0.13 ms; 3 x C3: -2.4 ms) and costs 0.2-0.4 ms where they are few (C2, k-truss).
     uint32_t defer_chunks = kLocDeferChunks;
-    if (const char *e = getenv("KOMB_LOCAL_DEFER_CHUNKS")) defer_chunks = (uint32_t)strtoul(e, nullptr, 10);     // (no result depends on it)
+    if (const char *e = ctx_opt(ctx, "LOCAL_DEFER_CHUNKS")) defer_chunks = (uint32_t)strtoul(e, nullptr, 10);     // (no result depends on it)
     g.flags = (use_list ? kLocUseList : 0u) | (g.nchunk >= defer_chunks && g.nchunk > 0 ? kLocDeferNotify : 0u);
 #ifdef KOMB_DEBUG_SWITCHES
     if (const char *e = getenv("KOMB_LOCAL_MODE")) g.flags = (uint32_t)atoi(e);      // 1 = list, 2 = notification kernel

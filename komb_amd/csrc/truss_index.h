@@ -64,18 +64,6 @@ __global__ __launch_bounds__(kBlock) void k_bin_offsets(const uint32_t *__restri
     }
 }
 
-// sum over the vertices of d+(a) (d+(a) - 1): bound on the own-role entries (every edge a->x closes at most d+(a) - 1
-// triangles with the other out-neighbours of a); half of it bounds the triangles
-__global__ __launch_bounds__(kBlock) void k_own_bound(const uint32_t *__restrict__ orow, int64_t nv, unsigned long long *__restrict__ total)
-{
-    unsigned long long t = 0;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
-        const unsigned long long d = orow[v + 1] - orow[v];
-        t += d ? d * (d - 1ull) : 0ull;
-    }
-    block_add_u64(t, total);
-}
-
 __global__ __launch_bounds__(kBlock) void k_count_mismatch(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int64_t n,
                                                            unsigned long long *__restrict__ bad)
 {

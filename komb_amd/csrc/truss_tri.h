@@ -1,10 +1,11 @@
-// truss_tri.h -- step 2a of the k-truss path (ktruss.hip): the triangle enumeration k_triangles (igraph_trussness's
-// igraph_list_triangles + per-edge support count, reference src/graph.cpp:508) in its count / fill / record-
-// stream modes, and the helpers of round 2's index layouts (bounded slices + k_compact_inc, exact two-pass).
-// Included by ktruss.hip only.
+// truss_tri.h -- the probe enumeration of rounds 1-3 (igraph_trussness's igraph_list_triangles + per-edge support count,
+// reference src/graph.cpp:508), kept for the exact count-scan-fill TWO-PASS build of the incidence index:
+// the fallback of ktruss.hip when the record stream of the wedge enumeration (truss_wedge.h) does not fit in memory or
+// runs out, and a second, independent enumeration the tests cross-check the first against.  Also the definitions the two
+// enumerations share (record stream, dense own-role blocks).  Included by ktruss.hip only.
 #pragma once
 
-#include "peel_dev.h"
+#include "truss_line.h"
 
 namespace komb {
 
@@ -28,17 +29,12 @@ namespace {
 // global atomic.  Hits are rare (~4% of the probes): they are parked in an LDS
 // buffer and handled densely, 64 triangles at a time.
 //   TRI_COUNT  counts supports (own[] by plain stores, other[] by atomics).
-//   TRI_SINGLE writes each edge's incidence pairs into its slice
-//              [off[x], off[x+1]): own-role entries from the front (LDS
-//              cursor), third-role entries from the back (global counter).  The
-//              slices are either capacity-bounded (no counting pass at all;
-//              k_compact_inc then packs them) or exact (after TRI_COUNT + scan:
-//              the two ends meet precisely).
+//   TRI_SINGLE writes each edge's incidence pairs into its EXACT slice
+//              [off[x], off[x+1]) (after TRI_COUNT + scan): own-role entries
+//              from the front (LDS cursor), third-role entries from the back
+//              (a global cursor counted down): the two ends meet precisely.
 // Tasks whose rows exceed the LDS budget fall back to global binary search and
 // global atomics for all three roles.
-#ifndef KOMB_TRI_CAP
-#define KOMB_TRI_CAP 256
-#endif
 #ifndef KOMB_TRI_EU
 #define KOMB_TRI_EU 4
 #endif
@@ -49,21 +45,17 @@ namespace {
 #define KOMB_TRI_V 16
 #endif
 constexpr int kTriV = KOMB_TRI_V;               // consecutive source vertices per task (<= 63: lane l holds orow[v0 + l])
-constexpr int kTriCap = KOMB_TRI_CAP;
 #ifndef KOMB_TRI_R
 #define KOMB_TRI_R 4
 #endif
 constexpr int kTriR = KOMB_TRI_R;              // consecutive elements of one row N+(b) a lane probes per trip (16-byte loads; 4 or 8)
 static_assert(kTriR == 4 || kTriR == 8, "chunks are loaded as 16-byte vectors");
-struct __attribute__((packed, aligned(4))) Int4U { int32_t x, y, z, w; };      // 16 bytes at a 4-byte aligned address
-struct __attribute__((packed, aligned(4))) UInt2U { uint32_t x, y; };
 constexpr int kTriBuf = 128;                   // parked triangles per wave on the unstaged path (handled once >= 64 are waiting)
 #ifndef KOMB_TRI_REC
 #define KOMB_TRI_REC 384
 #endif
 constexpr int kTriRec = KOMB_TRI_REC;           // triangle records a staged task keeps until it is done (own-role entries, 8 bytes each)
 constexpr int kTriCand = KOMB_TRI_CAND;        // parked lookup candidates per wave (searched once >= 64 are waiting)
-constexpr int kTriWaves = kBlock / kWave;
 #ifndef KOMB_TRI_SIGW
 #define KOMB_TRI_SIGW 8
 #endif
@@ -72,30 +64,21 @@ constexpr int kTriSigShift = 32 - 5 - (kTriSigW == 2 ? 1 : kTriSigW == 4 ? 2 : k
 
 enum : int { TRI_COUNT = 0, TRI_SINGLE = 2 };
 
-#ifdef KOMB_TRI_PROFILE
-// debug: when every wavefront of the enumeration started and ended (100 MHz clock), to see its tail
-__device__ unsigned long long g_tri_prof[2 * 16384];
-#endif
-
-// BACK: other_or_cursor[x] starts at off[x+1]-1, the last position of x's slice, and is counted DOWN: the
-// returning atomic is the third-role write position itself (no load of off[x+1] from a second random line)
-// DENSE (TRI_SINGLE over capacity-bounded slices): the own-role entries do not go to the slices at all.  A staged
-// task keeps one 8-byte record per triangle in LDS and, when it is done, writes the own-role entries of all its edges
-// as ONE compact block of `dense` (claimed from `dense_cursor` in chunks, see below), edge after edge:
-// ownoff[e] = where edge e's entries start.  176 M scattered 8-byte stores (one HBM line each) become a coalesced
-// stream.  A task with more triangles than the record buffer holds, and a row too long to stage, fall back to the
-// slices (ownoff[e] = kOwnSpill); k_compact_inc reads either.
+// ---- shared with the wedge enumeration (truss_wedge.h)
+// DENSE own-role blocks: a staged task keeps one 8-byte record per triangle in LDS and, when it is done, writes the own-role
+// entries of all its edges as ONE compact block of `dense` (claimed from a cursor in chunks), edge after edge: ownoff[e] =
+// where edge e's entries start.  176 M scattered 8-byte stores (one HBM line each) become a coalesced stream.  A task
+// without a block (a row too long to stage, a region that has run out) says ownoff[e] = kOwnSpill: its entries are records.
 constexpr unsigned long long kOwnSpill = ~0ull;
 constexpr uint32_t kOwnChunk = 4096;                // entries a wavefront claims from dense_cursor at a time (one atomic per ~15 tasks)
 
-// STREAM (TRI_SINGLE, with DENSE): no slices at all.  Every incidence entry that does not go into a dense own-role block
-// -- the third-role entry of every triangle, and all three entries of a triangle whose task has no block (a spilled or
-// unstaged sub-range, a region that has run out) -- is appended as a record (key = the edge the entry belongs to, value =
-// the other two edges) to ONE stream, 64 records per store instruction, no atomic and no scattered store per triangle.
-// A wavefront claims kRecChunk positions of the stream at a time; what it leaves unused gets a sentinel key (larger
-// than every edge id).  The host then sorts the records by key (the destination-binned build of the index: DESIGN.md
-// section 4.2) and merges them with the dense blocks.  A claim beyond `cap` writes nothing: the host sees the cursor
-// pass the capacity and falls back to the exact two-pass build.
+// STREAM: every incidence entry that does not go into a dense own-role block -- the third-role entry of every triangle, and
+// all three entries of a triangle whose task has no block -- is appended as a record (key = the edge the entry belongs to,
+// value = the other two edges) to ONE stream, 64 records per store instruction, no atomic and no scattered store per
+// triangle.  A wavefront claims kRecChunk positions of the stream at a time; what it leaves unused gets a sentinel key
+// (larger than every edge id).  The host then sorts the records by bin (truss_index.h) and merges them with the dense
+// blocks.  A claim beyond `cap` writes nothing: the host sees the cursor pass the capacity and falls back to the exact
+// two-pass build.
 constexpr uint32_t kRecChunk = 1024;
 struct TriStream {
     uint32_t *key;                       // [cap]
@@ -107,17 +90,17 @@ struct TriStream {
     int spread_shift;
 };
 
-template <int MODE, class OffT = uint32_t, bool BACK = false, bool DENSE = false, bool STREAM = false>     // OffT: 64-bit when the bounded slices exceed 2^32 entries
+template <int MODE>
 __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                       int64_t nv, int64_t task_lo, int64_t task_hi,
                                                       uint32_t *own, uint32_t *other_or_cursor,
-                                                      const OffT *__restrict__ off, int2 *__restrict__ inc,
-                                                      int2 *__restrict__ dense, unsigned long long *dense_cursor, unsigned long long dense_cap,
-                                                      unsigned long long *__restrict__ ownoff, int ablate, TriStream ts, int tv)
+                                                      const uint32_t *__restrict__ off, int2 *__restrict__ inc, int ablate, int tv)
 {
+    // other_or_cursor: TRI_COUNT: the third-role counters; TRI_SINGLE: every edge's back cursor, which starts at off[x+1]-1,
+    // the last position of x's slice, and is counted DOWN (k_back_cursors): the returning atomic is the third-role write
+    // position itself
     // tv: consecutive source vertices per task (<= kTriV).  Fewer than kTriV when the graph has few vertices for its work
     // (a 20 000-vertex graph with 4 M edges is 1 250 tasks of 16 vertices: not even one per SIMD)
-    static_assert(!STREAM || (MODE == TRI_SINGLE && DENSE), "the record stream replaces the slices of the single pass");
     // ablate (debug, KOMB_TRI_ABLATE): 1 = no gather of w, 2 = no row lookup, 4 = no stores/atomics, 8 = no probes at all,
     // 16 = no own-role stores, 32 = no third-role atomic + store
     static_assert(kTriCap <= 256, "edge indices and cursors of a staged task are kept in 8 bits");
@@ -146,32 +129,6 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
     uint8_t *s_rid = sh_rid[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
-    unsigned long long chunk_pos = 0, chunk_end = 0;             // this wavefront's claim on `dense` (wave-uniform)
-    unsigned long long rec_pos = 0, rec_end = 0;                 // this wavefront's claim on the record stream (wave-uniform)
-    // all 64 lanes call: the lanes with `has` append (key, val) at consecutive positions of the wavefront's claim
-    auto rec_append = [&](bool has, uint32_t key, int2 val) {
-        const uint64_t m = __ballot(has);
-        if (!m) return;
-        const uint32_t c = (uint32_t)__popcll(m);
-        const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
-        const uint32_t left = (uint32_t)min((unsigned long long)c, rec_end - rec_pos);    // (wave-uniform) positions left in the current claim
-        unsigned long long q = rec_pos + rank;
-        if (left < c) {                                          // the claim runs out inside this append: the rest goes to a new one
-            unsigned long long got = 0;
-            if (lane == 0) got = atomicAdd(ts.cursor, (unsigned long long)kRecChunk);
-            const uint32_t glo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
-            const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
-            const unsigned long long fresh = ((unsigned long long)ghi << 32) | glo;
-            if (rank >= left) q = fresh + (rank - left);
-            rec_pos = fresh + (c - left);
-            rec_end = fresh + kRecChunk;
-        } else rec_pos += c;
-        if (has && q < ts.cap) { ts.key[q] = key; ts.val[q] = val; }
-    };
-
-#ifdef KOMB_TRI_PROFILE
-    if (lane == 0 && gw < 16384) g_tri_prof[2 * gw] = wall_clock64();
-#endif
     for (int64_t task = task_lo + gw; task < task_hi; task += nw) {
       const int64_t v0t = task * tv;
       const int nvt_all = (int)min((int64_t)tv, nv - v0t);
@@ -228,22 +185,14 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                     const uint32_t e = S0 + tr.x, i = S0 + tr.y, jj = tr.z;
                     if (MODE == TRI_COUNT) {
                         atomicAdd(&other_or_cursor[e], 1u); atomicAdd(&other_or_cursor[i], 1u); atomicAdd(&other_or_cursor[jj], 1u);
-                    } else if (!STREAM) {
-                        const OffT pe = off[e] + atomicAdd(&own[e], 1u);
-                        const OffT pi = off[i] + atomicAdd(&own[i], 1u);
-                        const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
+                    } else {
+                        const uint32_t pe = off[e] + atomicAdd(&own[e], 1u);
+                        const uint32_t pi = off[i] + atomicAdd(&own[i], 1u);
+                        const uint32_t pj = atomicSub(&other_or_cursor[jj], 1u);
                         inc[pe] = make_int2((int)i, (int)jj);
                         inc[pi] = make_int2((int)e, (int)jj);
                         inc[pj] = make_int2((int)e, (int)i);
                     }
-                }
-                if (STREAM) {                                    // all three entries of these triangles are records
-                    const bool has = x < n_tri;
-                    const uint3 tr = has ? s_tri[x] : make_uint3(0u, 0u, 0u);
-                    const uint32_t e = S0 + tr.x, i = S0 + tr.y, jj = tr.z;
-                    rec_append(has, e, make_int2((int)i, (int)jj));
-                    rec_append(has, i, make_int2((int)e, (int)jj));
-                    rec_append(has, jj, make_int2((int)e, (int)i));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -252,40 +201,25 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
 
         // ---- staged sub-range.  A triangle's own-role cursors are LDS atomics taken when it is found; the rest waits in
         // the record buffer: record = (e_rel | i_rel << 8 | cursor_e << 16 | cursor_i << 24, j).  The records are worked off
-        // densely, 64 per pass (`drain`): the third-role entry (one returning global atomic + one store) and -- when the
-        // own-role entries go to the slices (exact slices, or a DENSE sub-range that has spilled) -- the two own-role stores.
-        // A DENSE sub-range keeps its records until it is done.
-        uint32_t n_rec = 0, n_done = 0;                         // wave-uniform: records, records whose third role is written
-        bool spilled = !DENSE;                                  // wave-uniform: own-role entries go to inc[off[edge] + cursor]
-        auto drain = [&](uint32_t lo, uint32_t hi, bool third, bool own_role) {
+        // densely, 64 per pass (`drain`): the third-role entry (one returning global atomic + one store) and the two
+        // own-role stores.
+        uint32_t n_rec = 0;                                     // wave-uniform: records waiting
+        auto drain = [&]() {
             __builtin_amdgcn_wave_barrier();
-            if (MODE == TRI_SINGLE && STREAM) for (uint32_t b0 = lo; b0 < hi; b0 += kWave) {
+            if (MODE == TRI_SINGLE) for (uint32_t b0 = 0; b0 < n_rec; b0 += kWave) {
                 const uint32_t x = b0 + (uint32_t)lane;
-                const bool has = x < hi;
-                const uint2 rc = has ? s_rec[x] : make_uint2(0u, 0u);
-                const uint32_t e = S0 + (rc.x & 0xFFu), i = S0 + ((rc.x >> 8) & 0xFFu), jj = rc.y;
-                if (third && !(ablate & 32)) rec_append(has, jj, make_int2((int)e, (int)i));
-                if (own_role && !(ablate & 16)) {
-                    rec_append(has, e, make_int2((int)i, (int)jj));
-                    rec_append(has, i, make_int2((int)e, (int)jj));
-                }
-            }
-            if (MODE == TRI_SINGLE && !STREAM) for (uint32_t b0 = lo; b0 < hi; b0 += kWave) {
-                const uint32_t x = b0 + (uint32_t)lane;
-                if (x < hi) {
+                if (x < n_rec) {
                     const uint2 rc = s_rec[x];
                     const uint32_t e = S0 + (rc.x & 0xFFu), i = S0 + ((rc.x >> 8) & 0xFFu), jj = rc.y;
-                    if (third && !(ablate & 32)) {
-                        const OffT pj = BACK ? (OffT)atomicSub(&other_or_cursor[jj], 1u) : off[jj + 1] - 1u - atomicAdd(&other_or_cursor[jj], 1u);
-                        inc[pj] = make_int2((int)e, (int)i);
-                    }
-                    if (own_role && !(ablate & 16)) {
+                    if (!(ablate & 32)) inc[atomicSub(&other_or_cursor[jj], 1u)] = make_int2((int)e, (int)i);
+                    if (!(ablate & 16)) {
                         inc[off[e] + ((rc.x >> 16) & 0xFFu)] = make_int2((int)i, (int)jj);
                         inc[off[i] + (rc.x >> 24)] = make_int2((int)e, (int)jj);
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            n_rec = 0;
         };
 
         // probes that pass the signature test are parked and looked up densely, 64 at a time
@@ -323,21 +257,7 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
                 }
                 if (MODE == TRI_SINGLE) {
                     n_rec += (uint32_t)__popcll(hm);
-                    if (n_rec - n_done >= (uint32_t)kWave) {                 // 64 or more are waiting: one dense pass over all of them
-                        drain(n_done, n_rec, true, spilled);
-                        n_done = n_rec;
-                    }
-                    if (n_rec > (uint32_t)kTriRec - kWave) {
-                        // the buffer is full.  A DENSE sub-range gives up its block: everything kept so far, and what follows,
-                        // goes to the slices
-                        if (DENSE && !spilled) {
-                            drain(n_done, n_rec, true, false);
-                            drain(0, n_rec, false, true);
-                            spilled = true;
-                            if (lane == 0) atomicAdd(dense_cursor + 1, 1ull);     // statistics
-                        } else drain(n_done, n_rec, true, true);
-                        n_rec = 0; n_done = 0;
-                    }
+                    if (n_rec >= (uint32_t)kWave) drain();                    // 64 or more are waiting: one dense pass over all of them
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -432,73 +352,13 @@ __global__ __launch_bounds__(kBlock, KOMB_TRI_EU) void k_triangles(const uint32_
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (!staged) {
-            flush_tris();
-            if (DENSE) for (uint32_t k = (uint32_t)lane; k < E; k += kWave) ownoff[S0 + k] = kOwnSpill;
-            continue;
-        }
+        if (!staged) { flush_tris(); continue; }
         search_cands();
-        if (MODE == TRI_SINGLE) { drain(n_done, n_rec, true, spilled); n_done = n_rec; }
-        bool to_dense = MODE == TRI_SINGLE && DENSE && !spilled;     // wave-uniform
-        unsigned long long base = 0;
-        if (to_dense) {
-            // the own-role entries of this sub-range as one block of `dense`: exclusive prefix of the cursors (into s_col,
-            // which is done with), a claim on the wavefront's chunk, the offsets, the entries
-            __builtin_amdgcn_wave_barrier();
-            uint32_t run = 0;
-            for (uint32_t k0 = 0; k0 < E; k0 += kWave) {
-                const uint32_t k = k0 + (uint32_t)lane;
-                const uint32_t c = k < E ? s_cnt[k] : 0u;
-                const uint32_t ic = wave_incl_scan(c);
-                if (k < E) s_col[k] = (int32_t)(run + ic - c);
-                run += (uint32_t)__shfl((int)ic, kWave - 1);
-            }
-            if (run) {
-                if (chunk_pos + run > chunk_end) {               // (wave-uniform) the block does not fit what is left of the chunk
-                    const uint32_t want = run > kOwnChunk ? run : kOwnChunk;
-                    unsigned long long got = 0;
-                    if (lane == 0) got = atomicAdd(dense_cursor, (unsigned long long)want);
-                    const uint32_t glo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
-                    const uint32_t ghi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
-                    chunk_pos = ((unsigned long long)ghi << 32) | glo;
-                    chunk_end = chunk_pos + want;
-                    if (chunk_end > dense_cap) {
-                        // the region is sized by a bound on the entries plus a share for the chunks' unused tails; blocks of
-                        // an unlucky size in a graph that meets the bound can exceed it: this sub-range goes to the slices
-                        to_dense = false;
-                        chunk_pos = 0; chunk_end = 0;
-                    }
-                }
-                if (to_dense) { base = chunk_pos; chunk_pos += run; }
-            }
-        }
-        if (to_dense) {
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) { own[S0 + k] = s_cnt[k]; ownoff[S0 + k] = base + (uint32_t)s_col[k]; }
-            if (!(ablate & 16)) for (uint32_t b0 = 0; b0 < n_rec; b0 += kWave) {
-                const uint32_t x = b0 + (uint32_t)lane;
-                if (x < n_rec) {
-                    const uint2 rc = s_rec[x];
-                    const uint32_t er = rc.x & 0xFFu, ir = (rc.x >> 8) & 0xFFu;
-                    dense[base + (uint32_t)s_col[er] + ((rc.x >> 16) & 0xFFu)] = make_int2((int)(S0 + ir), (int)rc.y);
-                    dense[base + (uint32_t)s_col[ir] + (rc.x >> 24)] = make_int2((int)(S0 + er), (int)rc.y);
-                }
-            }
-        } else {
-            if (MODE == TRI_SINGLE && DENSE && !spilled) drain(0, n_rec, false, true);      // no room in the region: own-role entries of every record to the slices
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
-                own[S0 + k] = STREAM ? 0u : s_cnt[k];            // (STREAM: those entries are records, counted with the sorted stream)
-                if (MODE == TRI_SINGLE && DENSE) ownoff[S0 + k] = kOwnSpill;
-            }
-        }
+        if (MODE == TRI_SINGLE) drain();
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = (uint32_t)lane; k < E; k += kWave) own[S0 + k] = s_cnt[k];
       }   // sub-ranges
     }
-    if (STREAM) for (unsigned long long q = rec_pos + (unsigned long long)lane; q < rec_end && q < ts.cap; q += kWave)
-        ts.key[q] = ts.sentinel | (((uint32_t)q & ts.spread_mask) << ts.spread_shift);
-#ifdef KOMB_TRI_PROFILE
-    if (lane == 0 && gw < 16384) g_tri_prof[2 * gw + 1] = wall_clock64();
-#endif
 }
 
 __global__ __launch_bounds__(kBlock) void k_total_u32(const uint32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ total)
@@ -529,81 +389,6 @@ __global__ __launch_bounds__(kBlock) void k_sum_counts(const uint32_t *__restric
     }
     block_add_u64(t, total);                                    // 64-bit: the 32-bit slice offsets must not wrap
 }
-// capacity of edge (a->b)'s slice in the single-pass layout: |N(a) & N(b)| <= d(a) - 1, a being the
-// lower-(degree,id) endpoint.  total accumulates the 64-bit sum (the 32-bit offsets must not wrap).
-// total[1]: bound on the OWN-role entries alone (the triangles an edge a->x closes with the other out-neighbours of a:
-// at most d+(a) - 1), the capacity of the dense own-role region.
-__global__ __launch_bounds__(kBlock) void k_slice_caps(const int32_t *__restrict__ osrc, const int32_t *__restrict__ deg,
-                                                       const uint32_t *__restrict__ orow, int64_t m,
-                                                       uint32_t *__restrict__ cap, unsigned long long *__restrict__ total)
-{
-    unsigned long long t = 0, to = 0;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < m; e += (int64_t)gridDim.x * kBlock) {
-        const int32_t a = osrc[e];
-        const uint32_t c = (uint32_t)(deg[a] - 1);
-        cap[e] = c;
-        t += c;
-        to += orow[a + 1] - orow[a] - 1u;
-    }
-    block_add_u64(t, total);
-    block_add_u64(to, total + 1);
-}
-
-// Dense index from the bounded slices: 64 consecutive edges per wavefront, their entries flattened
-// over the lanes; the dense slices of consecutive edges are contiguous, so the writes are one
-// coalesced stream.  Entry k of edge x sits at offc[x]+k (k < own[x]) or offc[x+1]-1-(k-own[x]).
-// With a dense own-role region (own_dense / ownoff, see k_triangles) the own-role entries of edge x are
-// own_dense[ownoff[x] + k] unless ownoff[x] is kOwnSpill.
-template <class OffT>
-__global__ __launch_bounds__(kBlock) void k_compact_inc(const OffT *__restrict__ offc, const uint32_t *__restrict__ own,
-                                                        const uint32_t *__restrict__ off, const int2 *__restrict__ sparse,
-                                                        const int2 *__restrict__ own_dense, const unsigned long long *__restrict__ ownoff,
-                                                        int2 *__restrict__ dense, int64_t m)
-{
-    __shared__ uint32_t sh_end[kBlock / kWave][kWave];
-    const int lane = lane_id();
-    uint32_t *s_end = sh_end[threadIdx.x >> 6];
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    const int64_t nbatches = (m + kWave - 1) / kWave;
-    for (int64_t bt = wave; bt < nbatches; bt += nwaves) {
-        const int64_t e = bt * kWave + lane;
-        uint32_t d0 = 0, len = 0, ow = 0;
-        OffT c0 = 0, c1 = 0;
-        unsigned long long oo = kOwnSpill;
-        if (e < m) { d0 = off[e]; len = off[e + 1] - d0; c0 = offc[e]; c1 = offc[e + 1]; ow = own[e]; if (ownoff) oo = ownoff[e]; }
-        const uint32_t incl = wave_incl_scan(len);
-        const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
-        const uint32_t dbase = (uint32_t)__shfl((int)d0, 0);
-        __builtin_amdgcn_wave_barrier();
-        s_end[lane] = incl;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t it0 = 0; it0 < total; it0 += kWave) {
-            const uint32_t it = it0 + (uint32_t)lane;
-            int t = 0;
-            {
-                int lo = 0;
-#pragma unroll
-                for (int st = kWave / 2; st > 0; st >>= 1) lo += (s_end[lo + st - 1] <= it) ? st : 0;
-                t = lo;
-            }
-            const uint32_t first = t ? s_end[t - 1] : 0u;
-            const OffT tc0 = (OffT)__shfl((unsigned long long)c0, t), tc1 = (OffT)__shfl((unsigned long long)c1, t);
-            const uint32_t tow = (uint32_t)__shfl((int)ow, t);
-            const unsigned long long too = __shfl(oo, t);
-            if (it < total) {
-                const uint32_t k = it - first;
-                if (k < tow && too != kOwnSpill) dense[dbase + it] = own_dense[too + k];
-                else {
-                    const OffT sp = k < tow ? tc0 + k : tc1 - 1u - (k - tow);
-                    dense[dbase + it] = sparse[sp];
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 } // namespace
 
 } // namespace komb

@@ -1,4 +1,4 @@
-// truss_wedge.h -- step 2a of the k-truss path (ktruss.hip), round 4: the triangle enumeration by WEDGES (igraph_trussness's
+// truss_wedge.h -- step 2a of the k-truss path (ktruss.hip): the triangle enumeration by WEDGES (igraph_trussness's
 // igraph_list_triangles + per-edge support count, reference src/graph.cpp:508).
 //
 // k_triangles (truss_tri.h) finds the triangles {a,b,c}, a -> b -> c in (degree,id) order, from the oriented edge e = (a->b)
@@ -11,8 +11,8 @@
 //
 // This kernel turns the test around: the candidates c come out of the staged row of a, and what is fetched per edge is
 // ONE 64-byte line of b -- start and length of N+(b), six PIVOTS (the elements that cut the row into seven equal segments)
-// and a 256-bit blocked Bloom signature of its elements (k_vertex_lines builds the lines in one pass over the oriented
-// CSR).  A candidate that passes the signature (the true hits, 16 % at |E| = 100 M, plus a few % false positives) is parked
+// and a 256-bit blocked Bloom signature of its elements (the preparation writes the lines with the oriented rows,
+// truss_prep.hip; truss_line.h).  A candidate that passes the signature (the true hits, 16 % at |E| = 100 M, plus a few % false positives) is parked
 // and looked up in N+(b) itself, 64 candidates at a time: the pivots (in LDS) name its segment, and a segment of up to 8
 // elements is two 16-byte loads issued together -- ONE trip to memory per survivor, where a binary search over the row
 // made five or six dependent ones (measured: 4.6 of the kernel's 8.0 ms); only then is a row of b touched at all.  What happens
@@ -28,111 +28,12 @@ namespace komb {
 
 namespace {
 
-constexpr int kLineWords = 16;                  // 64 bytes per vertex: start, length, 6 pivots, 4 x 64-bit signature blocks
-constexpr int kSigBlocks = 4;
 constexpr int kLdsLine = 10;                    // words of a line kept in LDS: 4 signature blocks, start, length
-constexpr int kPivots = 6;                      // the row's elements at positions seg, 2 seg, ... 6 seg, seg = ceil(length / 7)
 constexpr int kWCand = 128;                     // parked candidates per wavefront
-#ifndef KOMB_WEDGE_V
-#define KOMB_WEDGE_V 32
-#endif
-constexpr int kWedgeV = KOMB_WEDGE_V;           // light vertices per task at most (<= 63: lane l holds orow[v0 + l]); same-box A/B at
-                                                // |E| = 100M: 8: 6.77 ms, 16: 5.76-6.0, 32: 5.46-5.69, 48: 5.58, 63: 5.58
-static_assert(kWedgeV >= 1 && kWedgeV <= 63, "a task's row pointers live in the lanes of one wavefront");
 constexpr uint32_t kScratchRec = (uint32_t)kTriCap * (kTriCap - 1) / 2 + 128;     // records of a staged sub-range at most (+ one LDS buffer's slack)
-
-__device__ __forceinline__ void sig_slot(int32_t c, uint32_t &blk, unsigned long long &mask)
-{
-    const uint32_t h = (uint32_t)c * 0x9E3779B1u;
-    blk = h >> 30;                                                   // 0 .. 3
-    mask = (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u));
-}
-
-// line[v] = { orow[v], d+(v), signature of N+(v) }: one thread per vertex walks its row (neighbouring threads walk
-// neighbouring rows: the wavefront's reads cover one contiguous range of ocol), the signature is gathered in LDS
-__global__ __launch_bounds__(kBlock) void k_vertex_lines(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol, int64_t nv,
-                                                         uint4 *__restrict__ line)
-{
-    __shared__ unsigned long long sh_sig[kBlock][kSigBlocks];
-    unsigned long long *sg = sh_sig[threadIdx.x];
-    for (int64_t v0 = (int64_t)blockIdx.x * kBlock; v0 < nv; v0 += (int64_t)gridDim.x * kBlock) {
-        const int64_t v = v0 + threadIdx.x;
-        if (v >= nv) continue;
-        const uint32_t b = orow[v], e = orow[v + 1];
-#pragma unroll
-        for (int i = 0; i < kSigBlocks; ++i) sg[i] = 0ull;
-        for (uint32_t j = b; j < e; ++j) {
-            uint32_t blk; unsigned long long mask;
-            sig_slot(ocol[j], blk, mask);
-            sg[blk] |= mask;
-        }
-        const uint32_t len = e - b, seg = (len + (uint32_t)kPivots) / (uint32_t)(kPivots + 1);
-        int32_t pv[kPivots];
-#pragma unroll
-        for (int k = 0; k < kPivots; ++k) pv[k] = (uint32_t)(k + 1) * seg < len ? ocol[b + (uint32_t)(k + 1) * seg] : 0x7FFFFFFF;
-        uint4 *L = line + 4 * v;
-        L[0] = make_uint4(b, len, (uint32_t)pv[0], (uint32_t)pv[1]);
-        L[1] = make_uint4((uint32_t)pv[2], (uint32_t)pv[3], (uint32_t)pv[4], (uint32_t)pv[5]);
-        L[2] = make_uint4((uint32_t)sg[0], (uint32_t)(sg[0] >> 32), (uint32_t)sg[1], (uint32_t)(sg[1] >> 32));
-        L[3] = make_uint4((uint32_t)sg[2], (uint32_t)(sg[2] >> 32), (uint32_t)sg[3], (uint32_t)(sg[3] >> 32));
-    }
-}
-
-// ---- the enumeration's tasks.  A task is a run of consecutive source vertices -- or, for a row too long to stage, one of
-// several PARTS of that row's owned edges.  Vertex ids are (degree,id) ranks, so heavy rows are neighbours: a fixed number
-// of vertices per task would hand one wavefront sixteen hub rows in a row (a K_250 inside a sparse graph: 12.7 ms of an
-// otherwise 1 ms enumeration on 16 wavefronts).  Rule: a row of kHeavyRow slots or more is a task of its own; lighter
-// vertices are grouped up to `group` (<= kWedgeV) of them, never across a multiple of `group`; a row beyond the LDS budget
-// (unstaged) is cut into parts of about kPartPairs wedges, its 64-edge batches dealt round-robin to the parts.
-// Descriptor: x = first vertex, y = vertices | part << 6 | parts << 19.
-#ifndef KOMB_HEAVY_ROW
-#define KOMB_HEAVY_ROW 32
-#endif
-constexpr uint32_t kHeavyRow = KOMB_HEAVY_ROW;
-constexpr unsigned long long kPartPairs = 16384;
-constexpr uint32_t kMaxParts = 8191;
-
-__device__ __forceinline__ bool task_starts(const uint32_t *__restrict__ orow, int64_t v, int group)
-{
-    if (v % group == 0) return true;
-    if (orow[v + 1] - orow[v] >= kHeavyRow) return true;
-    return orow[v] - orow[v - 1] >= kHeavyRow;                     // (v > 0 here)
-}
-
-__global__ __launch_bounds__(kBlock) void k_task_count(const uint32_t *__restrict__ orow, int64_t nv, int group, uint32_t *__restrict__ cnt)
-{
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) {
-        uint32_t c = 0;
-        if (v < nv && task_starts(orow, v, group)) {
-            const unsigned long long d = orow[v + 1] - orow[v];
-            c = 1;
-            if (d > (unsigned long long)kTriCap) {
-                const unsigned long long parts = (d * (d - 1ull) / 2ull + kPartPairs - 1ull) / kPartPairs;
-                const unsigned long long batches = (d + kWave - 1ull) / kWave;
-                c = (uint32_t)min(min(parts, batches), (unsigned long long)kMaxParts);
-            }
-        }
-        cnt[v] = c;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_task_fill(const uint32_t *__restrict__ orow, int64_t nv, int group, const uint32_t *__restrict__ toff,
-                                                      uint2 *__restrict__ tasks)
-{
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
-        const uint32_t n = toff[v + 1] - toff[v];
-        if (!n) continue;
-        uint32_t nverts = 1;
-        while (v + nverts < nv && nverts < (uint32_t)group && !task_starts(orow, v + nverts, group)) ++nverts;
-        for (uint32_t p = 0; p < n; ++p) tasks[toff[v] + p] = make_uint2((uint32_t)v, nverts | (p << 6) | (n << 19));
-    }
-}
 
 // MODE: TRI_COUNT (supports only: own[] by plain stores, other[] by atomics) or TRI_SINGLE (the record-stream build:
 // own-role entries as dense per-task blocks, everything else as records; truss_tri.h)
-#ifndef KOMB_WEDGE_EU
-#define KOMB_WEDGE_EU 4
-#endif
 template <int MODE>
 __global__ __launch_bounds__(kBlock, KOMB_WEDGE_EU) void k_wedges(const uint32_t *__restrict__ orow, const int32_t *__restrict__ ocol,
                                                                    const uint4 *__restrict__ line, const uint2 *__restrict__ tasks,

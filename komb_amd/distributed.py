@@ -86,6 +86,7 @@ def core_run_sharded(acc, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     cb = make_allreduce_callback(acc.device, group)
     acc._keepalive = cb
+    acc._sync_env_options()
     rc = acc._lib.komb_core_run_sharded(acc._ctx, rank, world, ctypes.cast(cb, ctypes.c_void_p), None)
     acc._check(rc)
 
@@ -121,5 +122,6 @@ def truss_run_sharded(acc, vmask=None, group=None, shard_peel=None):
         vmask = np.ascontiguousarray(vmask, dtype=np.uint8)
     cb = make_allreduce_callback(acc.device, group)
     acc._keepalive = cb
+    acc._sync_env_options()
     rc = acc._lib.komb_truss_run_sharded(acc._ctx, ptr(vmask), rank, world, ctypes.cast(cb, ctypes.c_void_p), None)
     acc._check(rc)

@@ -642,6 +642,7 @@ int main(int argc, const char **argv)
     // Creating the HIP context takes ~0.6 s; it runs beside the SAM parse (never in the host-only test mode).
     komb_opts opts{};
     opts.device = getenv("KOMB_DEVICE") ? atoi(getenv("KOMB_DEVICE")) : 0;
+    opts.reserved[0] = KOMB_CREATE_WARM_UPLOAD;          // the upload's pinned staging buffers are made beside the SAM parse, off the critical path
     std::future<komb_ctx *> ctx_early;
     g_ctx_early = &ctx_early;
     for (const std::string *path : {&args.input, &args.input2})          // fail on a missing input before a second thread exists

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the library reads no environment variable: the tests' KOMB_* switches reach it as per-context options through the
+    # Python plumbing (komb_amd/api.py: FORWARD_ENV_OPTIONS)
+    import komb_amd.api
+    komb_amd.api.FORWARD_ENV_OPTIONS = True
 
 
 @pytest.fixture(scope="session")

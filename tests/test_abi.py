@@ -29,7 +29,7 @@ def test_header_symbols_exported(built):
 
 def test_abi_version(built):
     import komb_amd
-    assert komb_amd._lib.load().komb_abi_version() == 6
+    assert komb_amd._lib.load().komb_abi_version() == 7
 
 
 def test_stats_struct_matches_header(built):

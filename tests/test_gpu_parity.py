@@ -26,7 +26,7 @@ def _i64(x):
 
 def test_native_library_is_loaded(K):
     lib = K._lib.load()
-    assert lib.komb_abi_version() == 6
+    assert lib.komb_abi_version() == 7
     with open("/proc/self/maps") as f:
         assert "libkomb_accel.so" in f.read()
 
@@ -259,11 +259,10 @@ def test_full_size_c2_properties(K, O):
 
 
 def test_index_layouts_agree(K, O, monkeypatch):
-    """The three index builds must give the same supports and trussness: record stream (default: dense own-role blocks +
-    sorted records; also with a dense region that runs out, with no dense region at all, and with a stream that runs out
-    and falls back), bounded slices + compaction (32- and 64-bit slice offsets, own-role entries in dense per-task blocks
-    or in the slices), exact two-pass."""
-    env = ("KOMB_TWO_PASS", "KOMB_INDEX", "KOMB_OFF64", "KOMB_OWN_DENSE_CAP", "KOMB_NO_OWN_DENSE", "KOMB_REC_CAP")
+    """The two index builds -- over the two enumerations -- must give the same supports and trussness: record stream of the
+    wedge enumeration (default: dense own-role blocks + sorted records; also with a dense region that runs out, with no dense
+    region at all, and with a stream that runs out and falls back), exact two-pass over the probe enumeration of rounds 1-3."""
+    env = ("KOMB_TWO_PASS", "KOMB_INDEX", "KOMB_OWN_DENSE_CAP", "KOMB_NO_OWN_DENSE", "KOMB_REC_CAP")
     uv = K.gen_hug_edges(40000, 110000, 2.3, 21)
     with K.KombAccel() as a:
         a.from_edges(40000, uv)
@@ -289,10 +288,6 @@ def test_index_layouts_agree(K, O, monkeypatch):
             # stream: a dense region that runs out half way (the tasks that find no room send their own-role entries to the
             # stream one by one), no dense region at all (three records per triangle), a stream that runs out (-> two-pass)
             (dict(KOMB_OWN_DENSE_CAP="70000"), 0), (dict(KOMB_NO_OWN_DENSE="1"), 0), (dict(KOMB_REC_CAP="50000"), 2),
-            # bounded slices: 32- and 64-bit offsets, with and without the dense own-role region
-            (dict(KOMB_INDEX="slices"), 1), (dict(KOMB_INDEX="slices", KOMB_OFF64="1"), 1),
-            (dict(KOMB_INDEX="slices", KOMB_OWN_DENSE_CAP="70000"), 1),
-            (dict(KOMB_INDEX="slices", KOMB_NO_OWN_DENSE="1"), 1), (dict(KOMB_INDEX="slices", KOMB_NO_OWN_DENSE="1", KOMB_OFF64="1"), 1),
         ]
         for kv, layout in variants:
             r, st = run(**kv)
@@ -308,7 +303,7 @@ def test_index_layouts_agree(K, O, monkeypatch):
 def test_sharded_peel_engine_single_rank(K, O, monkeypatch):
     """The sharded peel of shard_dev.h with ONE rank: the same host loop, kernels and range-filtered problem
     types as with N ranks, the exchange being the identity -- k-core and k-truss against the oracle on graphs with hub rows
-    / hub edges (heavy units), cliques (one far level), cascades and the three index layouts.  (N ranks: tests/test_distributed.py.)"""
+    / hub edges (heavy units), cliques (one far level), cascades and the two index layouts.  (N ranks: tests/test_distributed.py.)"""
     rng = np.random.default_rng(17)
     iu = np.triu_indices(90, 1)
     clique = np.stack(iu, axis=1) + 50
@@ -334,7 +329,7 @@ def test_sharded_peel_engine_single_rank(K, O, monkeypatch):
                 assert np.array_equal(core, ocore), (i, finish)
                 if finish == "none":                 # (with the local finish a small graph is handed over whole, before any exchange)
                     assert st["shard_exchanges"] > 0 and st["core_subrounds"] > 0 and st["core_local_units"] == 0
-                for layout in ("stream", "slices", "two_pass"):
+                for layout in ("stream", "two_pass"):
                     monkeypatch.setenv("KOMB_INDEX", layout)
                     eu, ev, tr, sup = a.run_truss(with_support=True)
                     st = a.stats()
@@ -409,7 +404,7 @@ def test_wedge_enumeration_paths(K, O, monkeypatch):
         otr = O.trussness(o_rowptr, o_col)
         with K.KombAccel() as a:
             a.from_edges(nv, uv)
-            for env in ({}, {"KOMB_NO_REC_SCRATCH": "1"}, {"KOMB_ENUM": "probe"}, {"KOMB_NO_OWN_DENSE": "1"}):
+            for env in ({}, {"KOMB_NO_REC_SCRATCH": "1"}, {"KOMB_INDEX": "two_pass"}, {"KOMB_NO_OWN_DENSE": "1"}):
                 for k, v in env.items(): monkeypatch.setenv(k, v)
                 eu, ev, tr, sup = a.run_truss(with_support=True)
                 st = a.stats()
@@ -489,43 +484,36 @@ def test_result_slices(K, O):
         assert np.array_equal(tr, otr)
 
 
-def test_wide_slice_offsets_reached_naturally(K, monkeypatch):
-    """A graph whose capacity-bounded slices hold more than 2^32 entries by themselves (dense uniform random, 30 000
-    vertices, ~12.5 M edges of degree ~830: sum over edges of d(lower endpoint) - 1 ~ 1e10), so the single pass runs with
-    64-bit slice offsets without KOMB_OFF64.  Checked against the two-pass index (exact slices, 32-bit offsets) and through
-    the size-independent properties; the oracle would need minutes here."""
+def test_dense_uniform_stream_against_two_pass(K, monkeypatch):
+    """A dense uniform random graph (30 000 vertices, ~12.5 M edges of degree ~830: oriented rows of ~400 slots, all beyond
+    the enumeration's staging limit, most beyond the preparation's per-wavefront sort).  The record-stream build over the
+    wedge enumeration against the exact two-pass build over the probe enumeration, and the size-independent properties;
+    the oracle would need minutes here."""
     rng = np.random.default_rng(77)
     nv = 30000
     uv = rng.integers(0, nv, (12_600_000, 2)).astype(np.int64)
-    for k in ("KOMB_OFF64", "KOMB_TWO_PASS", "KOMB_NO_OWN_DENSE", "KOMB_INDEX"):
+    for k in ("KOMB_TWO_PASS", "KOMB_NO_OWN_DENSE", "KOMB_INDEX"):
         monkeypatch.delenv(k, raising=False)
     with K.KombAccel() as a:
         a.from_edges(nv, uv)
         del uv
         deg, core = a.run_core()
-        r0 = a.run_truss(with_support=True)                                 # the default build (record stream)
-        assert a.stats()["index_layout"] == 0
-        monkeypatch.setenv("KOMB_INDEX", "slices")
-        eu, ev, tr, sup = a.run_truss(with_support=True)
-        monkeypatch.delenv("KOMB_INDEX", raising=False)
+        eu, ev, tr, sup = a.run_truss(with_support=True)                    # the default build (record stream)
         st = a.stats()
-        for x, y in zip((eu, ev, tr, sup), r0):
-            assert np.array_equal(x, y)
-        lower = np.minimum(deg[eu], deg[ev])                                # d(a) of the lower-(degree, id) endpoint a
-        assert int((lower.astype(np.int64) - 1).sum()) > 2**32           # the bound the slices are sized by, beyond 32 bits
-        assert st["index_layout"] == 1 and st["ms_tri_count"] == 0 and st["ms_compact"] > 0   # ... and still the single pass
+        assert st["index_layout"] == 0 and st["ms_tri_count"] == 0 and st["truss_prepared"] == 1 and st["ms_prepare"] > 0
         assert sup.sum(dtype=np.int64) == 3 * st["triangles"]
         assert np.all(tr >= 2) and np.all(tr <= sup + 2)
         assert np.all(np.minimum(core[eu], core[ev]) >= tr - 1)
         monkeypatch.setenv("KOMB_TWO_PASS", "1")
         r2 = a.run_truss(with_support=True)
         monkeypatch.delenv("KOMB_TWO_PASS", raising=False)
-        assert a.stats()["ms_tri_count"] > 0
+        st2 = a.stats()
+        assert st2["ms_tri_count"] > 0 and st2["truss_prepared"] == 0 and st2["ms_prepare"] == 0     # the preparation stayed with the graph
         for x, y in zip((eu, ev, tr, sup), r2):
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("layout", ["stream", "slices", "two_pass"])
+@pytest.mark.parametrize("layout", ["stream", "two_pass"])
 def test_cliques_and_hubs(K, O, monkeypatch, layout):
     """Complete graphs: long oriented rows (the LDS staging falls back to global search), every
     edge a heavy unit (slices of n-2 > 64 items).  Star + clique: a hub row split into chunks."""
@@ -595,7 +583,7 @@ def test_incidence_limit_is_refused(K):
             a.truss_fetch()                      # no stale result is exposed
 
 
-@pytest.mark.parametrize("layout", ["stream", "slices", "two_pass"])
+@pytest.mark.parametrize("layout", ["stream", "two_pass"])
 def test_kernel_threshold_boundaries(K, O, monkeypatch, layout):
     """Slice lengths around kLight=64 and kChunk=128 ("book" graphs: one spine edge with k pages), and
     16-vertex task blocks whose staged oriented rows straddle the 512-slot LDS budget (dense G(n,p))."""
