@@ -95,6 +95,9 @@ typedef struct komb_stats {
     double  ms_prepare;             /* device time of the preparation the last k-truss call (or komb_truss_prepare) made; 0 when it found one */
     int32_t truss_prepared;         /* 1 when the last k-truss call made a preparation (whole graph or induced subgraph)      */
     int32_t engine_flags;           /* which engines the last k-core / k-truss call ran: KOMB_ENGINE_* below                  */
+    double  ms_prep_vertex;         /* parts of ms_prepare: vertices ordered by (degree, id) (k_prep_vertex, radix sort, scans)   */
+    double  ms_prep_edges;          /* every canonical edge handed to its oriented row (k_prep_kept, _heavy, k_prep_dplus, scan)  */
+    double  ms_prep_rows;           /* rows sorted, lines and canonical map written (k_prep_rows, _heavy); the rest: task table  */
 } komb_stats;
 #define KOMB_ENGINE_LOCAL_FINISH 1   /* a remainder went to the local fixed point (local_dev.h)            */
 #define KOMB_ENGINE_LDS_TAIL     2   /* ... to the single-workgroup LDS tail                                */

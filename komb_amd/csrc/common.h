@@ -69,10 +69,11 @@ struct PeelCtrl {
     uint32_t tail_h[2];     // append cursors of the heavy queues
     int32_t  next_min;      // min live key above the scanned level
     uint32_t live_tail;     // survivors appended by the running SCAN
-    uint32_t acc;           // (unused)
+    int32_t  last_retire;   // problems with one-byte states: the sub-round the last RETIRE step ran before (finaliser only)
     // ---- hand-over to a finish (local_dev.h, truss_tail.h, core_tail.h); constant while launches are queued
     uint32_t tail_limit;    // a level that starts with at most this many units left sets done = 3 (0: never)
-    uint32_t pad1[8];
+    uint32_t pad1[7];       // (-DKOMB_STEP_TIMERS: stopwatch sums)
+    int32_t  max_retire_gap;    // the most sub-rounds that ever passed without a RETIRE step: the host checks it against the period
 };
 static_assert(offsetof(PeelCtrl, seq) == 60 && offsetof(PeelCtrl, tail_l) == 64, "PeelCtrl: the entry state is one 64-byte line");
 static_assert(sizeof(PeelCtrl) == 128, "PeelCtrl layout");
@@ -207,7 +208,8 @@ struct TrussPrep {
     void     *wtasks = nullptr;              // [n_wtasks] task descriptors of the triangle enumeration (truss_line.h)
     int64_t   n_wtasks = 0;
     int64_t   own_bound = 0;                 // sum over the vertices of d+ (d+ - 1): bound on the own-role index entries (capacities of a k-truss run)
-    double    ms = 0.0;                      // device time of the build (HIP events)
+    double    ms = 0.0;                      // device time of the build (HIP events) ...
+    double    ms_part[4] = {0, 0, 0, 0};     // ... and of its parts: vertex order | edges to rows + row pointers | row sort + lines + canonical map | tasks
 };
 
 struct komb_ctx {

@@ -204,6 +204,7 @@ __global__ void k_ctrl_init(PeelCtrl *ctrl, const uint32_t *grp_done, uint32_t u
         const uint32_t front = grp_done[kInitOff + 2];
         PeelCtrl c{};
         c.mode = MODE_SCAN; c.round = 1; c.seq = 1;
+        c.last_retire = 1;                           // (the RETIRE-gap invariant counts from the first sub-round)
         c.remaining = units - peeled;
         c.done = (c.remaining == 0) ? 1 : 0;
         c.level = c.remaining ? first : 0;           // start at the first populated level
@@ -390,9 +391,9 @@ int core_run(komb_ctx *ctx, int rank, int world, komb_allreduce_fn fn, void *use
 #ifdef KOMB_STEP_TIMERS
     {
         const PeelCtrl &c = ctx->h_ctrl[0];
-        const double n = c.pad1[7] ? (double)c.pad1[7] : 1.0;
+        const double n = c.pad1[6] ? (double)c.pad1[6] : 1.0;
         fprintf(stderr, "komb core step timers (block 0, %u small multi-workgroup PROCESS steps), us per step: ctrl %.2f queue+slice %.2f items %.2f flush %.2f barrier %.2f ticket %.2f\n",
-                c.pad1[7], c.pad1[0] / n / 100.0, c.pad1[1] / n / 100.0, c.pad1[2] / n / 100.0, c.pad1[3] / n / 100.0, c.pad1[4] / n / 100.0, c.pad1[5] / n / 100.0);
+                c.pad1[6], c.pad1[0] / n / 100.0, c.pad1[1] / n / 100.0, c.pad1[2] / n / 100.0, c.pad1[3] / n / 100.0, c.pad1[4] / n / 100.0, c.pad1[5] / n / 100.0);
     }
 #endif
     KOMB_TRY(st);

@@ -297,7 +297,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     komb_stats &st = ctx->stats;
     st.triangles = 0; st.truss_levels = st.truss_subrounds = st.truss_launches = 0;
     st.max_trussness = 0; st.ms_support = st.ms_peel = st.ms_orient = st.ms_tri_count = st.ms_tri_fill = st.ms_gather = st.ms_allreduce = st.ms_compact = 0.0;
-    st.truss_scans = 0; st.ms_prepare = 0.0; st.truss_prepared = 0;
+    st.truss_scans = 0; st.ms_prepare = 0.0; st.truss_prepared = 0; st.ms_prep_vertex = st.ms_prep_edges = st.ms_prep_rows = 0.0;
     auto empty_result = [&]() -> int {
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, 4));
@@ -323,10 +323,12 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         if (sub.ns == 0) return empty_result();
         KOMB_TRY(prep_build(ctx, sub.rowptr, sub.col, sub.nv, sub.ns, &sub_prep));
         st.ms_prepare = sub_prep.ms; st.truss_prepared = 1;
+        st.ms_prep_vertex = sub_prep.ms_part[0]; st.ms_prep_edges = sub_prep.ms_part[1]; st.ms_prep_rows = sub_prep.ms_part[2];
         tp = &sub_prep;
     } else if (!ctx->prep.valid) {
         KOMB_TRY(prep_ensure(ctx));
         st.ms_prepare = ctx->prep.ms; st.truss_prepared = 1;
+        st.ms_prep_vertex = ctx->prep.ms_part[0]; st.ms_prep_edges = ctx->prep.ms_part[1]; st.ms_prep_rows = ctx->prep.ms_part[2];
     }
     const int64_t nv = tp->nv;
     const int64_t m = tp->ne;
@@ -753,12 +755,17 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
 #ifdef KOMB_STEP_TIMERS
     {
         const PeelCtrl &c = ctx->h_ctrl[0];
-        const double n = c.pad1[7] ? (double)c.pad1[7] : 1.0;
+        const double n = c.pad1[6] ? (double)c.pad1[6] : 1.0;
         fprintf(stderr, "komb step timers (block 0, %u small multi-workgroup PROCESS steps), us per step: ctrl %.2f queue+slice %.2f items %.2f flush %.2f barrier %.2f ticket %.2f\n",
-                c.pad1[7], c.pad1[0] / n / 100.0, c.pad1[1] / n / 100.0, c.pad1[2] / n / 100.0, c.pad1[3] / n / 100.0, c.pad1[4] / n / 100.0, c.pad1[5] / n / 100.0);
+                c.pad1[6], c.pad1[0] / n / 100.0, c.pad1[1] / n / 100.0, c.pad1[2] / n / 100.0, c.pad1[3] / n / 100.0, c.pad1[4] / n / 100.0, c.pad1[5] / n / 100.0);
     }
 #endif
     if (ctx->h_ctrl[0].done != 1) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss peel ended in an inconsistent state");
+    // the one-byte edge states are exact only while a RETIRE step runs every retire_every sub-rounds: the engine records the
+    // longest gap it ever saw (peel_dev.h: finalize_step)
+    if (ctx->h_ctrl[0].max_retire_gap > retire_every)
+        KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss peel: %d sub-rounds passed without a RETIRE step (period %d): edge state codes may have wrapped",
+                  ctx->h_ctrl[0].max_retire_gap, retire_every);
     st.engine_flags = (layout == IDX_TWO_PASS ? KOMB_ENGINE_TWO_PASS : 0) | (shard_peel_on ? KOMB_ENGINE_SHARD_PEEL : 0) |
                       (st.truss_local_units ? KOMB_ENGINE_LOCAL_FINISH : 0) | (st.truss_tail_runs ? KOMB_ENGINE_LDS_TAIL : 0);
     st.truss_levels = ctx->h_ctrl[0].n_levels;

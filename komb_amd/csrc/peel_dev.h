@@ -79,8 +79,8 @@ __device__ __forceinline__ uint32_t marker_chunks(int32_t m) { return (uint32_t)
 enum : uint32_t { ST_ALIVE_LIGHT = 0, ST_ALIVE_HEAVY = 1, ST_GONE = 2, ST_ROUND0 = 3 };
 enum : int { REL_GONE = 0, REL_NOW = 1, REL_LATER = 2 };
 constexpr uint32_t kStateWindow = 253;          // 256 - ST_ROUND0
-constexpr int32_t kRetireEvery = 120;           // sub-rounds between two RETIRE steps: codes in use span <= 2 * kRetireEvery + 2 < kStateWindow
-static_assert(2 * kRetireEvery + 2 < (int32_t)kStateWindow, "state codes must not wrap between two RETIRE steps");
+constexpr int32_t kRetireEvery = 120;           // sub-rounds between two RETIRE steps: codes in use span <= kRetireEvery + 1 sub-rounds (checked: PeelCtrl::max_retire_gap)
+static_assert(2 * kRetireEvery + 2 < (int32_t)kStateWindow, "state codes must not wrap between two RETIRE steps, even if one were late by a whole period");
 __device__ __forceinline__ uint8_t state_of_round(int32_t q) { return (uint8_t)(ST_ROUND0 + (uint32_t)q % kStateWindow); }
 __device__ __forceinline__ uint8_t state_of_stamp(int32_t stamp)      // initial states: stamp = alive marker, 0 (triangle-free: gone) or 1 (first frontier)
 {
@@ -282,7 +282,7 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
     if (lane == 0) { (void)atomicExch(&ctrl->seq, launch + 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __builtin_amdgcn_wave_barrier();
     if (cv.mode & MODE_RETIRE) {                            // the state bytes are fresh: on to the step that was due
-        if (lane == 0) { ctrl->mode = cv.mode & ~MODE_RETIRE; *out = cv; out->mode = cv.mode & ~MODE_RETIRE; }
+        if (lane == 0) { ctrl->mode = cv.mode & ~MODE_RETIRE; ctrl->last_retire = cv.round; *out = cv; out->mode = cv.mode & ~MODE_RETIRE; }
         return;
     }
     const bool scan = cv.mode == MODE_SCAN;
@@ -326,7 +326,18 @@ __device__ __forceinline__ void finalize_step(PeelCtrl *ctrl, const CtrlView &cv
         }
         // state codes of sub-rounds long gone must not wrap around (state_rel).  Also when the remainder is being offered to a
         // finish (done = 3): should the finish refuse it, the engine goes on from this state and must not have skipped a RETIRE
+#ifdef KOMB_TEST_OLD_RETIRE_RULE                            // (the rule before commit 9b51a4a, for the regression test's negative control)
+        if (retire && !done) mode |= MODE_RETIRE;
+#else
         if (retire && done != 1 && done != 2) mode |= MODE_RETIRE;
+#endif
+        // the invariant the byte states rest on, made explicit: every increment of `round` passes through here, and a RETIRE
+        // step runs every retire_every sub-rounds -- the codes in use never span more than retire_every + 1 sub-rounds
+        // (< kStateWindow - 1).  The host fails the run if the gap ever exceeded the period (drive checks in ktruss.hip).
+        if (retire_every > 0) {
+            const int32_t gap = round - ctrl->last_retire;
+            if (gap > ctrl->max_retire_gap) ctrl->max_retire_gap = gap;
+        }
     }
     ctrl->mode = mode; ctrl->level = level; ctrl->round = round; ctrl->done = done;
     ctrl->cur_sel = nsel; ctrl->cur_light = cur_l; ctrl->cur_heavy = cur_h; ctrl->remaining = remaining;
@@ -737,7 +748,7 @@ __global__ __launch_bounds__(kPeelBlock, (kPeelBlock / 64) * kPeelPerCu / 4) voi
             tk[6] = wall_clock64();
             // sums of: ctrl read, queue + slice, items, flush, barrier, ticket; and the number of steps sampled
             for (int i = 0; i < 6; ++i) atomicAdd(&ctrl->pad1[i], (uint32_t)(tk[i + 1] - tk[i]));
-            atomicAdd(&ctrl->pad1[7], 1u);
+            atomicAdd(&ctrl->pad1[6], 1u);
         }
 #endif
         last = __shfl(last, 0);

@@ -253,7 +253,7 @@ int shard_peel(komb_ctx *ctx, DevBufs &bufs, const P &p, int32_t *key, uint32_t 
     auto fail_later = [&](int code, const char *what) { if (local_err == KOMB_OK) { local_err = code; local_msg = what; } };
     auto exchange = [&](uint32_t *buf, int64_t count, bool is_header) -> int {
         const auto t0 = std::chrono::steady_clock::now();
-        KOMB_HIP(ctx, hipStreamSynchronize(s));             // the buffer is complete when the callback runs
+        if (world > 1) KOMB_HIP(ctx, hipStreamSynchronize(s));   // the buffer is complete when the callback runs (one rank: no callback, no drain)
         if (world > 1 && fn(user, buf, count) != 0) {
             // (a header whose own exchange failed cannot be trusted for the sizes of what follows: this rank has to leave)
             if (is_header) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "sharded peel: all-reduce callback failed");

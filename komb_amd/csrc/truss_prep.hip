@@ -12,15 +12,18 @@
 // How (round 5; rounds 1-4 sorted |E| 12-byte records by a 48-bit key here: 6 radix passes, 4.8 of 14 ms at |E| = 100M).
 // No record is sorted.  A row of the oriented CSR is a SUBSET of a row of the symmetric one, so:
 //   1. vertices are radix-sorted by degree (stable: ties in id order)                      -> o2i, i2o;
-//   2. one pass over the symmetric rows keeps the neighbours of higher rank, as (internal id, canonical offset) pairs
-//      in the front of the row's own region of a scratch array; counts d+; writes the canonical edge list;
-//   3. a scan of d+ (in internal order) gives the oriented row pointers;
+//   2. one pass over the UPPER half of the symmetric rows (every canonical edge (v,w), v < w, once: one gather of o2i[w])
+//      writes the canonical edge list and hands the edge to the row of its lower-RANK endpoint as an (internal id of the
+//      other endpoint, canonical id) pair in a scratch array shaped like the symmetric CSR: v's own edges from the FRONT of
+//      v's region (a running count, no atomic), the edges v gives to w from the BACK of w's region (one atomic on w's back
+//      cursor).  d+(v) <= d(v), so the two ends never meet;
+//   3. d+ = front count + back count; its scan (in internal order) gives the oriented row pointers;
 //   4. one pass per oriented row sorts its <= ~10^2 entries by rank counting in LDS and writes targets, sources, the
-//      row's line, and the internal id of the canonical edges the row owns in FORWARD direction (lower original id =
-//      lower rank: their canonical id was a local offset in step 2);
-//   5. the other canonical edges (u < v but rank(v) < rank(u)) find their slot in the SHORT oriented row of v with
-//      one line fetch and one segment fetch (the enumeration's look-up, truss_line.h: line_find);
-//   6. the task table.
+//      row's line, and -- every entry carries its canonical id -- the internal id of every canonical edge;
+//   5. the task table.
+// (Round 5's first version walked BOTH halves of every row -- no atomics, twice the gathers -- and then searched the
+// oriented rows for the half of the canonical edges whose lower endpoint has the higher rank: 9.6 ms at |E| = 100M, the
+// gathers of 40 MB tables running at ~55 G/s; this one: see DESIGN.md section 4.1.)
 // Rows too long for a wavefront (symmetric rows beyond kPrepHeavy slots, oriented rows beyond kRowCap) are done by a
 // workgroup each.
 #include "truss_line.h"
@@ -36,18 +39,20 @@ constexpr int kPrepHB = 1024;
 constexpr uint32_t kRowCap = 1024;              // oriented entries a wavefront sorts in LDS at a time; longer rows: k_prep_rows_heavy
 constexpr uint32_t kRowStage = 8192;            // ... which stages up to this many in LDS
 constexpr int kPW = kBlock / kWave;
-constexpr int kPrepU = 4;                       // trips of a wavefront whose loads are in flight together (k_prep_kept, k_prep_reversed)
+constexpr int kPrepU = 4;                       // trips of a wavefront whose loads are in flight together (k_prep_kept)
 
 // ---- 1. degrees as sort keys; first upper slot (column above row) of every row and how many there are
 __global__ __launch_bounds__(kBlock) void k_prep_vertex(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                         uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
-                                                        uint32_t *__restrict__ first_upper, uint32_t *__restrict__ upper_cnt)
+                                                        uint32_t *__restrict__ first_upper, uint32_t *__restrict__ upper_cnt,
+                                                        uint32_t *__restrict__ backcur)
 {
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) {
         if (v == nv) { upper_cnt[v] = 0u; continue; }
         const uint32_t b = rowptr[v], e = rowptr[v + 1];
         dkey[v] = e - b;
         dval[v] = (uint32_t)v;
+        backcur[v] = e - 1u;                                      // the last position of v's region: counted DOWN by the edges v is given
         uint32_t lo = b, hi = e;                                  // first slot with col > v (rows hold no loops)
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -76,38 +81,36 @@ __device__ __forceinline__ int owner_of(const uint32_t *s_end, uint32_t it)
     return lo;
 }
 
-// ---- 2. the kept neighbours.  A wavefront takes 64 consecutive ORIGINAL vertices: their rows are one contiguous range of
-// col[], flattened over the lanes.  Slot j = (v, w) is kept when rank(w) > rank(v); the r-th kept slot of row v goes to
-// tmp[rowptr[v] + r] = (o2i[w], offset of (v,w) among the canonical edges of v, or ~0 when w < v).  Every upper slot
-// (w > v) also writes its canonical edge (v, w) at ebase[v] + offset.
+// ---- 2. every canonical edge to the row of its lower-rank endpoint.  A wavefront takes 64 consecutive ORIGINAL vertices; the
+// UPPER parts of their rows (columns above the row: the canonical edges, ids ebase[v] + offset) are flattened over the lanes.
+// Edge (v, w): a = o2i[v], b = o2i[w] (the one gather).  b > a: the oriented edge a -> b is v's: tmp[rowptr[v] + r] = (b, k),
+// r = v's running count.  b < a: it is w's: tmp[backcur[w]--] = (a, k).
 __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                       const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
-                                                      uint2 *__restrict__ tmp, uint32_t *__restrict__ dplus_i,
-                                                      int32_t *__restrict__ ceu, int32_t *__restrict__ cev, unsigned long long *__restrict__ own_bound)
+                                                      uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur,
+                                                      int32_t *__restrict__ ceu, int32_t *__restrict__ cev)
 {
-    __shared__ uint32_t sh_end[kPW][kWave], sh_beg[kPW][kWave], sh_a[kPW][kWave], sh_fu[kPW][kWave], sh_eb[kPW][kWave], sh_cnt[kPW][kWave];
+    __shared__ uint32_t sh_end[kPW][kWave], sh_beg[kPW][kWave], sh_a[kPW][kWave], sh_rp[kPW][kWave], sh_eb[kPW][kWave], sh_cnt[kPW][kWave];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
-    uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w], *s_a = sh_a[w], *s_fu = sh_fu[w], *s_eb = sh_eb[w], *s_cnt = sh_cnt[w];
+    uint32_t *s_end = sh_end[w], *s_beg = sh_beg[w], *s_a = sh_a[w], *s_rp = sh_rp[w], *s_eb = sh_eb[w], *s_cnt = sh_cnt[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * kBlock) >> 6;
     const int64_t ntasks = (nv + kWave - 1) / kWave;
-    unsigned long long ob = 0;
     for (int64_t task = gw; task < ntasks; task += nw) {
         const int64_t v0 = task * kWave, v = v0 + lane;
         const bool has = v < nv;
-        const uint32_t beg = has ? rowptr[v] : 0u, end = has ? rowptr[v + 1] : 0u;
+        const uint32_t beg = has ? rowptr[v] : 0u, end = has ? rowptr[v + 1] : 0u, up = has ? fu[v] : 0u;
         const bool heavy = end - beg > kPrepHeavy;                 // (left to k_prep_kept_heavy: no slot of it is walked here)
-        const uint32_t incl = wave_incl_scan(heavy ? 0u : end - beg);
+        const uint32_t incl = wave_incl_scan(heavy ? 0u : end - up);
         const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
         __builtin_amdgcn_wave_barrier();
         s_end[lane] = incl;
-        s_beg[lane] = beg;
+        s_beg[lane] = up;
+        s_rp[lane] = beg;
         s_a[lane] = has ? (uint32_t)o2i[v] : 0u;
-        s_fu[lane] = has ? fu[v] : 0u;
         s_eb[lane] = has ? ebase[v] : 0u;
         s_cnt[lane] = 0u;
         __builtin_amdgcn_wave_barrier();
-        // kPrepU trips at a time: their owner searches (LDS) first, then all their column loads, then all their rank gathers --
-        // one trip after the other is two dependent trips to memory per 64 slots (measured: 4.0 ms at |E| = 100M; this: see DESIGN)
+        // kPrepU trips at a time: their owner searches (LDS) first, then all their column loads, then all their rank gathers
         for (uint32_t it0 = 0; it0 < total; it0 += kWave * kPrepU) {
             int t[kPrepU];
             uint32_t rowstart[kPrepU], j[kPrepU], b[kPrepU];
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
                 const uint32_t it = it0 + (uint32_t)(u * kWave + lane);
                 on[u] = it < total;
                 t[u] = on[u] ? owner_of(s_end, it) : 0;
-                rowstart[u] = t[u] ? s_end[t[u] - 1] : 0u;         // flattened position of the row's first slot
+                rowstart[u] = t[u] ? s_end[t[u] - 1] : 0u;         // flattened position of the row's first upper slot
                 j[u] = s_beg[t[u]] + (it - rowstart[u]);
             }
 #pragma unroll
@@ -130,35 +133,32 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
                 const uint32_t base = it0 + (uint32_t)(u * kWave), it = base + (uint32_t)lane;
                 if (base >= total) break;                           // (wave-uniform)
                 const int tt = t[u];
-                const bool kept = on[u] && b[u] > s_a[tt];
-                const uint64_t K = __ballot(kept);
+                const uint32_t a = s_a[tt];
+                const uint32_t k = s_eb[tt] + (it - rowstart[u]);   // the canonical id of (v, w)
+                const bool mine = on[u] && b[u] > a, theirs = on[u] && b[u] < a;
+                if (on[u]) { ceu[k] = (int32_t)(v0 + tt); cev[k] = wv[u]; }
+                if (theirs) tmp[atomicSub(&backcur[wv[u]], 1u)] = make_uint2(a, k);
+                const uint64_t K = __ballot(mine);
                 const uint32_t f = rowstart[u] > base ? rowstart[u] - base : 0u;      // the lane where row tt starts in this trip (<= lane)
                 const uint32_t r = s_cnt[tt] + (uint32_t)__popcll(K & lanemask_lt() & ~((1ull << f) - 1ull));
-                const uint32_t kk = (on[u] && j[u] >= s_fu[tt]) ? j[u] - s_fu[tt] : 0xFFFFFFFFu;
-                if (kk != 0xFFFFFFFFu) { const uint32_t k = s_eb[tt] + kk; ceu[k] = (int32_t)(v0 + tt); cev[k] = wv[u]; }
-                if (kept) tmp[(size_t)s_beg[tt] + r] = make_uint2(b[u], kk);
+                if (mine) tmp[(size_t)s_rp[tt] + r] = make_uint2(b[u], k);
                 __builtin_amdgcn_wave_barrier();
                 // the last lane of every row's segment of this trip carries the row's count forward
-                if (on[u] && (it + 1u == s_end[tt] || lane == kWave - 1)) s_cnt[tt] = r + (kept ? 1u : 0u);
+                if (on[u] && (it + 1u == s_end[tt] || lane == kWave - 1)) s_cnt[tt] = r + (mine ? 1u : 0u);
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (has && !heavy) {
-            const unsigned long long d = s_cnt[lane];
-            dplus_i[s_a[lane]] = (uint32_t)d;
-            ob += d ? d * (d - 1ull) : 0ull;
-        }
+        if (has && !heavy) nlocal[v] = s_cnt[lane];
         __builtin_amdgcn_wave_barrier();
     }
-    block_add_u64(ob, own_bound);
 }
 
 // the same for the rows beyond kPrepHeavy slots, a workgroup each: they are the tail of the degree order
 __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                              const uint32_t *__restrict__ sorted_deg, const int32_t *__restrict__ i2o,
                                                              const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
-                                                             uint2 *__restrict__ tmp, uint32_t *__restrict__ dplus_i,
-                                                             int32_t *__restrict__ ceu, int32_t *__restrict__ cev, unsigned long long *__restrict__ own_bound)
+                                                             uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur,
+                                                             int32_t *__restrict__ ceu, int32_t *__restrict__ cev)
 {
     __shared__ uint32_t sh_wc[kPrepHB / kWave];
     const int lane = lane_id(), wv_ = (int)(threadIdx.x >> 6);
@@ -170,36 +170,48 @@ __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__r
         const int32_t v = i2o[a];
         const uint32_t beg = rowptr[v], end = beg + deg, fuv = fu[v], eb = ebase[v];
         uint32_t run = 0;
-        for (uint32_t j0 = beg; j0 < end; j0 += kPrepHB) {
+        for (uint32_t j0 = fuv; j0 < end; j0 += kPrepHB) {
             const uint32_t j = j0 + threadIdx.x;
             const bool active = j < end;
             const int32_t wv = active ? col[j] : 0;
             const uint32_t b = active ? (uint32_t)o2i[wv] : 0u;
-            const bool kept = active && b > (uint32_t)a;
-            const uint32_t kk = (active && j >= fuv) ? j - fuv : 0xFFFFFFFFu;
-            if (kk != 0xFFFFFFFFu) { ceu[eb + kk] = v; cev[eb + kk] = wv; }
-            const uint64_t K = __ballot(kept);
+            const bool mine = active && b > (uint32_t)a, theirs = active && b < (uint32_t)a;
+            const uint32_t k = eb + (j - fuv);
+            if (active) { ceu[k] = v; cev[k] = wv; }
+            if (theirs) tmp[atomicSub(&backcur[wv], 1u)] = make_uint2((uint32_t)a, k);
+            const uint64_t K = __ballot(mine);
             __syncthreads();
             if (lane == 0) sh_wc[wv_] = (uint32_t)__popcll(K);
             __syncthreads();
             uint32_t before = 0, all = 0;
 #pragma unroll
             for (int x = 0; x < kPrepHB / kWave; ++x) { const uint32_t c = sh_wc[x]; if (x < wv_) before += c; all += c; }
-            if (kept) tmp[(size_t)beg + run + before + (uint32_t)__popcll(K & lanemask_lt())] = make_uint2(b, kk);
+            if (mine) tmp[(size_t)beg + run + before + (uint32_t)__popcll(K & lanemask_lt())] = make_uint2(b, k);
             run += all;
         }
-        if (threadIdx.x == 0) {
-            dplus_i[a] = run;
-            if (run) atomicAdd(own_bound, (unsigned long long)run * (run - 1ull));
-        }
+        if (threadIdx.x == 0) nlocal[v] = run;
     }
 }
 
-// ---- 4. the oriented rows.  A wavefront takes 64 consecutive INTERNAL vertices; their kept lists (step 2) are read into LDS
-// in batches of <= kRowCap entries (whole rows), every entry is ranked among its row's by counting, and leaves as the
-// row's rank-th slot.  hlist: the rows beyond kRowCap, for k_prep_rows_heavy.
+// ---- 3. d+(v) = the edges v kept itself + the edges it was given; by internal id, for the scan
+__global__ __launch_bounds__(kBlock) void k_prep_dplus(const uint32_t *__restrict__ rowptr, int64_t nv, const int32_t *__restrict__ o2i,
+                                                       const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
+                                                       uint32_t *__restrict__ dplus_i, unsigned long long *__restrict__ own_bound)
+{
+    unsigned long long ob = 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long d = nlocal[v] + (rowptr[v + 1] - 1u - backcur[v]);
+        dplus_i[o2i[v]] = (uint32_t)d;
+        ob += d ? d * (d - 1ull) : 0ull;
+    }
+    block_add_u64(ob, own_bound);
+}
+
+// ---- 4. the oriented rows.  A wavefront takes 64 consecutive INTERNAL vertices; their lists (step 2: nlocal entries at the
+// front of the vertex' region, the rest behind its back cursor) are read into LDS in batches of <= kRowCap entries (whole
+// rows), every entry is ranked among its row's by counting, and leaves as the row's rank-th slot.
 __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict__ orow, int64_t nv, const int32_t *__restrict__ i2o,
-                                                      const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ ebase,
+                                                      const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
                                                       const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
                                                       uint32_t *__restrict__ canon2e, uint4 *__restrict__ line)
 {
@@ -207,10 +219,10 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
     __shared__ uint32_t sh_kk[kPW][kRowCap];
     __shared__ unsigned long long sh_sig[kPW][kWave][kSigBlocks];
     __shared__ int32_t sh_piv[kPW][kWave][kPivots];
-    __shared__ uint32_t sh_end[kPW][kWave], sh_rp[kPW][kWave], sh_ob[kPW][kWave], sh_eb[kPW][kWave];
+    __shared__ uint32_t sh_end[kPW][kWave], sh_rp[kPW][kWave], sh_ob[kPW][kWave], sh_nl[kPW][kWave], sh_bk[kPW][kWave];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
     int32_t *s_b = sh_b[w];
-    uint32_t *s_kk = sh_kk[w], *s_end = sh_end[w], *s_rp = sh_rp[w], *s_ob = sh_ob[w], *s_eb = sh_eb[w];
+    uint32_t *s_kk = sh_kk[w], *s_end = sh_end[w], *s_rp = sh_rp[w], *s_ob = sh_ob[w], *s_nl = sh_nl[w], *s_bk = sh_bk[w];
     unsigned long long (*s_sig)[kSigBlocks] = sh_sig[w];
     int32_t (*s_piv)[kPivots] = sh_piv[w];
     const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * kBlock) >> 6;
@@ -224,7 +236,8 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
         const uint32_t len = big ? 0u : d;
         __builtin_amdgcn_wave_barrier();
         s_rp[lane] = has ? rowptr[v] : 0u;
-        s_eb[lane] = has ? ebase[v] : 0u;
+        s_nl[lane] = has ? nlocal[v] : 0u;
+        s_bk[lane] = has ? backcur[v] + 1u : 0u;                   // the first entry v was given
         s_ob[lane] = ob;
 #pragma unroll
         for (int x = 0; x < kSigBlocks; ++x) s_sig[lane][x] = 0ull;
@@ -241,7 +254,8 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
             for (uint32_t k = (uint32_t)lane; k < E; k += kWave) {
                 const int t = owner_of(s_end, k);
                 const uint32_t first = t ? s_end[t - 1] : 0u;
-                const uint2 ent = tmp[(size_t)s_rp[t] + (k - first)];
+                const uint32_t idx = k - first, nl = s_nl[t];
+                const uint2 ent = tmp[idx < nl ? (size_t)s_rp[t] + idx : (size_t)s_bk[t] + (idx - nl)];
                 s_b[k] = (int32_t)ent.x; s_kk[k] = ent.y;
             }
             __builtin_amdgcn_wave_barrier();
@@ -254,8 +268,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
                 const uint32_t e = s_ob[t] + rank;
                 ocol[e] = mine;
                 osrc[e] = (int32_t)(a0 + t);
-                const uint32_t kk = s_kk[k];
-                if (kk != 0xFFFFFFFFu) canon2e[s_eb[t] + kk] = e;
+                canon2e[s_kk[k]] = e;
                 uint32_t blk; unsigned long long mask;
                 sig_slot(mine, blk, mask);
                 atomicOr(&s_sig[t][blk], mask);
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
 // global memory beyond (quadratic in a row that long: a graph with such rows is far beyond the index's triangle limit)
 __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__restrict__ hlist, const uint32_t *__restrict__ hcount,
                                                             const uint32_t *__restrict__ orow, const int32_t *__restrict__ i2o,
-                                                            const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ ebase,
+                                                            const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
                                                             const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
                                                             uint32_t *__restrict__ canon2e, uint4 *__restrict__ line)
 {
@@ -293,25 +306,26 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__re
     for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
         const uint32_t a = hlist[h], ob = orow[a], d = orow[a + 1] - ob;
         const int32_t v = i2o[a];
-        const uint2 *row = tmp + rowptr[v];
-        const uint32_t eb = ebase[v];
+        const uint32_t nl = nlocal[v];
+        const uint2 *front = tmp + rowptr[v], *back = tmp + (backcur[v] + 1u);
+        auto entry = [&](uint32_t i) -> uint2 { return i < nl ? front[i] : back[i - nl]; };
         const bool staged = d <= kRowStage;
         __syncthreads();
         if (threadIdx.x < (uint32_t)kSigBlocks) sh_sig[threadIdx.x] = 0ull;
         if (threadIdx.x < (uint32_t)kPivots) sh_piv[threadIdx.x] = 0x7FFFFFFF;
-        if (staged) for (uint32_t i = threadIdx.x; i < d; i += kBlock) sh_b[i] = (int32_t)row[i].x;
+        if (staged) for (uint32_t i = threadIdx.x; i < d; i += kBlock) sh_b[i] = (int32_t)entry(i).x;
         __syncthreads();
         const uint32_t seg = (d + (uint32_t)kPivots) / (uint32_t)(kPivots + 1);
         for (uint32_t i = threadIdx.x; i < d; i += kBlock) {
-            const uint2 ent = row[i];
+            const uint2 ent = entry(i);
             const int32_t mine = (int32_t)ent.x;
             uint32_t rank = 0;
             if (staged) for (uint32_t x = 0; x < d; ++x) rank += sh_b[x] < mine ? 1u : 0u;
-            else for (uint32_t x = 0; x < d; ++x) rank += (int32_t)row[x].x < mine ? 1u : 0u;
+            else for (uint32_t x = 0; x < d; ++x) rank += (int32_t)entry(x).x < mine ? 1u : 0u;
             const uint32_t e = ob + rank;
             ocol[e] = mine;
             osrc[e] = (int32_t)a;
-            if (ent.y != 0xFFFFFFFFu) canon2e[eb + ent.y] = e;
+            canon2e[ent.y] = e;
             uint32_t blk; unsigned long long mask;
             sig_slot(mine, blk, mask);
             atomicOr(&sh_sig[blk], mask);
@@ -328,39 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__re
     }
 }
 
-// ---- 5. the canonical edges whose lower ORIGINAL endpoint has the higher rank: the oriented edge o2i[v] -> o2i[u] sits in the
-// (short) oriented row of v; its line names the segment, the segment is one trip to memory
-__global__ __launch_bounds__(kBlock) void k_prep_reversed(const int32_t *__restrict__ ceu, const int32_t *__restrict__ cev, int64_t ne,
-                                                          const int32_t *__restrict__ o2i, const uint4 *__restrict__ line, const int32_t *__restrict__ ocol,
-                                                          uint32_t *__restrict__ canon2e, uint32_t *__restrict__ bad)
-{
-    // kPrepU edges per thread and trip, every stage's loads issued together: a chain of four dependent trips to memory per
-    // edge (map word + endpoints -> ranks -> line -> segment) runs for kPrepU edges at once
-    const int64_t step = (int64_t)gridDim.x * kBlock;
-    for (int64_t k0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; k0 < ne; k0 += step * kPrepU) {
-        bool todo[kPrepU];
-        int32_t u_[kPrepU], v_[kPrepU], c[kPrepU], ar[kPrepU];
-        uint4 l0[kPrepU], l1[kPrepU];
-#pragma unroll
-        for (int u = 0; u < kPrepU; ++u) {
-            const int64_t k = k0 + u * step;
-            todo[u] = k < ne && canon2e[k] == 0xFFFFFFFFu;
-            u_[u] = k < ne ? ceu[k] : 0; v_[u] = k < ne ? cev[k] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < kPrepU; ++u) { c[u] = todo[u] ? o2i[u_[u]] : 0; ar[u] = todo[u] ? o2i[v_[u]] : 0; }
-#pragma unroll
-        for (int u = 0; u < kPrepU; ++u) if (todo[u]) { const uint4 *L = line + 4 * (int64_t)ar[u]; l0[u] = L[0]; l1[u] = L[1]; }
-#pragma unroll
-        for (int u = 0; u < kPrepU; ++u) if (todo[u]) {
-            const uint32_t e = line_find(l0[u], l1[u], c[u], ocol);
-            if (e == 0xFFFFFFFFu) atomicAdd(bad, 1u);
-            else canon2e[k0 + u * step] = e;
-        }
-    }
-}
-
-// ---- 6. the enumeration's tasks (truss_line.h) + the list of the oriented rows beyond kRowCap (made with the counts: one
+// ---- 5. the enumeration's tasks (truss_line.h) + the list of the oriented rows beyond kRowCap (made with the counts: one
 // pass over the row pointers)
 __global__ __launch_bounds__(kBlock) void k_task_count(const uint32_t *__restrict__ orow, int64_t nv, int group, uint32_t *__restrict__ cnt,
                                                        uint32_t *__restrict__ hlist, uint32_t *__restrict__ hcount, uint32_t hcap)
@@ -397,9 +379,9 @@ __global__ __launch_bounds__(kBlock) void k_task_fill(const uint32_t *__restrict
 }
 
 __global__ void k_prep_flags(const uint32_t *__restrict__ toff, int64_t nv, const uint32_t *__restrict__ hcount, const unsigned long long *__restrict__ own_bound,
-                             const uint32_t *__restrict__ bad, unsigned long long *__restrict__ out)
+                             const uint32_t *__restrict__ orow, unsigned long long *__restrict__ out)
 {
-    if (threadIdx.x == 0) { out[0] = toff[nv]; out[1] = *own_bound; out[2] = *bad; out[3] = *hcount; }
+    if (threadIdx.x == 0) { out[0] = toff[nv]; out[1] = *own_bound; out[2] = orow[nv]; out[3] = *hcount; }
 }
 
 // sum_v d(v)^2, sum_e min(d(u),d(v)), max d, sum over the oriented edges of d+(a) + d+(b): the roofline model's inputs
@@ -519,8 +501,8 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     P.nv = nv; P.ne = ne;
     struct Fail { komb_ctx *c; TrussPrep *p; bool armed = true; ~Fail() { if (armed) prep_free(c, p); } } fail{ctx, &P};
     EventSet evs;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    KOMB_HIP(ctx, evs.make(&ev[0])); KOMB_HIP(ctx, evs.make(&ev[1]));
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // start | vertices ordered | edges handed out | rows done | end
+    for (auto &e : ev) KOMB_HIP(ctx, evs.make(&e));
     KOMB_HIP(ctx, hipEventRecord(ev[0], s));
     KOMB_HIP(ctx, pool_get(ctx, &P.o2i, (size_t)nv));
     KOMB_HIP(ctx, pool_get(ctx, &P.i2o, (size_t)nv));
@@ -539,62 +521,67 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
 
     DevBufs bufs(ctx);
     uint32_t *d_dk[2] = {nullptr, nullptr}, *d_dv[2] = {nullptr, nullptr}, *d_fu = nullptr, *d_uc = nullptr, *d_ebase = nullptr, *d_dplus = nullptr;
+    uint32_t *d_nlocal = nullptr, *d_backcur = nullptr;
     uint32_t *d_tcnt = nullptr, *d_hlist = nullptr, *d_words = nullptr;
-    unsigned long long *d_acc = nullptr;                             // [0] own bound, [1..4] flags read back
+    unsigned long long *d_acc = nullptr;                             // [0] own bound, [1..4] what the host reads back
     uint2 *d_tmp = nullptr;
     for (int i = 0; i < 2; ++i) { KOMB_HIP(ctx, bufs.alloc(&d_dk[i], (size_t)nv)); KOMB_HIP(ctx, bufs.alloc(&d_dv[i], (size_t)nv)); }
     KOMB_HIP(ctx, bufs.alloc(&d_fu, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_uc, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_dplus, (size_t)nv + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_nlocal, (size_t)nv));
+    KOMB_HIP(ctx, bufs.alloc(&d_backcur, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_tcnt, (size_t)nv + 1));
     const uint32_t hcap = (uint32_t)(ne / kRowCap + 64);
     KOMB_HIP(ctx, bufs.alloc(&d_hlist, (size_t)hcap));
-    KOMB_HIP(ctx, bufs.alloc(&d_words, 4));                          // [0] rows beyond kRowCap, [1] canonical edges step 5 could not place
+    KOMB_HIP(ctx, bufs.alloc(&d_words, 4));                          // [0] rows beyond kRowCap
     KOMB_HIP(ctx, bufs.alloc(&d_acc, 8));
     KOMB_HIP(ctx, bufs.alloc(&d_tmp, (size_t)ns));
     KOMB_HIP(ctx, hipMemsetAsync(d_words, 0, 4 * sizeof(uint32_t), s));
     KOMB_HIP(ctx, hipMemsetAsync(d_acc, 0, 8 * sizeof(unsigned long long), s));
     KOMB_HIP(ctx, hipMemsetAsync(d_dplus + nv, 0, sizeof(uint32_t), s));
-    if (ne > 0) KOMB_HIP(ctx, hipMemsetAsync(P.canon2e, 0xFF, (size_t)ne * sizeof(uint32_t), s));
 
     const int gv = grid_for(nv + 1);
     const int gwave = grid_for((nv + kWave - 1) / kWave, kPW, 256 * 8);
     // 1. vertices by (degree, original id): a degree is below nv, so the sort looks at that many bits only
-    k_prep_vertex<<<gv, kBlock, 0, s>>>(rowptr, col, nv, d_dk[0], d_dv[0], d_fu, d_uc);
+    k_prep_vertex<<<gv, kBlock, 0, s>>>(rowptr, col, nv, d_dk[0], d_dv[0], d_fu, d_uc, d_backcur);
     uint32_t *sk = d_dk[0], *sv = d_dv[0];
     if (nv > 0) {
         KOMB_TRY(prim_sort_pairs_u32_u32(ctx, d_dk[0], d_dk[1], d_dv[0], d_dv[1], nv, id_bits(nv), &sk, &sv));
         k_prep_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, nv, P.i2o, P.o2i);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_uc, d_ebase, nv + 1));
-    // 2. kept neighbours, d+, canonical edge list
-    if (nv > 0 && ne > 0) {
-        k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_tmp, d_dplus, P.ceu, P.cev, d_acc);
-        k_prep_kept_heavy<<<512, kPrepHB, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_tmp, d_dplus, P.ceu, P.cev, d_acc);
-    } else if (nv > 0) KOMB_HIP(ctx, hipMemsetAsync(d_dplus, 0, (size_t)nv * sizeof(uint32_t), s));
-    // 3. oriented row pointers
+    KOMB_HIP(ctx, hipEventRecord(ev[1], s));
+    // 2. every canonical edge to the row of its lower-rank endpoint; the canonical edge list; 3. d+ and the oriented row pointers
+    if (nv > 0) {
+        k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_tmp, d_nlocal, d_backcur, P.ceu, P.cev);
+        k_prep_kept_heavy<<<512, kPrepHB, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_tmp, d_nlocal, d_backcur, P.ceu, P.cev);
+        k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(rowptr, nv, P.o2i, d_nlocal, d_backcur, d_dplus, d_acc);
+    }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_dplus, P.orow, nv + 1));
-    // 6a. task counts + the list of the long oriented rows (one pass over the row pointers)
+    KOMB_HIP(ctx, hipEventRecord(ev[2], s));
+    // 5a. task counts + the list of the long oriented rows (one pass over the row pointers)
     const int group = (int)std::max<int64_t>(1, std::min<int64_t>(kWedgeV, nv / (256 * KOMB_WEDGE_EU * kTriWaves * 4)));
     k_task_count<<<gv, kBlock, 0, s>>>(P.orow, nv, group, d_tcnt, d_hlist, d_words, hcap);
-    // 4. oriented rows, lines, the forward half of the canonical map
+    // 4. oriented rows, lines, the canonical map
     if (nv > 0) {
-        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, P.i2o, rowptr, d_ebase, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
-        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, P.i2o, rowptr, d_ebase, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
+        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, P.i2o, rowptr, d_nlocal, d_backcur, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
+        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, P.i2o, rowptr, d_nlocal, d_backcur, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
     }
-    // 5. the reversed half
-    if (ne > 0) k_prep_reversed<<<grid_for(ne), kBlock, 0, s>>>(P.ceu, P.cev, ne, P.o2i, P.vline, P.ocol, P.canon2e, d_words + 1);
-    // 6b. tasks
+    KOMB_HIP(ctx, hipEventRecord(ev[3], s));
+    // 5b. tasks
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_tcnt, d_tcnt, nv + 1));
     if (nv > 0) k_task_fill<<<grid_for(nv), kBlock, 0, s>>>(d_tcnt, nv, group, (uint2 *)P.wtasks);
-    k_prep_flags<<<1, 64, 0, s>>>(d_tcnt, nv, d_words, d_acc, d_words + 1, d_acc + 1);
-    KOMB_HIP(ctx, hipEventRecord(ev[1], s));
+    k_prep_flags<<<1, 64, 0, s>>>(d_tcnt, nv, d_words, d_acc, P.orow, d_acc + 1);
+    KOMB_HIP(ctx, hipEventRecord(ev[4], s));
     unsigned long long h[4] = {0, 0, 0, 0};
     KOMB_HIP(ctx, d2h(ctx, h, d_acc + 1, sizeof(h)));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-    if (h[2]) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss preparation: %llu canonical edges without an oriented slot", h[2]);
+    float ms = 0.f, part[4] = {0.f, 0.f, 0.f, 0.f};
+    (void)hipEventElapsedTime(&ms, ev[0], ev[4]);
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&part[i], ev[i], ev[i + 1]);
+    for (int i = 0; i < 4; ++i) P.ms_part[i] = (double)part[i];
+    if (h[2] != (unsigned long long)ne) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss preparation: %llu oriented slots for %lld edges", h[2], (long long)ne);
     if (h[3] > hcap) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss preparation: %llu oriented rows beyond %u slots, room for %u", h[3], kRowCap, hcap);
     if (h[0] > task_cap) KOMB_FAIL(ctx, KOMB_ERR_DEVICE, "k-truss preparation: %llu tasks, room for %zu", h[0], task_cap);
     P.n_wtasks = (int64_t)h[0];

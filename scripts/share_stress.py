@@ -9,6 +9,8 @@ sys.path.insert(0, ROOT)
 def worker(idx, iters):
     import numpy as np
     import komb_amd
+    import komb_amd.api
+    komb_amd.api.FORWARD_ENV_OPTIONS = True      # KOMB_FINISH (argument 3) reaches the library as a per-context option
     from oracle import oracle as O
     nv = 300000
     uv = komb_amd.gen_hug_edges(nv, int(2.45 * nv), 2.6, 100 + idx)

@@ -24,7 +24,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import komb_amd                                    # noqa: E402
+import komb_amd.api                                # noqa: E402
 from komb_amd import distributed as kd             # noqa: E402
+komb_amd.api.FORWARD_ENV_OPTIONS = True            # this worker's KOMB_* switches reach the library as per-context options (api.py)
 from oracle import oracle as O                     # noqa: E402
 
 
@@ -307,6 +309,7 @@ def peel_main():
                     return rc
                 bad = komb_amd._lib.ALLREDUCE_FN(_cb)
                 os.environ["KOMB_FINISH"] = "none"
+                a._sync_env_options()
                 rc = a._lib.komb_core_run_sharded(a._ctx, rank, world, ctypes.cast(bad, ctypes.c_void_p), None)
                 os.environ.pop("KOMB_FINISH", None)
                 assert rc == komb_amd._lib.KOMB_ERR_DEVICE, f"rank {rank}: the injected failure was not reported (rc {rc})"

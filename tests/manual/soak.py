@@ -1,6 +1,6 @@
 """Randomised soak: many graphs of assorted shapes, k-core and k-truss (with support) against the CPU oracle,
 each under a random choice of the finish (local fixed point / LDS tails / none), its hand-over thresholds and item
-limit, and of the index layout (record stream / bounded slices / two pass, 32 / 64-bit slice offsets, dense or block-less
+limit, and of the index layout (record stream / two pass, dense or block-less
 own-role entries, a dense region or a record stream that runs out), the period of the engine's RETIRE step, the fixed point's
 notification kernel, -- one graph in seven -- the sharded peel's engine with one rank (shard_dev.h), and -- one in five --
 the sliced results of komb_truss_run_slice for a random rank of a random world size.
@@ -9,6 +9,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import komb_amd
+import komb_amd.api
+komb_amd.api.FORWARD_ENV_OPTIONS = True     # the switches below reach the library as per-context options
 from oracle import oracle as O
 
 n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
@@ -51,11 +53,11 @@ with komb_amd.KombAccel() as a:
         items = str(rng.choice(["", "0", "60", "5000", "200000"]))       # item limit of the local finish ("" = the default): small ones exercise the refusal
         if items: os.environ["KOMB_LOCAL_ITEMS"] = items
         else: os.environ.pop("KOMB_LOCAL_ITEMS", None)
-        for k, on in (("KOMB_TWO_PASS", rng.random() < 0.15), ("KOMB_OFF64", rng.random() < 0.3), ("KOMB_NO_OWN_DENSE", rng.random() < 0.3),
+        for k, on in (("KOMB_TWO_PASS", rng.random() < 0.15), ("KOMB_NO_OWN_DENSE", rng.random() < 0.3),
                       ("KOMB_SHARD_PEEL", rng.random() < 0.15)):
             if on: os.environ[k] = "1"
             else: os.environ.pop(k, None)
-        os.environ["KOMB_INDEX"] = str(rng.choice(["stream", "stream", "slices", "two_pass"]))
+        os.environ["KOMB_INDEX"] = str(rng.choice(["stream", "stream", "stream", "two_pass"]))
         for k, choices in (("KOMB_OWN_DENSE_CAP", ["", "", "0", "200", "5000"]), ("KOMB_REC_CAP", ["", "", "", "100", "3000"]), ("KOMB_RETIRE_EVERY", ["", "", "1", "3", "40"]),
                            ("KOMB_LOCAL_DEFER_CHUNKS", ["", "1"])):
             v = str(rng.choice(choices))
@@ -79,7 +81,7 @@ with komb_amd.KombAccel() as a:
             np.save(f"gpurun_out/soak_fail_{g}.npy", uv)
             print(f"MISMATCH graph {g} kind {kind} nv {nv} env FINISH={os.environ['KOMB_FINISH']} LOCAL_LIMIT={os.environ['KOMB_LOCAL_LIMIT']} "
                   f"TAIL={os.environ['KOMB_TAIL']} CORE_TAIL={os.environ['KOMB_CORE_TAIL']} "
-                  f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} OFF64={os.environ.get('KOMB_OFF64')} NO_OWN_DENSE={os.environ.get('KOMB_NO_OWN_DENSE')} LOCAL_ITEMS={os.environ.get('KOMB_LOCAL_ITEMS')} "
+                  f"TWO_PASS={os.environ.get('KOMB_TWO_PASS')} NO_OWN_DENSE={os.environ.get('KOMB_NO_OWN_DENSE')} LOCAL_ITEMS={os.environ.get('KOMB_LOCAL_ITEMS')} "
                   f"INDEX={os.environ.get('KOMB_INDEX')} OWN_DENSE_CAP={os.environ.get('KOMB_OWN_DENSE_CAP')} REC_CAP={os.environ.get('KOMB_REC_CAP')} "
                   f"DEFER={os.environ.get('KOMB_LOCAL_DEFER_CHUNKS')} SHARD_PEEL={os.environ.get('KOMB_SHARD_PEEL')} RETIRE={os.environ.get('KOMB_RETIRE_EVERY')}", flush=True)
         if g % 100 == 99:

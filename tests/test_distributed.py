@@ -74,15 +74,15 @@ def test_processes_sharing_one_gpu(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--c4-allreduce"], ["--same-graph", "--shard"], ["--replicas"], ["--batch"], ["--shard-peel"]])
+@pytest.mark.parametrize("extra", [[], ["--c4-allreduce"], ["--same-graph", "--shard"], ["--replicas-sliced"], ["--replicas"], ["--batch"], ["--shard-peel"]])
 def test_bench_two_ranks_on_one_gpu(built, extra):
     """`python bench.py --gpus 2` started plainly: it spawns its two ranks itself (before anything has touched the GPU) and
-    rank 0 prints the one JSON line.  Both ranks share GPU 0 here (KOMB_BENCH_ONE_DEVICE=1, exchange over gloo).  Default:
-    the same graph on both ranks, the whole path on both, each rank's slice of the results (komb_truss_run_slice; verified
-    against a whole run after the timed region), no exchange; --c4-allreduce (= BASELINE configs[3] to the letter;
-    --same-graph --shard is the older spelling): the support count sharded + all-reduce, strong scaling; --replicas: nothing
-    sliced; --batch: one graph per rank, weak scaling, own metric name; --shard-peel: --c4-allreduce plus the peel sharded by
-    edge range (one frontier exchange per sub-round)."""
+    rank 0 prints the one JSON line.  Both ranks share GPU 0 here (KOMB_BENCH_ONE_DEVICE=1, exchange over gloo).  Default
+    (= --shard-peel): BASELINE configs[3] / north_star's partition -- the same graph on both ranks, the support count sharded +
+    all-reduce, the peel sharded by edge range with one frontier exchange per sub-round, the other flows timed beside it;
+    --c4-allreduce (--same-graph --shard is the older spelling): the support all-reduce only; --replicas-sliced: round 4's
+    default (each rank's slice of the results, verified against a whole run after the timed region, no exchange); --replicas:
+    nothing sliced; --batch: one graph per rank, weak scaling, own metric name."""
     import json
     env = dict(os.environ, KOMB_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1",
@@ -92,20 +92,21 @@ def test_bench_two_ranks_on_one_gpu(built, extra):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["value_resident"] >= d["value"] * 0.8 and d["phases_ms"]["ms_prepare"] > 0
     par = d["config"]["parallelism"]
     if extra == ["--batch"]:
         assert d["scaling"] == "weak" and "independent graphs" in par and d["metric"].startswith("aggregate peeled edges/sec")
     else:
         assert d["scaling"] == "strong" and d["metric"] == "peeled edges/sec (k-truss)"
-        if extra == []:
+        if extra == ["--replicas-sliced"]:
             assert "slices verified after the timed region: True" in par and d["phases_ms"]["ms_allreduce"] == 0
         elif extra == ["--replicas"]:
             assert "replicas" in par
         else:
             assert "sharded" in par and d["config"]["workload"].startswith("C4") and d["phases_ms"]["ms_allreduce"] > 0
-        if extra == ["--shard-peel"]:                   # the peel by edge range on top: exchanges counted, k-core sharded as well
+        if extra in ([], ["--shard-peel"]):              # the peel by edge range: exchanges counted, k-core sharded as well, the other flows beside
             assert d["config"]["shard_peel"]["exchanges"] > 0 and "edge range" in d["config"]["workload"] and "sharded" in d["kcore"]
+            assert set(d["alternatives"]) == {"support_allreduce_only", "replicas_sliced"} and d["config"]["engine_flags"] & 4
         else:
             assert "shard_peel" not in d["config"] and d["phases_ms"]["ms_exchange"] == 0
     assert "cpu_baseline" not in d                       # timed at N = 1 only

@@ -247,6 +247,12 @@ def test_full_size_c2_properties(K, O):
         osup, otri = O.support(rowptr, col)
         assert np.array_equal(sup, osup) and st["triangles"] == otri
         assert np.array_equal(tr, _oracle_trussness_fast(O, rowptr, col))      # full-value parity, every run
+        # CoreA at this size (a9 + a10, src/CoreA.h:109-187): both rank vectors and every score against the oracle
+        rd, rk = a.fractional_ranks(deg, core)
+        assert np.array_equal(rd, O.fractional_rank_fast(deg.astype(np.int64)))
+        assert np.array_equal(rk, O.fractional_rank_fast(core.astype(np.int64) * nv + deg))
+        assert np.array_equal(a.get_anomaly_score(deg, core), O.corea_scores(deg, core))
+        assert a.stats()["ms_corea"] > 0
         # the top truss class is closed: every edge of the max-truss subgraph has
         # >= tmax-2 triangles inside it (checked with the oracle on that small subgraph)
         top = tr == tr.max()
@@ -448,6 +454,90 @@ def test_edge_state_bytes_and_retire_steps(K, O, monkeypatch):
     assert most > 2 * 253, most                         # the codes did wrap
 
 
+def test_truss_preparation_lifecycle(K, O):
+    """The k-truss side of a graph (truss_prep.hip) is made by the first k-truss call, inside that call (ms_prepare), kept for
+    the next ones, dropped by komb_truss_unprepare together with the last result, and never made by the graph build, k-core or
+    CoreA; an induced subgraph gets a temporary one every time and leaves the whole graph's alone."""
+    nv = 50000
+    uv = np.asarray(K.gen_hug_edges(nv, 150000, 2.3, 31)).reshape(-1, 2)
+    o_rowptr, o_col = O.simplify(nv, uv)
+    otr = O.trussness(o_rowptr, o_col)
+    for build in ("edges", "csr"):
+        with K.KombAccel() as a:
+            if build == "edges": a.from_edges(nv, uv)
+            else: a.from_csr(o_rowptr, o_col)
+            st = a.stats()
+            assert st["ms_build_relabel"] == 0 and st["ms_prepare"] == 0 and st["truss_prepared"] == 0
+            deg, core = a.run_core()
+            a.get_anomaly_score(deg, core)
+            assert a.stats()["ms_prepare"] == 0                               # k-core and CoreA never touch it
+            eu, ev, tr = a.run_truss()
+            st = a.stats()
+            assert st["truss_prepared"] == 1 and st["ms_prepare"] > 0 and np.array_equal(tr, otr)
+            a.truss_run()
+            st = a.stats()
+            assert st["truss_prepared"] == 0 and st["ms_prepare"] == 0        # found, not rebuilt
+            a.truss_unprepare()
+            with pytest.raises(K.KombError) as e:
+                a.truss_fetch()                                               # the result went with it
+            assert e.value.code == K._lib.KOMB_ERR_STATE
+            a.truss_prepare()
+            assert a.stats()["ms_prepare"] > 0
+            a.truss_prepare()                                                 # a no-op now
+            eu2, ev2, tr2 = a.run_truss()
+            assert a.stats()["truss_prepared"] == 0 and np.array_equal(tr2, otr) and np.array_equal(eu2, eu) and np.array_equal(ev2, ev)
+            mask = (core >= np.sort(core)[-nv // 20]).astype(np.uint8)
+            for _ in range(2):
+                seu, sev, stra = a.run_truss(mask)
+                st = a.stats()
+                assert st["truss_prepared"] == 1 and st["ms_prepare"] > 0      # the subgraph's own, every time
+                weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
+                assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+            eu3, ev3, tr3 = a.run_truss()
+            assert a.stats()["truss_prepared"] == 0 and np.array_equal(tr3, otr) and np.array_equal(eu3, eu)
+            a.graph_moments()
+            st = a.stats()
+            assert st["sum_deg_sq"] == int((deg.astype(np.int64) ** 2).sum()) and st["max_degree"] == int(deg.max())
+            a.set_option("INDEX", "no_such_layout")
+            with pytest.raises(K.KombError) as e:
+                a.truss_run()
+            assert e.value.code == K._lib.KOMB_ERR_ARG
+            a.set_option("INDEX", None)
+            a.truss_run()
+
+
+def test_retire_step_due_at_a_refused_hand_over(K, O, monkeypatch):
+    """Regression test for commit 9b51a4a (round 4's last engine fix): a RETIRE step that falls due exactly when the remainder
+    is offered to the local finish must stay pending when the finish REFUSES the offer (KOMB_LOCAL_ITEMS=0 refuses every one)
+    and the general engine goes on.  With a RETIRE period of 1 or 3 the offer of these graphs coincides with a due RETIRE; the
+    engine records the longest run of sub-rounds without a RETIRE (PeelCtrl::max_retire_gap) and the host fails the run when
+    it exceeds the period -- which it does under the old rule (`if (retire && !done)`; build with -DKOMB_TEST_OLD_RETIRE_RULE:
+    tests/manual/retire_rule_negative_control.sh).  Results against the oracle on the >= 506-sub-round graphs of the test above."""
+    iu = np.triu_indices(90, 1)
+    cases = [("hug 100k alpha 2.1", 100000, np.asarray(K.gen_hug_edges(100000, 300000, 2.1, 3)).reshape(-1, 2)),
+             ("clique ladder", 4000, np.concatenate([np.stack(np.triu_indices(k, 1), axis=1) + 37 * i for i, k in enumerate(range(3, 100))]).astype(np.int64)),
+             ("K_90 + tail", 600, np.concatenate([np.stack(iu, axis=1), np.stack([np.arange(89, 599), np.arange(90, 600)], axis=1)]).astype(np.int64))]
+    most = 0
+    for name, nv, uv in cases:
+        uv = np.ascontiguousarray(uv, dtype=np.int64)
+        o_rowptr, o_col = O.simplify(nv, uv)
+        otr = O.trussness(o_rowptr, o_col)
+        with K.KombAccel() as a:
+            a.from_edges(nv, uv)
+            for every in ("1", "3"):
+                for limit in (None, "200", "3000"):           # hand-over thresholds: the default fraction, and small remainders late in the peel
+                    env = {"KOMB_FINISH": "local", "KOMB_LOCAL_ITEMS": "0", "KOMB_RETIRE_EVERY": every}
+                    if limit: env["KOMB_LOCAL_LIMIT"] = limit
+                    for k, v in env.items(): monkeypatch.setenv(k, v)
+                    eu, ev, tr = a.run_truss()
+                    st = a.stats()
+                    for k in env: monkeypatch.delenv(k, raising=False)
+                    assert st["truss_local_units"] == 0, (name, env)             # every offer was refused: the engine peeled to the end
+                    assert np.array_equal(tr, otr), (name, env)
+                    most = max(most, st["truss_subrounds"])
+    assert most > 2 * 253, most
+
+
 def test_result_slices(K, O):
     """komb_truss_run_slice (what bench.py --gpus N runs on every rank): the whole path, the results of the rank's slice of
     the canonical edges, zeros elsewhere -- the slices of 1, 2, 3 and 7 ranks add up to the whole result (trussness and
@@ -638,6 +728,14 @@ def test_full_size_c3_known_answer(K, O):
         assert np.all(tr <= np.minimum(core[eu], core[ev]) + 1)
         assert hashlib.sha256(core.tobytes()).hexdigest()[:16] == "120d47bf172d8b8f"
         assert hashlib.sha256(tr.tobytes()).hexdigest()[:16] == "5970a467914854ea"
+        # CoreA at this size (10 M keys; coreness * n + degree reaches 7.2e8 here -- below 2^31, so the reference's `int` key,
+        # src/CoreA.h:122, is still defined on this graph): ranks and scores against the oracle
+        assert int(core.max()) * nv + int(deg.max()) < 2**31
+        rd, rk = a.fractional_ranks(deg, core)
+        assert np.array_equal(rd, O.fractional_rank_fast(deg.astype(np.int64)))
+        assert np.array_equal(rk, O.fractional_rank_fast(core.astype(np.int64) * nv + deg))
+        del rd, rk
+        assert np.array_equal(a.get_anomaly_score(deg, core), O.corea_scores(deg, core))
         # full-value parity, every run: all 100.1M trussness values against the oracle's OpenMP variant (~45 s on 16
         # threads); without the native build the recorded hash above stays the only full-size check
         if O.native_lib() is not None:
