@@ -98,6 +98,8 @@ typedef struct komb_stats {
     double  ms_prep_vertex;         /* parts of ms_prepare: vertices ordered by (degree, id) (k_prep_vertex, radix sort, scans)   */
     double  ms_prep_edges;          /* every canonical edge handed to its oriented row (k_prep_kept, _heavy, k_prep_dplus, scan)  */
     double  ms_prep_rows;           /* rows sorted, lines and canonical map written (k_prep_rows, _heavy); the rest: task table  */
+    int32_t stream_retries;         /* record-stream build: 1 when the first attempt's capacities (two triangles per edge) ran out and the enumeration ran again with what it asked for */
+    int32_t reserved0;
 } komb_stats;
 #define KOMB_ENGINE_LOCAL_FINISH 1   /* a remainder went to the local fixed point (local_dev.h)            */
 #define KOMB_ENGINE_LDS_TAIL     2   /* ... to the single-workgroup LDS tail                                */

@@ -46,6 +46,7 @@ class KombStats(ctypes.Structure):
         ("ms_build_h2d", ctypes.c_double), ("ms_build_relabel", ctypes.c_double),
         ("ms_prepare", ctypes.c_double), ("truss_prepared", ctypes.c_int32), ("engine_flags", ctypes.c_int32),
         ("ms_prep_vertex", ctypes.c_double), ("ms_prep_edges", ctypes.c_double), ("ms_prep_rows", ctypes.c_double),
+        ("stream_retries", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 KOMB_CREATE_NULL_STREAM, KOMB_CREATE_NO_WARMUP, KOMB_CREATE_WARM_UPLOAD = 1, 2, 4

@@ -156,8 +156,8 @@ int komb_core_fetch(komb_ctx *ctx, int32_t *degree, int32_t *coreness)
     KOMB_TRY(require_device(ctx));
     if (!ctx->core_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_core_fetch: komb_core_run has not completed");
     if (ctx->nv == 0) return KOMB_OK;
-    if (degree) KOMB_HIP(ctx, hipMemcpy(degree, ctx->d_deg, (size_t)ctx->nv * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (coreness) KOMB_HIP(ctx, hipMemcpy(coreness, ctx->d_core, (size_t)ctx->nv * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (degree) KOMB_HIP(ctx, staged_copy(ctx, degree, ctx->d_deg, (size_t)ctx->nv * sizeof(int32_t), false));
+    if (coreness) KOMB_HIP(ctx, staged_copy(ctx, coreness, ctx->d_core, (size_t)ctx->nv * sizeof(int32_t), false));
     return KOMB_OK;
 }
 
@@ -241,9 +241,9 @@ int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss)
     if (!ctx->truss_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch: komb_truss_run has not completed");
     const size_t bytes = (size_t)ctx->t_ne * sizeof(int32_t);
     if (bytes == 0) return KOMB_OK;
-    if (eu) KOMB_HIP(ctx, hipMemcpy(eu, ctx->d_t_eu, bytes, hipMemcpyDeviceToHost));
-    if (ev) KOMB_HIP(ctx, hipMemcpy(ev, ctx->d_t_ev, bytes, hipMemcpyDeviceToHost));
-    if (truss) KOMB_HIP(ctx, hipMemcpy(truss, ctx->d_t_truss, bytes, hipMemcpyDeviceToHost));
+    if (eu) KOMB_HIP(ctx, staged_copy(ctx, eu, ctx->d_t_eu, bytes, false));
+    if (ev) KOMB_HIP(ctx, staged_copy(ctx, ev, ctx->d_t_ev, bytes, false));
+    if (truss) KOMB_HIP(ctx, staged_copy(ctx, truss, ctx->d_t_truss, bytes, false));
     return KOMB_OK;
 }
 
@@ -252,7 +252,7 @@ int komb_truss_fetch_support(komb_ctx *ctx, int32_t *support)
     KOMB_TRY(require_device(ctx));
     if (!ctx->truss_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch_support: komb_truss_run has not completed");
     const size_t bytes = (size_t)ctx->t_ne * sizeof(int32_t);
-    if (bytes && support) KOMB_HIP(ctx, hipMemcpy(support, ctx->d_t_sup, bytes, hipMemcpyDeviceToHost));
+    if (bytes && support) KOMB_HIP(ctx, staged_copy(ctx, support, ctx->d_t_sup, bytes, false));
     return KOMB_OK;
 }
 
@@ -280,7 +280,8 @@ int komb_corea_scores(komb_ctx *ctx, const int32_t *degree, const int32_t *coren
     KOMB_TRY(corea_ranks(ctx, degree, coreness, nv, rd.get(), rc.get()));
     // host libm on purpose: |ln r_deg - ln r_key| as src/CoreA.h:131, same "%f" text downstream (element-wise: the host's
     // threads share the loop, every element is the same libm call it would be on one)
-#pragma omp parallel for schedule(static)
+    // (a GPU box shows every CPU of its host and grants a share of them: 16 threads at most)
+#pragma omp parallel for schedule(static) num_threads(16) if (nv > 100000)
     for (int64_t i = 0; i < nv; ++i) score[i] = std::fabs(std::log(rd[(size_t)i]) - std::log(rc[(size_t)i]));
     return KOMB_OK;
 }

@@ -389,6 +389,8 @@ int graph_from_edges(komb_ctx *ctx, int64_t nv, int64_t n_raw, const int64_t *uv
 int graph_from_csr(komb_ctx *ctx, int64_t nv, const int64_t *rowptr, const int32_t *col);
 void graph_free(komb_ctx *ctx);
 void stager_free(komb_ctx *ctx);
+// graph_build.hip: blocking copy pageable host memory <-> device through pinned staging buffers and a few host threads (>= 32 MB; else a plain copy)
+hipError_t staged_copy(komb_ctx *ctx, void *dst, const void *src, size_t bytes, bool to_device);
 void warm_up(komb_ctx *ctx);                 // graph_build.hip: first kernel launch of the library + the upload's staging buffers
 // truss_prep.hip: the k-truss side of a symmetric CSR (device pointers; nv vertices, ns = 2 |E| slots)
 int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_t nv, int64_t ns, TrussPrep *out);

@@ -80,8 +80,8 @@ int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t 
     for (int t = 0; t < 4; ++t) KOMB_HIP(ctx, bufs.alloc(&d_k[t], (size_t)n));
     for (int t = 0; t < 4; ++t) KOMB_HIP(ctx, bufs.alloc(&d_i[t], (size_t)n));
     for (int t = 0; t < 2; ++t) KOMB_HIP(ctx, bufs.alloc(&d_r[t], (size_t)n));
-    KOMB_HIP(ctx, hipMemcpyAsync(d_deg, deg, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    KOMB_HIP(ctx, hipMemcpyAsync(d_core, core, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    KOMB_HIP(ctx, staged_copy(ctx, d_deg, deg, (size_t)n * 4, true));
+    KOMB_HIP(ctx, staged_copy(ctx, d_core, core, (size_t)n * 4, true));
     int64_t g64 = (n + kBlock - 1) / kBlock;
     const int grid = (int)(g64 > 4096 ? 4096 : g64);
     ctx->timer.start(s);
@@ -95,9 +95,8 @@ int corea_ranks(komb_ctx *ctx, const int32_t *deg, const int32_t *core, int64_t 
     if (st == KOMB_OK) k_run_ranks<<<grid, kBlock, 0, s>>>(sk, si, n, d_r[1]);
     ctx->stats.ms_corea = ctx->timer.stop(s);
     KOMB_TRY(st);
-    KOMB_HIP(ctx, hipMemcpyAsync(rank_deg, d_r[0], (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    KOMB_HIP(ctx, hipMemcpyAsync(rank_key, d_r[1], (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    KOMB_HIP(ctx, hipStreamSynchronize(s));
+    KOMB_HIP(ctx, staged_copy(ctx, rank_deg, d_r[0], (size_t)n * 8, false));
+    KOMB_HIP(ctx, staged_copy(ctx, rank_key, d_r[1], (size_t)n * 8, false));
     return KOMB_OK;
 }
 

@@ -68,14 +68,19 @@ H2DStager *stager_get(komb_ctx *ctx)
     return ok ? g : nullptr;
 }
 
-// blocking copy of pageable host memory to the device; complete on return
-hipError_t h2d_staged(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
+} // namespace
+
+// blocking copy between pageable host memory and the device through the pinned staging buffers, a few host threads each with
+// a stream of its own; complete on return.  to_device = false: device -> host (the ranks of CoreA, the result fetches).
+hipError_t staged_copy(komb_ctx *ctx, void *dst, const void *src, size_t bytes, bool to_device)
 {
-    H2DStager *g = bytes >= (64u << 20) ? stager_get(ctx) : nullptr;
+    H2DStager *g = bytes >= (32u << 20) ? stager_get(ctx) : nullptr;
     if (!g) {
-        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream);
         return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
     }
+    // (device -> host: what the context's stream has written must be complete before the staging streams read it)
+    if (!to_device) { const hipError_t e0 = hipStreamSynchronize(ctx->stream); if (e0 != hipSuccess) return e0; }
     const size_t nchunks = (bytes + H2DStager::kChunk - 1) / H2DStager::kChunk;
     hipError_t err[H2DStager::kThreads];
     std::thread th[H2DStager::kThreads];
@@ -85,16 +90,33 @@ hipError_t h2d_staged(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
     auto work = [=, &err](int t, int stride) {
         hipError_t e = hipSetDevice(dev);
         size_t turn = 0;
+        size_t pend_off[H2DStager::kBufs] = {}, pend_len[H2DStager::kBufs] = {};      // device -> host: chunks in flight into the pinned buffers
         for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += (size_t)stride, ++turn) {
             const int b = (int)(turn % H2DStager::kBufs);
-            if (turn >= (size_t)H2DStager::kBufs) e = hipEventSynchronize(g->ev[t][b]);      // the buffer's previous copy has left it
+            if (turn >= (size_t)H2DStager::kBufs) {
+                e = hipEventSynchronize(g->ev[t][b]);                                 // the buffer's previous copy is done
+                if (e == hipSuccess && !to_device) memcpy((char *)dst + pend_off[b], g->pin[t][b], pend_len[b]);
+            }
             if (e != hipSuccess) break;
             const size_t off = c * H2DStager::kChunk, len = std::min(H2DStager::kChunk, bytes - off);
-            memcpy(g->pin[t][b], (const char *)src + off, len);
-            e = hipMemcpyAsync((char *)dst + off, g->pin[t][b], len, hipMemcpyHostToDevice, g->st[t]);
+            if (to_device) {
+                memcpy(g->pin[t][b], (const char *)src + off, len);
+                e = hipMemcpyAsync((char *)dst + off, g->pin[t][b], len, hipMemcpyHostToDevice, g->st[t]);
+            } else {
+                e = hipMemcpyAsync(g->pin[t][b], (const char *)src + off, len, hipMemcpyDeviceToHost, g->st[t]);
+                pend_off[b] = off; pend_len[b] = len;
+            }
             if (e == hipSuccess) e = hipEventRecord(g->ev[t][b], g->st[t]);
         }
         const hipError_t e2 = hipStreamSynchronize(g->st[t]);
+        if (!to_device && e == hipSuccess && e2 == hipSuccess) {
+            // the last (up to kBufs) chunks of this thread are still in the pinned buffers
+            const size_t done = turn;
+            for (size_t q = done > (size_t)H2DStager::kBufs ? done - H2DStager::kBufs : 0; q < done; ++q) {
+                const int b = (int)(q % H2DStager::kBufs);
+                memcpy((char *)dst + pend_off[b], g->pin[t][b], pend_len[b]);
+            }
+        }
         err[t] = e != hipSuccess ? e : e2;
     };
     // how many threads can be had is known only by trying: the stride is fixed before the first one starts copying
@@ -117,6 +139,10 @@ hipError_t h2d_staged(komb_ctx *ctx, void *dst, const void *src, size_t bytes)
     for (int t = 0; t < started; ++t) { th[t].join(); if (err[t] != hipSuccess) e = err[t]; }
     return e;
 }
+
+namespace {
+
+inline hipError_t h2d_staged(komb_ctx *ctx, void *dst, const void *src, size_t bytes) { return staged_copy(ctx, dst, src, bytes, true); }
 
 // ---------------------------------------------------------------- kernels
 inline int grid_for(int64_t n)

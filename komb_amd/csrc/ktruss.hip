@@ -402,7 +402,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
 #else
     const int ablate = 0;
 #endif
-    st.ms_sort = 0.0; st.tri_records = 0; st.ms_compact = 0.0; st.ms_tri_count = 0.0; st.ms_tri_fill = 0.0;
+    st.ms_sort = 0.0; st.tri_records = 0; st.ms_compact = 0.0; st.ms_tri_count = 0.0; st.ms_tri_fill = 0.0; st.stream_retries = 0;
     st.index_layout = layout;
     auto zero_counts = [&]() -> hipError_t { return hipMemsetAsync(d_own, 0, 2 * ((size_t)m + 1) * sizeof(uint32_t), s); };
     // (the wedge enumeration writes own[] of every edge it owns, and the stream build on one GPU never touches the third-role
@@ -438,45 +438,67 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         const unsigned long long bound = (unsigned long long)tp->own_bound;
         const int gws = std::min(gw, 256 * KOMB_WEDGE_EU);           // resident workgroups only: every wavefront ends with one partly used claim
         const unsigned long long slack = (unsigned long long)gws * kTriWaves * kRecChunk + kRecChunk;
-        unsigned long long own_cap = bound + bound / 8 + (unsigned long long)gws * kTriWaves * kOwnChunk + kOwnChunk;
-        if (const char *oc = ctx_opt(ctx, "OWN_DENSE_CAP")) own_cap = strtoull(oc, nullptr, 10) + 1;      // (tests: a region that runs out)
-        if (ctx_flag(ctx, "NO_OWN_DENSE")) own_cap = 1;              // (tests: every entry a record)
-        unsigned long long t_bound = bound / 2;
-        unsigned long long rec_cap = 3 * t_bound + (3 * t_bound) / 14 + slack;
-        if (const char *rc = ctx_opt(ctx, "REC_CAP")) rec_cap = strtoull(rc, nullptr, 10) + 1;            // (tests: a stream that runs out)
-        // (what the pool holds unused counts as free: the choice must not depend on what an earlier call left cached)
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        const unsigned long long budget = (unsigned long long)((free_b + ctx->pool.unused_bytes()) * 0.7);
-        if (own_cap * sizeof(int2) > budget / 2) own_cap = budget / 2 / sizeof(int2);
-        if (rec_cap * 12ull > budget / 2) rec_cap = budget / 2 / 12ull;
-        if (rec_cap > 0xFFFFFFF0ull) rec_cap = 0xFFFFFFF0ull;        // 32-bit record positions
+        const unsigned long long own_slack = (unsigned long long)gws * kTriWaves * kOwnChunk + kOwnChunk;
+        const unsigned long long t_bound = bound / 2;
+        // the bounds: what NO graph with this preparation can exceed ...
+        const unsigned long long own_full = bound + bound / 8 + own_slack, rec_full = 3 * t_bound + (3 * t_bound) / 14 + slack;
+        // ... and what the FIRST attempt reserves: room for two triangles per edge (a unitig graph has about one: C3 0.88, and the
+        // bounds are 7 x / 20 x what it touches -- 34 GB whose first allocation costs a one-shot komb2 run up to a second).  A graph
+        // with more finds the region / the stream too small -- the claim cursors keep counting past the capacities, so the
+        // need is then known -- and the enumeration runs ONCE more with exactly that; only if that does not fit either, or
+        // the memory is not there, does the build fall back to the two-pass layout.
+        unsigned long long own_cap = std::min(own_full, 4ull * (unsigned long long)m + own_slack);
+        unsigned long long rec_cap = std::min(rec_full, 2ull * (unsigned long long)m + slack);
+        bool fixed_caps = false;                                     // (tests: capacities that run out on purpose are not grown)
+        if (const char *oc = ctx_opt(ctx, "OWN_DENSE_CAP")) { own_cap = strtoull(oc, nullptr, 10) + 1; rec_cap = rec_full; fixed_caps = true; }
+        if (ctx_flag(ctx, "NO_OWN_DENSE")) { own_cap = 1; rec_cap = rec_full; fixed_caps = true; }      // (tests: every entry a record)
+        if (const char *rc = ctx_opt(ctx, "REC_CAP")) { rec_cap = strtoull(rc, nullptr, 10) + 1; fixed_caps = true; }
+        if (ctx_flag(ctx, "FULL_CAPS")) { own_cap = own_full; rec_cap = rec_full; }                     // (the bounds at once, as rounds 3-4 did)
         // keys of unused record positions: above every edge id, their bin field taken from the position (they spread over the bins)
         const uint32_t sentinel = geom.sentinel_base();
         uint32_t *d_key = nullptr; int2 *d_val = nullptr;
-        bool ok = bufs.alloc(&d_key, (size_t)rec_cap) == hipSuccess && bufs.alloc(&d_val, (size_t)rec_cap) == hipSuccess &&
-                  bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess && bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess &&
-                  bufs.alloc(&d_dcur, 4) == hipSuccess;
-        // the wedge enumeration's wave-private record scratch (truss_wedge.h); without the memory for it a sub-range whose
-        // records outgrow the LDS buffer gives up its dense block
-        uint2 *d_scratch = nullptr;
-        if (ok && !ctx_flag(ctx, "NO_REC_SCRATCH") && bufs.alloc(&d_scratch, (size_t)gws * kTriWaves * kScratchRec) != hipSuccess) { (void)hipGetLastError(); d_scratch = nullptr; }
         unsigned long long n_claimed = 0;
-        if (ok) {
+        bool ok = false;
+        st.ms_tri_fill = 0.0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            // (what the pool holds unused counts as free: the choice must not depend on what an earlier call left cached)
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            const unsigned long long budget = (unsigned long long)((free_b + ctx->pool.unused_bytes()) * 0.7);
+            if (own_cap * sizeof(int2) > budget / 2) own_cap = budget / 2 / sizeof(int2);
+            if (rec_cap * 12ull > budget / 2) rec_cap = budget / 2 / 12ull;
+            if (rec_cap > 0xFFFFFFF0ull) rec_cap = 0xFFFFFFF0ull;    // 32-bit record positions
+            ok = bufs.alloc(&d_key, (size_t)rec_cap) == hipSuccess && bufs.alloc(&d_val, (size_t)rec_cap) == hipSuccess &&
+                 bufs.alloc(&d_owndense, (size_t)own_cap) == hipSuccess &&
+                 (d_ownoff || bufs.alloc(&d_ownoff, (size_t)m + 1) == hipSuccess) && (d_dcur || bufs.alloc(&d_dcur, 4) == hipSuccess);
+            // the wedge enumeration's wave-private record scratch (truss_wedge.h); without the memory for it a sub-range whose
+            // records outgrow the LDS buffer gives up its dense block
+            uint2 *d_scratch = nullptr;
+            if (ok && !ctx_flag(ctx, "NO_REC_SCRATCH") && bufs.alloc(&d_scratch, (size_t)gws * kTriWaves * kScratchRec) != hipSuccess) { (void)hipGetLastError(); d_scratch = nullptr; }
+            if (!ok) { (void)hipGetLastError(); break; }
             KOMB_HIP(ctx, hipMemsetAsync(d_dcur, 0, 4 * sizeof(unsigned long long), s));
             const TriStream ts{d_key, d_val, d_dcur + 2, rec_cap, sentinel, geom.nb - 1u, kChunkBits};
             ctx->timer.start(s);
             k_wedges<TRI_SINGLE><<<gws, kBlock, 0, s>>>(d_orow, d_ocol, d_line, d_wtasks, 0, n_wtasks, d_own, d_other, d_owndense, d_dcur, own_cap, d_ownoff, ts, d_scratch, ablate);
-            st.ms_tri_fill = ctx->timer.stop(s);
+            st.ms_tri_fill += ctx->timer.stop(s);
             unsigned long long dc[4] = {0, 0, 0, 0};
             KOMB_HIP(ctx, d2h(ctx, dc, d_dcur, sizeof(dc)));
             n_claimed = dc[2];
             bufs.release(d_scratch);
             if (ctx_flag(ctx, "TRI_DEBUG"))
-                fprintf(stderr, "komb triangles: stream build: %llu record positions claimed of %llu, dense own-role region %llu entries claimed of %llu, %llu task ranges overflowed their record buffer\n",
-                        dc[2], rec_cap, dc[0], own_cap, dc[1]);
-            if (n_claimed > rec_cap) ok = false;                     // the stream ran out: records were dropped
-        } else (void)hipGetLastError();
+                fprintf(stderr, "komb triangles: stream build (attempt %d): %llu record positions claimed of %llu, dense own-role region %llu entries claimed of %llu, %llu task ranges overflowed their record buffer\n",
+                        attempt, dc[2], rec_cap, dc[0], own_cap, dc[1]);
+            if (n_claimed <= rec_cap) break;                         // every record is there (a dense region that ran out only made more of them)
+            ok = false;                                              // the stream ran out: records were dropped
+            if (attempt == 1 || fixed_caps) break;
+            // once more, with what this attempt asked for: the dense region it claimed (all of it this time, so fewer records than
+            // it claimed now) and the records it claimed
+            bufs.release(d_key); bufs.release(d_val); bufs.release(d_owndense);
+            d_key = nullptr; d_val = nullptr; d_owndense = nullptr;
+            own_cap = std::min(own_full, std::max(own_cap, dc[0] + own_slack));
+            rec_cap = std::min(rec_full, n_claimed + slack);
+            st.stream_retries += 1;
+        }
         uint32_t *d_skey = nullptr;
         if (ok) {
             // sort the records by destination bin

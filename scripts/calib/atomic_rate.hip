@@ -47,8 +47,8 @@ int main()
     for (uint32_t n : {100u << 20, 25u << 20, 1u << 20}) {
         int32_t *t = nullptr;
         CK(hipMalloc(&t, (size_t)n * 4));
-        for (int grid : {256 * 8, 256}) {
-            const int block = grid == 256 ? 1024 : 256;
+        for (int grid : {256 * 8, 256 * 4}) {                // 8 and 4 workgroups of 256 threads per CU
+            const int block = 256;
             for (int mode = 0; mode < 6; ++mode) {
                 CK(hipMemset(t, 0x55, (size_t)n * 4));
                 float best = 1e9f;

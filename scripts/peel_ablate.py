@@ -4,6 +4,7 @@ whose input does not depend on what earlier steps did).  KOMB_ACCEL_LIB=komb_amd
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import komb_amd, bench
+import komb_amd.api; komb_amd.api.FORWARD_ENV_OPTIONS = True   # KOMB_* switches reach the library as per-context options
 nv, ncl, alpha, seed = bench.CONFIGS["c3"][:4]
 uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
 a = komb_amd.KombAccel(); a.from_edges(nv, uv); del uv

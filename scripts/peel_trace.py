@@ -3,6 +3,7 @@ general engine only (KOMB_FINISH=none), one line per step in gpurun_out/peel_tra
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import komb_amd
+import komb_amd.api; komb_amd.api.FORWARD_ENV_OPTIONS = True   # KOMB_* switches reach the library as per-context options
 import bench
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 if len(sys.argv) > 3:                  # a shape instead of a configuration: nv n_cliques alpha

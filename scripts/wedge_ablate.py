@@ -3,6 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import komb_amd
+import komb_amd.api; komb_amd.api.FORWARD_ENV_OPTIONS = True   # KOMB_* switches reach the library as per-context options
 nv, ncl = 10_000_000, 24_250_000
 uv = komb_amd.gen_hug_edges(nv, ncl, 2.6, 42)
 a = komb_amd.KombAccel(); a.from_edges(nv, uv); del uv

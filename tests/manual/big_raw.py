@@ -7,6 +7,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import komb_amd
+import komb_amd.api; komb_amd.api.FORWARD_ENV_OPTIONS = True   # KOMB_* switches reach the library as per-context options
 
 n_raw = int(sys.argv[1]) if len(sys.argv) > 1 else 1_150_000_000
 nv = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
