@@ -179,6 +179,35 @@ def rccl_main():
     dist.destroy_process_group()
 
 
+def rccl_n_main():
+    """N ranks on N GPUs, backend "nccl" (= RCCL over xGMI): the flow `bench.py --gpus N` runs by default -- the support
+    all-reduce in place on the device buffer + the peel sharded by edge range, one frontier exchange per sub-round through the
+    same callback -- and the sharded k-core, against the oracle on every rank.  Needs one GPU per rank: the test that launches
+    it skips on a one-GPU box."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert dist.get_backend() == "nccl"
+    nv = 60000
+    uv = komb_amd.gen_hug_edges(nv, int(2.6 * nv), 2.6, 11)
+    rowptr, col = O.simplify(nv, uv)
+    otr, ocore = O.trussness(rowptr, col), O.coreness(rowptr, col)
+    with komb_amd.KombAccel(device=local) as a:
+        a.from_edges(nv, uv)
+        for shard_peel in (False, True):
+            kd.truss_run_sharded(a, shard_peel=shard_peel)
+            st = a.stats()
+            assert np.array_equal(a.truss_fetch()[2], otr), f"rank {rank}: trussness (shard_peel={shard_peel})"
+            assert st["ms_allreduce"] > 0 and (st["shard_exchanges"] > 0) == shard_peel
+        kd.core_run_sharded(a)
+        assert np.array_equal(a.core_fetch()[1], ocore), f"rank {rank}: coreness"
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK rccl_n", world)
+    dist.destroy_process_group()
+
+
 def c3_main():
     """BASELINE configs[3]'s code path at the size it is quoted on: the C3 graph (|V|=10M, |E|=100.1M) on two ranks
     sharing GPU 0, komb_truss_run_sharded (support counted per shard, all-reduced over gloo), against the recorded
@@ -328,6 +357,8 @@ def main():
     mode = sys.argv[1]
     if mode == "rccl":
         return rccl_main()
+    if mode == "rccl_n":
+        return rccl_n_main()
     if mode == "c3":
         return c3_main()
     if mode == "peel":

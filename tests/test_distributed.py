@@ -65,6 +65,18 @@ def test_rccl_inplace_branch_single_rank(built):
 
 
 @pytest.mark.gpu
+def test_rccl_two_ranks_on_two_gpus(built):
+    """The default multi-GPU flow (support all-reduce + edge-range sharded peel) and the sharded k-core over RCCL with one GPU
+    per rank, against the oracle on both ranks.  Skips where there is one GPU (this pool's boxes): the one-GPU rehearsals
+    above run the same library code over gloo."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    r = _launch("rccl_n", 2, 29616)
+    assert r.returncode == 0 and "DIST_OK rccl_n 2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_processes_sharing_one_gpu(built):
     """Two processes decomposing at the same time on GPU 0 (scripts/share_stress.py): workgroups of a launch get
     dispatched late when the CUs are busy with somebody else's kernels -- the peel's launch-to-launch hand-over must not
