@@ -40,7 +40,7 @@ def gen_hug_edges(nv, n_cliques, alpha=2.6, seed=42):
 # komb_set_option before every compute call -- the forwarding is test infrastructure, the option mechanism is the ABI's.
 FORWARD_ENV_OPTIONS = False
 OPTION_NAMES = ("FINISH", "LOCAL_LIMIT", "LOCAL_ITEMS", "LOCAL_DENSITY", "LOCAL_DEFER_CHUNKS", "TAIL", "CORE_TAIL", "INDEX",
-                "REC_CAP", "OWN_DENSE_CAP", "NO_OWN_DENSE", "NO_REC_SCRATCH", "NO_FIRST_QUEUE", "FULL_CAPS", "RETIRE_EVERY", "SHARD_ENGINE",
+                "REC_CAP", "OWN_DENSE_CAP", "NO_OWN_DENSE", "NO_REC_SCRATCH", "NO_FIRST_QUEUE", "FULL_CAPS", "PREP_ROW_STAGE", "RETIRE_EVERY", "SHARD_ENGINE",
                 "TRI_DEBUG", "POOL_DEBUG", "BUILD_DEBUG", "LOCAL_DEBUG", "TAIL_DEBUG")
 
 

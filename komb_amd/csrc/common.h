@@ -243,6 +243,9 @@ struct komb_ctx {
     bool truss_done = false;
     int slice_rank = 0, slice_world = 1;     // komb_truss_run_slice: the canonical edges whose results this run materialises
     bool shard_peel = false;                 // komb_set_shard_peel: sharded runs split the peel too (shard_dev.h)
+    // what the record stream of the last k-truss run on a graph of this size turned out to need (ktruss.hip): a graph with more
+    // than two triangles per edge pays the second enumeration once per graph, not once per run
+    struct { int64_t nv = -1, m = -1; unsigned long long own_cap = 0, rec_cap = 0; } cap_hint;
 
     // ---- pinned host mirrors of the control blocks (double buffered)
     komb::PeelCtrl *h_ctrl = nullptr;        // [2]

@@ -290,6 +290,7 @@ void graph_free(komb_ctx *ctx)
     for (void *p : all) if (p) (void)hipFree(p);
     ctx->d_o_rowptr = nullptr; ctx->d_o_col = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
+    ctx->cap_hint.nv = -1; ctx->cap_hint.m = -1;
     ctx->pool.clear();                                   // scratch sized for the old graph
 }
 

@@ -454,6 +454,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         if (ctx_flag(ctx, "NO_OWN_DENSE")) { own_cap = 1; rec_cap = rec_full; fixed_caps = true; }      // (tests: every entry a record)
         if (const char *rc = ctx_opt(ctx, "REC_CAP")) { rec_cap = strtoull(rc, nullptr, 10) + 1; fixed_caps = true; }
         if (ctx_flag(ctx, "FULL_CAPS")) { own_cap = own_full; rec_cap = rec_full; }                     // (the bounds at once, as rounds 3-4 did)
+        if (!fixed_caps && ctx->cap_hint.nv == nv && ctx->cap_hint.m == m) {                            // what this graph needed last time
+            own_cap = std::min(own_full, std::max(own_cap, ctx->cap_hint.own_cap));
+            rec_cap = std::min(rec_full, std::max(rec_cap, ctx->cap_hint.rec_cap));
+        }
         // keys of unused record positions: above every edge id, their bin field taken from the position (they spread over the bins)
         const uint32_t sentinel = geom.sentinel_base();
         uint32_t *d_key = nullptr; int2 *d_val = nullptr;
@@ -488,7 +492,10 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
             if (ctx_flag(ctx, "TRI_DEBUG"))
                 fprintf(stderr, "komb triangles: stream build (attempt %d): %llu record positions claimed of %llu, dense own-role region %llu entries claimed of %llu, %llu task ranges overflowed their record buffer\n",
                         attempt, dc[2], rec_cap, dc[0], own_cap, dc[1]);
-            if (n_claimed <= rec_cap) break;                         // every record is there (a dense region that ran out only made more of them)
+            if (n_claimed <= rec_cap) {                              // every record is there (a dense region that ran out only made more of them)
+                if (!fixed_caps) { ctx->cap_hint.nv = nv; ctx->cap_hint.m = m; ctx->cap_hint.own_cap = own_cap; ctx->cap_hint.rec_cap = rec_cap; }
+                break;
+            }
             ok = false;                                              // the stream ran out: records were dropped
             if (attempt == 1 || fixed_caps) break;
             // once more, with what this attempt asked for: the dense region it claimed (all of it this time, so fewer records than

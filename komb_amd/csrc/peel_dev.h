@@ -244,8 +244,14 @@ __device__ __forceinline__ void stage_push(WaveStage &st, bool is_light, bool is
 
 // ------------------------------------------------------- step planning / finalisation
 constexpr uint32_t kSmallScan = 16384;          // a live list this short is scanned by one workgroup
-constexpr uint32_t kSmallLight = 64;            // a frontier this small (and <= kSmallHeavy chunks) is one workgroup's step
-constexpr uint32_t kSmallHeavy = 4;
+#ifndef KOMB_SMALL_LIGHT
+#define KOMB_SMALL_LIGHT 64
+#endif
+#ifndef KOMB_SMALL_HEAVY
+#define KOMB_SMALL_HEAVY 4
+#endif
+constexpr uint32_t kSmallLight = KOMB_SMALL_LIGHT;   // a frontier this small (and <= kSmallHeavy chunks) is one workgroup's step
+constexpr uint32_t kSmallHeavy = KOMB_SMALL_HEAVY;
 constexpr uint32_t kMaxInKernelSteps = 8192;    // bound on steps one launch may chain
 
 // How many workgroups take part in the step described by cv, and the light batch width.

@@ -193,15 +193,20 @@ __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__r
     }
 }
 
-// ---- 3. d+(v) = the edges v kept itself + the edges it was given; by internal id, for the scan
+// ---- 3. d+(v) = the edges v kept itself + the edges it was given; by internal id, for the scan -- and, also by internal id, where
+// step 4 finds the two parts of the vertex' list: { start of the front part, its length, start of the back part } (one
+// coalesced 16-byte read per row there instead of four gathers through i2o)
 __global__ __launch_bounds__(kBlock) void k_prep_dplus(const uint32_t *__restrict__ rowptr, int64_t nv, const int32_t *__restrict__ o2i,
                                                        const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
-                                                       uint32_t *__restrict__ dplus_i, unsigned long long *__restrict__ own_bound)
+                                                       uint32_t *__restrict__ dplus_i, uint4 *__restrict__ where_i, unsigned long long *__restrict__ own_bound)
 {
     unsigned long long ob = 0;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
-        const unsigned long long d = nlocal[v] + (rowptr[v + 1] - 1u - backcur[v]);
-        dplus_i[o2i[v]] = (uint32_t)d;
+        const uint32_t nl = nlocal[v], bk = backcur[v] + 1u;
+        const unsigned long long d = nl + (rowptr[v + 1] - bk);
+        const int32_t a = o2i[v];
+        dplus_i[a] = (uint32_t)d;
+        where_i[a] = make_uint4(rowptr[v], nl, bk, 0u);
         ob += d ? d * (d - 1ull) : 0ull;
     }
     block_add_u64(ob, own_bound);
@@ -210,8 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_dplus(const uint32_t *__restric
 // ---- 4. the oriented rows.  A wavefront takes 64 consecutive INTERNAL vertices; their lists (step 2: nlocal entries at the
 // front of the vertex' region, the rest behind its back cursor) are read into LDS in batches of <= kRowCap entries (whole
 // rows), every entry is ranked among its row's by counting, and leaves as the row's rank-th slot.
-__global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict__ orow, int64_t nv, const int32_t *__restrict__ i2o,
-                                                      const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
+__global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict__ orow, int64_t nv, const uint4 *__restrict__ where_i,
                                                       const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
                                                       uint32_t *__restrict__ canon2e, uint4 *__restrict__ line)
 {
@@ -232,12 +236,12 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
         const bool has = a < nv;
         const uint32_t ob = has ? orow[a] : 0u, d = has ? orow[a + 1] - ob : 0u;
         const bool big = d > kRowCap;
-        const int32_t v = has ? i2o[a] : 0;
+        const uint4 wh = has ? where_i[a] : make_uint4(0u, 0u, 0u, 0u);
         const uint32_t len = big ? 0u : d;
         __builtin_amdgcn_wave_barrier();
-        s_rp[lane] = has ? rowptr[v] : 0u;
-        s_nl[lane] = has ? nlocal[v] : 0u;
-        s_bk[lane] = has ? backcur[v] + 1u : 0u;                   // the first entry v was given
+        s_rp[lane] = wh.x;                                         // the vertex' own edges: tmp[wh.x .. + wh.y)
+        s_nl[lane] = wh.y;
+        s_bk[lane] = wh.z;                                         // the edges it was given: tmp[wh.z ..)
         s_ob[lane] = ob;
 #pragma unroll
         for (int x = 0; x < kSigBlocks; ++x) s_sig[lane][x] = 0ull;
@@ -294,22 +298,22 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
 // the oriented rows beyond kRowCap entries, a workgroup each: the same rank count, over LDS up to kRowStage entries, over
 // global memory beyond (quadratic in a row that long: a graph with such rows is far beyond the index's triangle limit)
 __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__restrict__ hlist, const uint32_t *__restrict__ hcount,
-                                                            const uint32_t *__restrict__ orow, const int32_t *__restrict__ i2o,
-                                                            const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
+                                                            const uint32_t *__restrict__ orow, const uint4 *__restrict__ where_i,
                                                             const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
-                                                            uint32_t *__restrict__ canon2e, uint4 *__restrict__ line)
+                                                            uint32_t *__restrict__ canon2e, uint4 *__restrict__ line, uint32_t stage_cap)
 {
+    // stage_cap: rows up to this many entries are ranked out of LDS (kRowStage; less only in tests: option PREP_ROW_STAGE)
     __shared__ int32_t sh_b[kRowStage];
     __shared__ unsigned long long sh_sig[kSigBlocks];
     __shared__ int32_t sh_piv[kPivots];
     const uint32_t n = *hcount;
     for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
         const uint32_t a = hlist[h], ob = orow[a], d = orow[a + 1] - ob;
-        const int32_t v = i2o[a];
-        const uint32_t nl = nlocal[v];
-        const uint2 *front = tmp + rowptr[v], *back = tmp + (backcur[v] + 1u);
+        const uint4 wh = where_i[a];
+        const uint32_t nl = wh.y;
+        const uint2 *front = tmp + wh.x, *back = tmp + wh.z;
         auto entry = [&](uint32_t i) -> uint2 { return i < nl ? front[i] : back[i - nl]; };
-        const bool staged = d <= kRowStage;
+        const bool staged = d <= stage_cap;
         __syncthreads();
         if (threadIdx.x < (uint32_t)kSigBlocks) sh_sig[threadIdx.x] = 0ull;
         if (threadIdx.x < (uint32_t)kPivots) sh_piv[threadIdx.x] = 0x7FFFFFFF;
@@ -522,6 +526,7 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     DevBufs bufs(ctx);
     uint32_t *d_dk[2] = {nullptr, nullptr}, *d_dv[2] = {nullptr, nullptr}, *d_fu = nullptr, *d_uc = nullptr, *d_ebase = nullptr, *d_dplus = nullptr;
     uint32_t *d_nlocal = nullptr, *d_backcur = nullptr;
+    uint4 *d_where = nullptr;
     uint32_t *d_tcnt = nullptr, *d_hlist = nullptr, *d_words = nullptr;
     unsigned long long *d_acc = nullptr;                             // [0] own bound, [1..4] what the host reads back
     uint2 *d_tmp = nullptr;
@@ -532,6 +537,7 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     KOMB_HIP(ctx, bufs.alloc(&d_dplus, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_nlocal, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_backcur, (size_t)nv));
+    KOMB_HIP(ctx, bufs.alloc(&d_where, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_tcnt, (size_t)nv + 1));
     const uint32_t hcap = (uint32_t)(ne / kRowCap + 64);
     KOMB_HIP(ctx, bufs.alloc(&d_hlist, (size_t)hcap));
@@ -557,7 +563,7 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     if (nv > 0) {
         k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_tmp, d_nlocal, d_backcur, P.ceu, P.cev);
         k_prep_kept_heavy<<<512, kPrepHB, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_tmp, d_nlocal, d_backcur, P.ceu, P.cev);
-        k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(rowptr, nv, P.o2i, d_nlocal, d_backcur, d_dplus, d_acc);
+        k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(rowptr, nv, P.o2i, d_nlocal, d_backcur, d_dplus, d_where, d_acc);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_dplus, P.orow, nv + 1));
     KOMB_HIP(ctx, hipEventRecord(ev[2], s));
@@ -566,8 +572,10 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     k_task_count<<<gv, kBlock, 0, s>>>(P.orow, nv, group, d_tcnt, d_hlist, d_words, hcap);
     // 4. oriented rows, lines, the canonical map
     if (nv > 0) {
-        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, P.i2o, rowptr, d_nlocal, d_backcur, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
-        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, P.i2o, rowptr, d_nlocal, d_backcur, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
+        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, d_where, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
+        uint32_t stage_cap = kRowStage;
+        if (const char *e = ctx_opt(ctx, "PREP_ROW_STAGE")) stage_cap = std::min<uint32_t>(kRowStage, (uint32_t)strtoul(e, nullptr, 10));   // (tests: the unstaged path)
+        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, d_where, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline, stage_cap);
     }
     KOMB_HIP(ctx, hipEventRecord(ev[3], s));
     // 5b. tasks

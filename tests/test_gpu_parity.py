@@ -506,6 +506,40 @@ def test_truss_preparation_lifecycle(K, O):
             a.truss_run()
 
 
+def test_preparation_long_rows(K, O, monkeypatch):
+    """The preparation's workgroup paths (truss_prep.hip): oriented rows beyond one wavefront's 1024-entry sort (K_1500: rows of
+    up to 1499 entries, ranked out of LDS by a workgroup -- and, with the staging switched off, out of global memory), symmetric
+    rows beyond 2048 slots (a hub: walked by a workgroup, nearly all of its edges handed to other rows through their back
+    cursors), and the same rows inside an induced subgraph."""
+    n = 1500
+    uv = np.stack(np.triu_indices(n, 1), axis=1).astype(np.int64)
+    for stage in (None, "100"):
+        if stage: monkeypatch.setenv("KOMB_PREP_ROW_STAGE", stage)
+        with K.KombAccel() as a:
+            a.from_edges(n, uv)
+            eu, ev, tr, sup = a.run_truss(with_support=True)
+            assert np.all(sup == n - 2) and np.all(tr == n) and a.stats()["triangles"] == n * (n - 1) * (n - 2) // 6
+            assert np.array_equal(eu, uv[:, 0]) and np.array_equal(ev, uv[:, 1])            # canonical order = the generator's
+        monkeypatch.delenv("KOMB_PREP_ROW_STAGE", raising=False)
+    # a hub with 6000 neighbours, 3000 of which form a clique chain among themselves; mask = hub + the chain
+    rng = np.random.default_rng(8)
+    hubn = 6000
+    star = np.stack([np.zeros(hubn, np.int64), np.arange(1, hubn + 1)], axis=1)
+    chain = np.concatenate([np.stack(np.triu_indices(30, 1), axis=1) + 1 + 25 * i for i in range(110)])
+    noise = rng.integers(1, hubn + 1, (20000, 2))
+    uv = np.concatenate([star, chain, noise]).astype(np.int64)
+    nv = hubn + 1
+    o_rowptr, o_col = O.simplify(nv, uv)
+    with K.KombAccel() as a:
+        a.from_edges(nv, uv)
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        assert np.array_equal(sup, O.support(o_rowptr, o_col)[0]) and np.array_equal(tr, O.trussness(o_rowptr, o_col))
+        mask = np.zeros(nv, np.uint8); mask[:3000] = 1
+        seu, sev, stra = a.run_truss(mask)
+        weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
+        assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+
+
 def test_retire_step_due_at_a_refused_hand_over(K, O, monkeypatch):
     """Regression test for commit 9b51a4a (round 4's last engine fix): a RETIRE step that falls due exactly when the remainder
     is offered to the local finish must stay pending when the finish REFUSES the offer (KOMB_LOCAL_ITEMS=0 refuses every one)
