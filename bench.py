@@ -58,14 +58,14 @@ def algorithmic_bytes(st):
     # the canonical edge list, the canonical map, one 64-byte line and two id maps per vertex
     prep_vertex = 4 * V + 3 * 2 * 8 * V + 8 * V         # row pointers in; three radix passes over (degree, id) pairs, read + write; two id maps out
     prep_edges = (4 * V + 4 * E) + 8 * E + 8 * E        # the upper half of the CSR in; the canonical edge list and one (id, canonical id) pair per edge out
-    prep_rows = 8 * E + 8 * E + 4 * E + 64 * V          # the pairs in; oriented targets + sources, the canonical map and one 64-byte line per vertex out
+    prep_rows = 8 * E + 8 * E + 4 * E + 64 * V          # the pairs in; oriented targets + sources, every slot's canonical id and one 64-byte line per vertex out
     prepare = prep_vertex + prep_edges + prep_rows
     tri_count = 12 * E + 4 * O + 24 * T                 # SURVEY 8(d) B_sup
     peel = 8 * E + 24 * T + 24 * T + 16 * T             # truss+stamp per edge; slice entries; two stamps per entry; 2 RMW per triangle
     survey_peel = 8 * E + 4 * st["sum_deg_sq"] + 16 * T # SURVEY 8(d) B_peel (merge re-intersection; not what we do)
     sort = 2 * 2 * 12 * R                               # the passes that run: two radix passes over 12-byte records, read + write
     finish = 16 * E + 48 * T + 4 * R                    # supports and slice pairs; every entry in once (record or block entry), out once
-    gather = 20 * E + 20 * E                            # resolve: stamp + slice pair in, (trussness, support) out; gather: map + pair in, two words out
+    gather = 24 * E                                     # one pass: stamp, slice pair and canonical id in; the initial support (by internal id) and the trussness (at its canonical id) out
     return {"prepare": prepare, "prep_vertex": prep_vertex, "prep_edges": prep_edges, "prep_rows": prep_rows, "tri_count": tri_count, "peel": peel, "survey_peel": survey_peel,
             "sort": sort, "finish": finish, "gather": gather}
 
@@ -484,8 +484,8 @@ def main():
             kernels["k_bin_offsets + k_bin_count + k_bin_finish"] = (phase["ms_compact"], 3, ab["finish"])
         else:
             kernels["k_triangles<single> (exact slices)"] = (phase["ms_tri_fill"], 1, ab["tri_count"])
-        # (sliced runs: the resolve pass covers every edge, the gather this rank's slice)
-        kernels["k_truss_resolve + k_gather_canonical"] = (phase["ms_gather"], 2, ab["gather"] // 2 + ab["gather"] // 2 // (world if sliced else 1))
+        # (sliced runs: the pass covers every edge, its stores this rank's slice)
+        kernels["k_truss_results"] = (phase["ms_gather"], 1, ab["gather"])
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, nbytes = kernels[dom]
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

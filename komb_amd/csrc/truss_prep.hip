@@ -44,15 +44,13 @@ constexpr int kPrepU = 4;                       // trips of a wavefront whose lo
 // ---- 1. degrees as sort keys; first upper slot (column above row) of every row and how many there are
 __global__ __launch_bounds__(kBlock) void k_prep_vertex(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                         uint32_t *__restrict__ dkey, uint32_t *__restrict__ dval,
-                                                        uint32_t *__restrict__ first_upper, uint32_t *__restrict__ upper_cnt,
-                                                        uint32_t *__restrict__ backcur)
+                                                        uint32_t *__restrict__ first_upper, uint32_t *__restrict__ upper_cnt)
 {
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v <= nv; v += (int64_t)gridDim.x * kBlock) {
         if (v == nv) { upper_cnt[v] = 0u; continue; }
         const uint32_t b = rowptr[v], e = rowptr[v + 1];
         dkey[v] = e - b;
         dval[v] = (uint32_t)v;
-        backcur[v] = e - 1u;                                      // the last position of v's region: counted DOWN by the edges v is given
         uint32_t lo = b, hi = e;                                  // first slot with col > v (rows hold no loops)
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -63,12 +61,20 @@ __global__ __launch_bounds__(kBlock) void k_prep_vertex(const uint32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_prep_invert(const uint32_t *__restrict__ sorted_ids, int64_t nv, int32_t *__restrict__ i2o, int32_t *__restrict__ o2i)
+// ... and every vertex' REGION of the scratch array step 2 fills: d(v) entries at regbase[rank of v] (the exclusive scan of the
+// sorted degrees), i.e. the regions follow each other in INTERNAL order -- step 4 walks internal vertices and reads them as a
+// stream (with the regions where the symmetric CSR has the rows, step 4 spent 1.3 of its 2.6 ms on two random places per row)
+__global__ __launch_bounds__(kBlock) void k_prep_invert(const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ sorted_deg,
+                                                        const uint32_t *__restrict__ regbase, int64_t nv, int32_t *__restrict__ i2o, int32_t *__restrict__ o2i,
+                                                        uint32_t *__restrict__ regstart, uint32_t *__restrict__ backcur)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
         const uint32_t v = sorted_ids[i];
         i2o[i] = (int32_t)v;
         o2i[v] = (int32_t)i;
+        const uint32_t r0 = regbase[i];
+        regstart[v] = r0;
+        backcur[v] = r0 + sorted_deg[i] - 1u;                     // the last position of v's region: counted DOWN by the edges v is given
     }
 }
 
@@ -83,12 +89,12 @@ __device__ __forceinline__ int owner_of(const uint32_t *s_end, uint32_t it)
 
 // ---- 2. every canonical edge to the row of its lower-rank endpoint.  A wavefront takes 64 consecutive ORIGINAL vertices; the
 // UPPER parts of their rows (columns above the row: the canonical edges, ids ebase[v] + offset) are flattened over the lanes.
-// Edge (v, w): a = o2i[v], b = o2i[w] (the one gather).  b > a: the oriented edge a -> b is v's: tmp[rowptr[v] + r] = (b, k),
+// Edge (v, w): a = o2i[v], b = o2i[w] (the one gather).  b > a: the oriented edge a -> b is v's: tmp[regstart[v] + r] = (b, k),
 // r = v's running count.  b < a: it is w's: tmp[backcur[w]--] = (a, k).
 __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                       const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
-                                                      uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur,
-                                                      int32_t *__restrict__ ceu, int32_t *__restrict__ cev)
+                                                      const uint32_t *__restrict__ regstart,
+                                                      uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur)
 {
     __shared__ uint32_t sh_end[kPW][kWave], sh_beg[kPW][kWave], sh_a[kPW][kWave], sh_rp[kPW][kWave], sh_eb[kPW][kWave], sh_cnt[kPW][kWave];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
         __builtin_amdgcn_wave_barrier();
         s_end[lane] = incl;
         s_beg[lane] = up;
-        s_rp[lane] = beg;
+        s_rp[lane] = has ? regstart[v] : 0u;                        // v's region of tmp
         s_a[lane] = has ? (uint32_t)o2i[v] : 0u;
         s_eb[lane] = has ? ebase[v] : 0u;
         s_cnt[lane] = 0u;
@@ -136,7 +142,6 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
                 const uint32_t a = s_a[tt];
                 const uint32_t k = s_eb[tt] + (it - rowstart[u]);   // the canonical id of (v, w)
                 const bool mine = on[u] && b[u] > a, theirs = on[u] && b[u] < a;
-                if (on[u]) { ceu[k] = (int32_t)(v0 + tt); cev[k] = wv[u]; }
                 if (theirs) tmp[atomicSub(&backcur[wv[u]], 1u)] = make_uint2(a, k);
                 const uint64_t K = __ballot(mine);
                 const uint32_t f = rowstart[u] > base ? rowstart[u] - base : 0u;      // the lane where row tt starts in this trip (<= lane)
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
 __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                              const uint32_t *__restrict__ sorted_deg, const int32_t *__restrict__ i2o,
                                                              const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
-                                                             uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur,
-                                                             int32_t *__restrict__ ceu, int32_t *__restrict__ cev)
+                                                             const uint32_t *__restrict__ regstart,
+                                                             uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur)
 {
     __shared__ uint32_t sh_wc[kPrepHB / kWave];
     const int lane = lane_id(), wv_ = (int)(threadIdx.x >> 6);
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__r
         const uint32_t deg = sorted_deg[a];
         if (deg <= kPrepHeavy) break;                              // (uniform: every thread read the same word)
         const int32_t v = i2o[a];
-        const uint32_t beg = rowptr[v], end = beg + deg, fuv = fu[v], eb = ebase[v];
+        const uint32_t beg = rowptr[v], end = beg + deg, fuv = fu[v], eb = ebase[v], reg = regstart[v];
         uint32_t run = 0;
         for (uint32_t j0 = fuv; j0 < end; j0 += kPrepHB) {
             const uint32_t j = j0 + threadIdx.x;
@@ -177,7 +182,6 @@ __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__r
             const uint32_t b = active ? (uint32_t)o2i[wv] : 0u;
             const bool mine = active && b > (uint32_t)a, theirs = active && b < (uint32_t)a;
             const uint32_t k = eb + (j - fuv);
-            if (active) { ceu[k] = v; cev[k] = wv; }
             if (theirs) tmp[atomicSub(&backcur[wv], 1u)] = make_uint2((uint32_t)a, k);
             const uint64_t K = __ballot(mine);
             __syncthreads();
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__r
             uint32_t before = 0, all = 0;
 #pragma unroll
             for (int x = 0; x < kPrepHB / kWave; ++x) { const uint32_t c = sh_wc[x]; if (x < wv_) before += c; all += c; }
-            if (mine) tmp[(size_t)beg + run + before + (uint32_t)__popcll(K & lanemask_lt())] = make_uint2(b, k);
+            if (mine) tmp[(size_t)reg + run + before + (uint32_t)__popcll(K & lanemask_lt())] = make_uint2(b, k);
             run += all;
         }
         if (threadIdx.x == 0) nlocal[v] = run;
@@ -197,16 +201,17 @@ __global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__r
 // step 4 finds the two parts of the vertex' list: { start of the front part, its length, start of the back part } (one
 // coalesced 16-byte read per row there instead of four gathers through i2o)
 __global__ __launch_bounds__(kBlock) void k_prep_dplus(const uint32_t *__restrict__ rowptr, int64_t nv, const int32_t *__restrict__ o2i,
+                                                       const uint32_t *__restrict__ regstart,
                                                        const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
                                                        uint32_t *__restrict__ dplus_i, uint4 *__restrict__ where_i, unsigned long long *__restrict__ own_bound)
 {
     unsigned long long ob = 0;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
-        const uint32_t nl = nlocal[v], bk = backcur[v] + 1u;
-        const unsigned long long d = nl + (rowptr[v + 1] - bk);
+        const uint32_t nl = nlocal[v], bk = backcur[v] + 1u, reg = regstart[v];
+        const unsigned long long d = nl + (reg + (rowptr[v + 1] - rowptr[v]) - bk);
         const int32_t a = o2i[v];
         dplus_i[a] = (uint32_t)d;
-        where_i[a] = make_uint4(rowptr[v], nl, bk, 0u);
+        where_i[a] = make_uint4(reg, nl, bk, 0u);
         ob += d ? d * (d - 1ull) : 0ull;
     }
     block_add_u64(ob, own_bound);
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_dplus(const uint32_t *__restric
 // rows), every entry is ranked among its row's by counting, and leaves as the row's rank-th slot.
 __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict__ orow, int64_t nv, const uint4 *__restrict__ where_i,
                                                       const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
-                                                      uint32_t *__restrict__ canon2e, uint4 *__restrict__ line)
+                                                      uint32_t *__restrict__ e2k, uint4 *__restrict__ line)
 {
     __shared__ int32_t sh_b[kPW][kRowCap];
     __shared__ uint32_t sh_kk[kPW][kRowCap];
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
                 const uint32_t e = s_ob[t] + rank;
                 ocol[e] = mine;
                 osrc[e] = (int32_t)(a0 + t);
-                canon2e[s_kk[k]] = e;
+                e2k[e] = s_kk[k];
                 uint32_t blk; unsigned long long mask;
                 sig_slot(mine, blk, mask);
                 atomicOr(&s_sig[t][blk], mask);
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
 __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__restrict__ hlist, const uint32_t *__restrict__ hcount,
                                                             const uint32_t *__restrict__ orow, const uint4 *__restrict__ where_i,
                                                             const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
-                                                            uint32_t *__restrict__ canon2e, uint4 *__restrict__ line, uint32_t stage_cap)
+                                                            uint32_t *__restrict__ e2k, uint4 *__restrict__ line, uint32_t stage_cap)
 {
     // stage_cap: rows up to this many entries are ranked out of LDS (kRowStage; less only in tests: option PREP_ROW_STAGE)
     __shared__ int32_t sh_b[kRowStage];
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__re
             const uint32_t e = ob + rank;
             ocol[e] = mine;
             osrc[e] = (int32_t)a;
-            canon2e[ent.y] = e;
+            e2k[e] = ent.y;
             uint32_t blk; unsigned long long mask;
             sig_slot(mine, blk, mask);
             atomicOr(&sh_sig[blk], mask);
@@ -468,10 +473,24 @@ __global__ __launch_bounds__(kBlock) void k_induce(const uint32_t *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_map_edges(const int32_t *__restrict__ vold, const int32_t *__restrict__ eu, const int32_t *__restrict__ ev, int64_t m,
-                                                      int32_t *__restrict__ out_u, int32_t *__restrict__ out_v)
+// the canonical edge list of a symmetric CSR: edge k = the k-th upper slot (column above row) in row order, endpoints through
+// `vold` when the CSR is an induced subgraph's (new -> original ids).  What igraph_edge answers after igraph_trussness
+// (reference src/graph.cpp:529-532): made when the endpoints are asked for, not inside the timed call.  A wavefront per row.
+__global__ __launch_bounds__(kBlock) void k_edge_list(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
+                                                      const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase, const int32_t *__restrict__ vold,
+                                                      int32_t *__restrict__ eu, int32_t *__restrict__ ev)
 {
-    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < m; k += (int64_t)gridDim.x * kBlock) { out_u[k] = vold[eu[k]]; out_v[k] = vold[ev[k]]; }
+    const int lane = lane_id();
+    const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t v = gw; v < nv; v += nw) {
+        const uint32_t j0 = fu[v], j1 = rowptr[v + 1], k0 = ebase[v];
+        const int32_t uo = vold ? vold[v] : (int32_t)v;
+        for (uint32_t j = j0 + (uint32_t)lane; j < j1; j += kWave) {
+            const int32_t w = col[j];
+            eu[k0 + (j - j0)] = uo;
+            ev[k0 + (j - j0)] = vold ? vold[w] : w;
+        }
+    }
 }
 
 inline int id_bits(int64_t nv)
@@ -490,7 +509,7 @@ template <class T> hipError_t pool_get(komb_ctx *ctx, T **out, size_t count)
 
 void prep_free(komb_ctx *ctx, TrussPrep *p)
 {
-    void *all[] = {p->o2i, p->i2o, p->orow, p->ocol, p->osrc, p->ceu, p->cev, p->canon2e, p->vline, p->wtasks};
+    void *all[] = {p->o2i, p->i2o, p->orow, p->ocol, p->osrc, p->e2k, p->vline, p->wtasks};
     for (void *q : all) ctx->pool.put(q);
     *p = TrussPrep{};
 }
@@ -513,9 +532,7 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     KOMB_HIP(ctx, pool_get(ctx, &P.orow, (size_t)nv + 1));
     KOMB_HIP(ctx, pool_get(ctx, &P.ocol, (size_t)ne + 8));           // + 8: the enumeration and line_find read 16 bytes at a time, past the end of the last row
     KOMB_HIP(ctx, pool_get(ctx, &P.osrc, (size_t)ne));
-    KOMB_HIP(ctx, pool_get(ctx, &P.ceu, (size_t)ne));
-    KOMB_HIP(ctx, pool_get(ctx, &P.cev, (size_t)ne));
-    KOMB_HIP(ctx, pool_get(ctx, &P.canon2e, (size_t)ne));
+    KOMB_HIP(ctx, pool_get(ctx, &P.e2k, (size_t)ne));
     KOMB_HIP(ctx, pool_get(ctx, &P.vline, 4 * (size_t)nv));
     // the task table's size is known on the device only: room for the most it can be (a start per vertex, a row of d slots in
     // at most d / 64 + 1 parts); what is not used is never touched
@@ -525,7 +542,7 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
 
     DevBufs bufs(ctx);
     uint32_t *d_dk[2] = {nullptr, nullptr}, *d_dv[2] = {nullptr, nullptr}, *d_fu = nullptr, *d_uc = nullptr, *d_ebase = nullptr, *d_dplus = nullptr;
-    uint32_t *d_nlocal = nullptr, *d_backcur = nullptr;
+    uint32_t *d_nlocal = nullptr, *d_backcur = nullptr, *d_regbase = nullptr, *d_regstart = nullptr;
     uint4 *d_where = nullptr;
     uint32_t *d_tcnt = nullptr, *d_hlist = nullptr, *d_words = nullptr;
     unsigned long long *d_acc = nullptr;                             // [0] own bound, [1..4] what the host reads back
@@ -538,6 +555,8 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     KOMB_HIP(ctx, bufs.alloc(&d_nlocal, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_backcur, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_where, (size_t)nv));
+    KOMB_HIP(ctx, bufs.alloc(&d_regbase, (size_t)nv + 1));
+    KOMB_HIP(ctx, bufs.alloc(&d_regstart, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_tcnt, (size_t)nv + 1));
     const uint32_t hcap = (uint32_t)(ne / kRowCap + 64);
     KOMB_HIP(ctx, bufs.alloc(&d_hlist, (size_t)hcap));
@@ -551,19 +570,20 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     const int gv = grid_for(nv + 1);
     const int gwave = grid_for((nv + kWave - 1) / kWave, kPW, 256 * 8);
     // 1. vertices by (degree, original id): a degree is below nv, so the sort looks at that many bits only
-    k_prep_vertex<<<gv, kBlock, 0, s>>>(rowptr, col, nv, d_dk[0], d_dv[0], d_fu, d_uc, d_backcur);
+    k_prep_vertex<<<gv, kBlock, 0, s>>>(rowptr, col, nv, d_dk[0], d_dv[0], d_fu, d_uc);
     uint32_t *sk = d_dk[0], *sv = d_dv[0];
     if (nv > 0) {
         KOMB_TRY(prim_sort_pairs_u32_u32(ctx, d_dk[0], d_dk[1], d_dv[0], d_dv[1], nv, id_bits(nv), &sk, &sv));
-        k_prep_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, nv, P.i2o, P.o2i);
+        KOMB_TRY(prim_exclusive_sum_u32(ctx, sk, d_regbase, nv));                   // the scratch regions, in internal order (the last one ends at ns)
+        k_prep_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, sk, d_regbase, nv, P.i2o, P.o2i, d_regstart, d_backcur);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_uc, d_ebase, nv + 1));
     KOMB_HIP(ctx, hipEventRecord(ev[1], s));
     // 2. every canonical edge to the row of its lower-rank endpoint; the canonical edge list; 3. d+ and the oriented row pointers
     if (nv > 0) {
-        k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_tmp, d_nlocal, d_backcur, P.ceu, P.cev);
-        k_prep_kept_heavy<<<512, kPrepHB, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_tmp, d_nlocal, d_backcur, P.ceu, P.cev);
-        k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(rowptr, nv, P.o2i, d_nlocal, d_backcur, d_dplus, d_where, d_acc);
+        k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_regstart, d_tmp, d_nlocal, d_backcur);
+        k_prep_kept_heavy<<<512, kPrepHB, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_regstart, d_tmp, d_nlocal, d_backcur);
+        k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(rowptr, nv, P.o2i, d_regstart, d_nlocal, d_backcur, d_dplus, d_where, d_acc);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_dplus, P.orow, nv + 1));
     KOMB_HIP(ctx, hipEventRecord(ev[2], s));
@@ -572,10 +592,10 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     k_task_count<<<gv, kBlock, 0, s>>>(P.orow, nv, group, d_tcnt, d_hlist, d_words, hcap);
     // 4. oriented rows, lines, the canonical map
     if (nv > 0) {
-        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, d_where, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline);
+        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, d_where, d_tmp, P.ocol, P.osrc, P.e2k, P.vline);
         uint32_t stage_cap = kRowStage;
         if (const char *e = ctx_opt(ctx, "PREP_ROW_STAGE")) stage_cap = std::min<uint32_t>(kRowStage, (uint32_t)strtoul(e, nullptr, 10));   // (tests: the unstaged path)
-        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, d_where, d_tmp, P.ocol, P.osrc, P.canon2e, P.vline, stage_cap);
+        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, d_where, d_tmp, P.ocol, P.osrc, P.e2k, P.vline, stage_cap);
     }
     KOMB_HIP(ctx, hipEventRecord(ev[3], s));
     // 5b. tasks
@@ -677,10 +697,17 @@ int induce_csr(komb_ctx *ctx, const uint8_t *vmask_host, InducedCsr *out)
     return KOMB_OK;
 }
 
-int map_edges(komb_ctx *ctx, const int32_t *vold, const int32_t *eu, const int32_t *ev, int64_t m, int32_t *out_u, int32_t *out_v)
+int edge_list(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_t nv, const int32_t *vold, int32_t *eu, int32_t *ev)
 {
-    if (m > 0) k_map_edges<<<grid_for(m), kBlock, 0, ctx->stream>>>(vold, eu, ev, m, out_u, out_v);
-    KOMB_HIP(ctx, hipGetLastError());
+    hipStream_t s = ctx->stream;
+    DevBufs bufs(ctx);
+    uint32_t *d_dk = nullptr, *d_dv = nullptr, *d_fu = nullptr, *d_uc = nullptr, *d_ebase = nullptr;
+    KOMB_HIP(ctx, bufs.alloc(&d_dk, (size_t)nv)); KOMB_HIP(ctx, bufs.alloc(&d_dv, (size_t)nv));
+    KOMB_HIP(ctx, bufs.alloc(&d_fu, (size_t)nv + 1)); KOMB_HIP(ctx, bufs.alloc(&d_uc, (size_t)nv + 1)); KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
+    k_prep_vertex<<<grid_for(nv + 1), kBlock, 0, s>>>(rowptr, col, nv, d_dk, d_dv, d_fu, d_uc);
+    KOMB_TRY(prim_exclusive_sum_u32(ctx, d_uc, d_ebase, nv + 1));
+    if (nv > 0) k_edge_list<<<grid_for(nv, kPW, 256 * 8), kBlock, 0, s>>>(rowptr, col, nv, d_fu, d_ebase, vold, eu, ev);
+    KOMB_HIP(ctx, hipStreamSynchronize(s));                          // (the scratch goes back to the pool when this returns)
     return KOMB_OK;
 }
 

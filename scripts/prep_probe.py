@@ -16,7 +16,7 @@ for i in range(reps):
     a.truss_unprepare()
     t0 = time.perf_counter(); a.truss_run(); t1 = time.perf_counter()
     s = a.stats()
-    print(f"cold step {i}: wall {1e3*(t1-t0):.2f} ms; prepare {s['ms_prepare']:.2f} enum {s['ms_tri_fill']:.2f} sort {s['ms_sort']:.2f} finish {s['ms_compact']:.2f} "
+    print(f"cold step {i}: wall {1e3*(t1-t0):.2f} ms; prepare {s['ms_prepare']:.2f} (vertex {s['ms_prep_vertex']:.2f} edges {s['ms_prep_edges']:.2f} rows {s['ms_prep_rows']:.2f}) enum {s['ms_tri_fill']:.2f} sort {s['ms_sort']:.2f} finish {s['ms_compact']:.2f} "
           f"peel {s['ms_peel']:.2f} gather {s['ms_gather']:.2f}; T={s['triangles']} tmax={s['max_trussness']}", flush=True)
 for i in range(reps):
     t0 = time.perf_counter(); a.truss_run(); t1 = time.perf_counter()
