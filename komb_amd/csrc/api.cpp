@@ -188,7 +188,7 @@ int komb_truss_prepare(komb_ctx *ctx)
 int komb_truss_unprepare(komb_ctx *ctx)
 {
     KOMB_TRY(require_device(ctx));
-    truss_free(ctx);                                     // (a result's endpoint arrays are the preparation's)
+    truss_free(ctx);
     prep_free(ctx, &ctx->prep);
     return KOMB_OK;
 }

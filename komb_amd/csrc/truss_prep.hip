@@ -34,8 +34,7 @@ namespace komb {
 
 namespace {
 
-constexpr uint32_t kPrepHeavy = 2048;           // symmetric rows longer than this are walked by a workgroup (k_prep_kept_heavy)
-constexpr int kPrepHB = 1024;
+constexpr uint32_t kPrepHeavy = 2048;           // symmetric rows longer than this are walked in chunks by the whole grid (k_prep_kept_heavy)
 constexpr uint32_t kRowCap = 1024;              // oriented entries a wavefront sorts in LDS at a time; longer rows: k_prep_rows_heavy
 constexpr uint32_t kRowStage = 8192;            // ... which stages up to this many in LDS
 constexpr int kPW = kBlock / kWave;
@@ -66,15 +65,16 @@ __global__ __launch_bounds__(kBlock) void k_prep_vertex(const uint32_t *__restri
 // stream (with the regions where the symmetric CSR has the rows, step 4 spent 1.3 of its 2.6 ms on two random places per row)
 __global__ __launch_bounds__(kBlock) void k_prep_invert(const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ sorted_deg,
                                                         const uint32_t *__restrict__ regbase, int64_t nv, int32_t *__restrict__ i2o, int32_t *__restrict__ o2i,
-                                                        uint32_t *__restrict__ regstart, uint32_t *__restrict__ backcur)
+                                                        uint32_t *__restrict__ regstart, uint32_t *__restrict__ backcur, uint32_t *__restrict__ nlocal)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
         const uint32_t v = sorted_ids[i];
         i2o[i] = (int32_t)v;
         o2i[v] = (int32_t)i;
-        const uint32_t r0 = regbase[i];
+        const uint32_t r0 = regbase[i], d = sorted_deg[i];
         regstart[v] = r0;
-        backcur[v] = r0 + sorted_deg[i] - 1u;                     // the last position of v's region: counted DOWN by the edges v is given
+        backcur[v] = r0 + d - 1u;                                 // the last position of v's region: counted DOWN by the edges v is given
+        if (d > kPrepHeavy) nlocal[v] = 0u;                       // (k_prep_kept_heavy counts the kept edges of a long row UP from here)
     }
 }
 
@@ -158,42 +158,70 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
     }
 }
 
-// the same for the rows beyond kPrepHeavy slots, a workgroup each: they are the tail of the degree order
-__global__ __launch_bounds__(kPrepHB) void k_prep_kept_heavy(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
-                                                             const uint32_t *__restrict__ sorted_deg, const int32_t *__restrict__ i2o,
-                                                             const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
-                                                             const uint32_t *__restrict__ regstart,
-                                                             uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur)
+// the same for the rows beyond kPrepHeavy slots (the tail of the degree order).  Their upper parts are cut into chunks of
+// kHeavyChunk slots, numbered through all heavy rows; wavefront i of the grid takes chunks i, i + W, ...: a hub of 10^5 slots is
+// walked by hundreds of wavefronts (a workgroup per row took 0.64 ms at C3 for its longest row: ~100 trips of gather -> atomic ->
+// store).  An edge the row keeps takes its place in the front part from the row's own counter (nlocal, zeroed by k_prep_invert;
+// one atomic per wavefront and 64 slots) -- step 4 sorts the row anyway.
+constexpr uint32_t kHeavyChunk = 256;
+__global__ __launch_bounds__(kBlock) void k_prep_kept_heavy(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
+                                                            const uint32_t *__restrict__ sorted_deg, const int32_t *__restrict__ i2o,
+                                                            const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
+                                                            const uint32_t *__restrict__ regstart,
+                                                            uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur)
 {
-    __shared__ uint32_t sh_wc[kPrepHB / kWave];
-    const int lane = lane_id(), wv_ = (int)(threadIdx.x >> 6);
-    for (int64_t h = blockIdx.x;; h += gridDim.x) {
-        const int64_t a = nv - 1 - h;
-        if (a < 0) break;
-        const uint32_t deg = sorted_deg[a];
-        if (deg <= kPrepHeavy) break;                              // (uniform: every thread read the same word)
-        const int32_t v = i2o[a];
-        const uint32_t beg = rowptr[v], end = beg + deg, fuv = fu[v], eb = ebase[v], reg = regstart[v];
-        uint32_t run = 0;
-        for (uint32_t j0 = fuv; j0 < end; j0 += kPrepHB) {
-            const uint32_t j = j0 + threadIdx.x;
-            const bool active = j < end;
-            const int32_t wv = active ? col[j] : 0;
-            const uint32_t b = active ? (uint32_t)o2i[wv] : 0u;
-            const bool mine = active && b > (uint32_t)a, theirs = active && b < (uint32_t)a;
-            const uint32_t k = eb + (j - fuv);
-            if (theirs) tmp[atomicSub(&backcur[wv], 1u)] = make_uint2((uint32_t)a, k);
-            const uint64_t K = __ballot(mine);
-            __syncthreads();
-            if (lane == 0) sh_wc[wv_] = (uint32_t)__popcll(K);
-            __syncthreads();
-            uint32_t before = 0, all = 0;
+    const int lane = lane_id();
+    const uint32_t wi = (uint32_t)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6), W = (uint32_t)(((int64_t)gridDim.x * kBlock) >> 6);
+    uint32_t cbase = 0;                                            // chunks of the heavy rows before this block of 64 rows (< ns / kHeavyChunk + nv)
+    for (int64_t h0 = 0; h0 < nv; h0 += kWave) {
+        const int64_t a = nv - 1 - h0 - lane;                      // internal ids from the top: degrees descending
+        const uint32_t deg = a >= 0 ? sorted_deg[a] : 0u;
+        const bool hv = deg > kPrepHeavy;
+        const uint64_t HM = __ballot(hv);                          // (a prefix of the lanes)
+        if (HM == 0) break;
+        int32_t v = 0;
+        uint32_t fuv = 0, eb = 0, reg = 0, end = 0;
+        if (hv) { v = i2o[a]; fuv = fu[v]; eb = ebase[v]; reg = regstart[v]; end = rowptr[v] + deg; }
+        const uint32_t nch = hv ? (end - fuv + kHeavyChunk - 1) / kHeavyChunk : 0u;
+        uint32_t inc = nch;                                        // inclusive scan of the chunk counts over the lanes
 #pragma unroll
-            for (int x = 0; x < kPrepHB / kWave; ++x) { const uint32_t c = sh_wc[x]; if (x < wv_) before += c; all += c; }
-            if (mine) tmp[(size_t)reg + run + before + (uint32_t)__popcll(K & lanemask_lt())] = make_uint2(b, k);
-            run += all;
+        for (int d = 1; d < kWave; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += t; }
+        const int nh = __popcll(HM);
+        for (int t = 0; t < nh; ++t) {
+            const uint32_t r_nch = (uint32_t)__shfl((int)nch, t), r_cb = cbase + (uint32_t)__shfl((int)inc, t) - r_nch;
+            uint32_t c = (wi + W - (r_cb % W)) % W;                // this wavefront's first chunk of the row
+            if (c >= r_nch) continue;
+            const int32_t rv = __shfl(v, t);
+            const uint32_t ra = (uint32_t)(nv - 1 - h0 - t);
+            const uint32_t r_fu = (uint32_t)__shfl((int)fuv, t), r_eb = (uint32_t)__shfl((int)eb, t), r_reg = (uint32_t)__shfl((int)reg, t), r_end = (uint32_t)__shfl((int)end, t);
+            for (; c < r_nch; c += W) {
+                const uint32_t j0 = r_fu + c * kHeavyChunk;
+                constexpr int kU = (int)(kHeavyChunk / kWave);
+                bool on[kU];
+                int32_t wv[kU];
+                uint32_t b[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) { const uint32_t j = j0 + (uint32_t)(u * kWave + lane); on[u] = j < r_end; wv[u] = on[u] ? col[j] : 0; }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) b[u] = on[u] ? (uint32_t)o2i[wv[u]] : 0u;
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const uint32_t k = r_eb + (j0 + (uint32_t)(u * kWave + lane) - r_fu);
+                    const bool mine = on[u] && b[u] > ra, theirs = on[u] && b[u] < ra;
+                    if (theirs) tmp[atomicSub(&backcur[wv[u]], 1u)] = make_uint2(ra, k);
+                    const uint64_t K = __ballot(mine);
+                    if (K) {
+                        const int lead = __ffsll((long long)K) - 1;
+                        uint32_t base = 0;
+                        if (lane == lead) base = atomicAdd(&nlocal[rv], (uint32_t)__popcll(K));
+                        base = (uint32_t)__shfl((int)base, lead);
+                        if (mine) tmp[(size_t)r_reg + base + (uint32_t)__popcll(K & lanemask_lt())] = make_uint2(b[u], k);
+                    }
+                }
+            }
         }
-        if (threadIdx.x == 0) nlocal[v] = run;
+        cbase += (uint32_t)__shfl((int)inc, kWave - 1);
+        if (nh < kWave) break;
     }
 }
 
@@ -575,14 +603,14 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     if (nv > 0) {
         KOMB_TRY(prim_sort_pairs_u32_u32(ctx, d_dk[0], d_dk[1], d_dv[0], d_dv[1], nv, id_bits(nv), &sk, &sv));
         KOMB_TRY(prim_exclusive_sum_u32(ctx, sk, d_regbase, nv));                   // the scratch regions, in internal order (the last one ends at ns)
-        k_prep_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, sk, d_regbase, nv, P.i2o, P.o2i, d_regstart, d_backcur);
+        k_prep_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, sk, d_regbase, nv, P.i2o, P.o2i, d_regstart, d_backcur, d_nlocal);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_uc, d_ebase, nv + 1));
     KOMB_HIP(ctx, hipEventRecord(ev[1], s));
     // 2. every canonical edge to the row of its lower-rank endpoint; the canonical edge list; 3. d+ and the oriented row pointers
     if (nv > 0) {
         k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_regstart, d_tmp, d_nlocal, d_backcur);
-        k_prep_kept_heavy<<<512, kPrepHB, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_regstart, d_tmp, d_nlocal, d_backcur);
+        k_prep_kept_heavy<<<256 * 4, kBlock, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_regstart, d_tmp, d_nlocal, d_backcur);
         k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(rowptr, nv, P.o2i, d_regstart, d_nlocal, d_backcur, d_dplus, d_where, d_acc);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_dplus, P.orow, nv + 1));

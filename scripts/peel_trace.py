@@ -19,6 +19,11 @@ uv = komb_amd.gen_hug_edges(nv, ncl, alpha, seed)
 a = komb_amd.KombAccel(); a.from_edges(nv, uv); del uv
 a.truss_run()                      # warm the pool
 a.core_run()
+a.truss_run()
+st = a.stats()
+print("untraced:", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items() if k in ("ms_peel", "ms_truss_local", "truss_local_items", "truss_local_units", "truss_local_sweeps", "truss_subrounds", "truss_levels", "truss_launches", "truss_scans", "max_trussness", "ms_core", "ms_core_local")}, flush=True)
 os.environ["KOMB_PEEL_TRACE"] = out
 a.truss_run()
 a.core_run()
+st = a.stats()
+print("traced:", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items() if k in ("ms_peel", "ms_truss_local", "truss_local_items", "truss_local_units", "truss_local_sweeps", "truss_subrounds", "truss_levels", "truss_launches", "truss_scans", "max_trussness", "ms_core", "ms_core_local")}, flush=True)

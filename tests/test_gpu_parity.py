@@ -509,8 +509,8 @@ def test_truss_preparation_lifecycle(K, O):
 def test_preparation_long_rows(K, O, monkeypatch):
     """The preparation's workgroup paths (truss_prep.hip): oriented rows beyond one wavefront's 1024-entry sort (K_1500: rows of
     up to 1499 entries, ranked out of LDS by a workgroup -- and, with the staging switched off, out of global memory), symmetric
-    rows beyond 2048 slots (a hub: walked by a workgroup, nearly all of its edges handed to other rows through their back
-    cursors), and the same rows inside an induced subgraph."""
+    rows beyond 2048 slots (a hub: walked in chunks by the whole grid, nearly all of its edges handed to other rows through their
+    back cursors; and long rows that keep their edges), and the same rows inside an induced subgraph."""
     n = 1500
     uv = np.stack(np.triu_indices(n, 1), axis=1).astype(np.int64)
     for stage in (None, "100"):
@@ -538,6 +538,20 @@ def test_preparation_long_rows(K, O, monkeypatch):
         seu, sev, stra = a.run_truss(mask)
         weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
         assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr)
+    # long rows that KEEP their edges: a cycle of 2100 vertices (ids first), each of them joined to each of 2060 others.  Both
+    # sides are beyond 2048 slots and the cycle's vertices have the lower (degree, id) rank, so the 2060 upper slots of each of
+    # them stay in its own row -- placed through the row's counter by many wavefronts at once.  Known answer: a cycle edge is in
+    # 2060 triangles, every other edge in 2 (its two cycle neighbours), and the whole graph is its own 4-truss.
+    nb, na = 2100, 2060
+    bip = np.stack(np.meshgrid(np.arange(nb), nb + np.arange(na), indexing="ij"), axis=-1).reshape(-1, 2)
+    cyc = np.stack([np.arange(nb), (np.arange(nb) + 1) % nb], axis=1)
+    uv = np.concatenate([bip, cyc]).astype(np.int64)
+    with K.KombAccel() as a:
+        a.from_edges(nb + na, uv)
+        eu, ev, tr, sup = a.run_truss(with_support=True)
+        assert len(eu) == nb * na + nb and a.stats()["triangles"] == nb * na
+        assert np.all(eu < ev) and np.all(np.diff(eu * (nb + na) + ev.astype(np.int64)) > 0)
+        assert np.all(tr == 4) and np.array_equal(sup, np.where(ev < nb, na, 2))
 
 
 def test_retire_step_due_at_a_refused_hand_over(K, O, monkeypatch):
