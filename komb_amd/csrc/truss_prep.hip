@@ -62,18 +62,19 @@ __global__ __launch_bounds__(kBlock) void k_prep_vertex(const uint32_t *__restri
 
 // ... and every vertex' REGION of the scratch array step 2 fills: d(v) entries at regbase[rank of v] (the exclusive scan of the
 // sorted degrees), i.e. the regions follow each other in INTERNAL order -- step 4 walks internal vertices and reads them as a
-// stream (with the regions where the symmetric CSR has the rows, step 4 spent 1.3 of its 2.6 ms on two random places per row)
+// stream (with the regions where the symmetric CSR has the rows, step 4 spent 1.3 of its 2.6 ms on two random places per row).
+// Regions and back cursors are addressed by internal id: whoever hands an edge to a vertex has gathered that id anyway, and
+// this kernel scatters one word per vertex (o2i), not three
 __global__ __launch_bounds__(kBlock) void k_prep_invert(const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ sorted_deg,
                                                         const uint32_t *__restrict__ regbase, int64_t nv, int32_t *__restrict__ i2o, int32_t *__restrict__ o2i,
-                                                        uint32_t *__restrict__ regstart, uint32_t *__restrict__ backcur, uint32_t *__restrict__ nlocal)
+                                                        uint32_t *__restrict__ backcur, uint32_t *__restrict__ nlocal)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
         const uint32_t v = sorted_ids[i];
         i2o[i] = (int32_t)v;
         o2i[v] = (int32_t)i;
         const uint32_t r0 = regbase[i], d = sorted_deg[i];
-        regstart[v] = r0;
-        backcur[v] = r0 + d - 1u;                                 // the last position of v's region: counted DOWN by the edges v is given
+        backcur[i] = r0 + d - 1u;                                 // (by INTERNAL id) the last position of the region: counted DOWN by the edges the vertex is given
         if (d > kPrepHeavy) nlocal[v] = 0u;                       // (k_prep_kept_heavy counts the kept edges of a long row UP from here)
     }
 }
@@ -89,11 +90,11 @@ __device__ __forceinline__ int owner_of(const uint32_t *s_end, uint32_t it)
 
 // ---- 2. every canonical edge to the row of its lower-rank endpoint.  A wavefront takes 64 consecutive ORIGINAL vertices; the
 // UPPER parts of their rows (columns above the row: the canonical edges, ids ebase[v] + offset) are flattened over the lanes.
-// Edge (v, w): a = o2i[v], b = o2i[w] (the one gather).  b > a: the oriented edge a -> b is v's: tmp[regstart[v] + r] = (b, k),
-// r = v's running count.  b < a: it is w's: tmp[backcur[w]--] = (a, k).
+// Edge (v, w): a = o2i[v], b = o2i[w] (the one gather).  b > a: the oriented edge a -> b is v's: tmp[regbase[a] + r] = (b, k),
+// r = v's running count.  b < a: it is w's: tmp[backcur[b]--] = (a, k).
 __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                       const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
-                                                      const uint32_t *__restrict__ regstart,
+                                                      const uint32_t *__restrict__ regbase,
                                                       uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur)
 {
     __shared__ uint32_t sh_end[kPW][kWave], sh_beg[kPW][kWave], sh_a[kPW][kWave], sh_rp[kPW][kWave], sh_eb[kPW][kWave], sh_cnt[kPW][kWave];
@@ -111,8 +112,9 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
         __builtin_amdgcn_wave_barrier();
         s_end[lane] = incl;
         s_beg[lane] = up;
-        s_rp[lane] = has ? regstart[v] : 0u;                        // v's region of tmp
-        s_a[lane] = has ? (uint32_t)o2i[v] : 0u;
+        const uint32_t av = has ? (uint32_t)o2i[v] : 0u;
+        s_a[lane] = av;
+        s_rp[lane] = has ? regbase[av] : 0u;                        // v's region of tmp
         s_eb[lane] = has ? ebase[v] : 0u;
         s_cnt[lane] = 0u;
         __builtin_amdgcn_wave_barrier();
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept(const uint32_t *__restrict
                 const uint32_t a = s_a[tt];
                 const uint32_t k = s_eb[tt] + (it - rowstart[u]);   // the canonical id of (v, w)
                 const bool mine = on[u] && b[u] > a, theirs = on[u] && b[u] < a;
-                if (theirs) tmp[atomicSub(&backcur[wv[u]], 1u)] = make_uint2(a, k);
+                if (theirs) tmp[atomicSub(&backcur[b[u]], 1u)] = make_uint2(a, k);
                 const uint64_t K = __ballot(mine);
                 const uint32_t f = rowstart[u] > base ? rowstart[u] - base : 0u;      // the lane where row tt starts in this trip (<= lane)
                 const uint32_t r = s_cnt[tt] + (uint32_t)__popcll(K & lanemask_lt() & ~((1ull << f) - 1ull));
@@ -167,7 +169,7 @@ constexpr uint32_t kHeavyChunk = 256;
 __global__ __launch_bounds__(kBlock) void k_prep_kept_heavy(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t nv,
                                                             const uint32_t *__restrict__ sorted_deg, const int32_t *__restrict__ i2o,
                                                             const int32_t *__restrict__ o2i, const uint32_t *__restrict__ fu, const uint32_t *__restrict__ ebase,
-                                                            const uint32_t *__restrict__ regstart,
+                                                            const uint32_t *__restrict__ regbase,
                                                             uint2 *__restrict__ tmp, uint32_t *__restrict__ nlocal, uint32_t *__restrict__ backcur)
 {
     const int lane = lane_id();
@@ -181,20 +183,21 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept_heavy(const uint32_t *__re
         if (HM == 0) break;
         int32_t v = 0;
         uint32_t fuv = 0, eb = 0, reg = 0, end = 0;
-        if (hv) { v = i2o[a]; fuv = fu[v]; eb = ebase[v]; reg = regstart[v]; end = rowptr[v] + deg; }
+        if (hv) { v = i2o[a]; fuv = fu[v]; eb = ebase[v]; reg = regbase[a]; end = rowptr[v] + deg; }
         const uint32_t nch = hv ? (end - fuv + kHeavyChunk - 1) / kHeavyChunk : 0u;
         uint32_t inc = nch;                                        // inclusive scan of the chunk counts over the lanes
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += t; }
         const int nh = __popcll(HM);
-        for (int t = 0; t < nh; ++t) {
-            const uint32_t r_nch = (uint32_t)__shfl((int)nch, t), r_cb = cbase + (uint32_t)__shfl((int)inc, t) - r_nch;
-            uint32_t c = (wi + W - (r_cb % W)) % W;                // this wavefront's first chunk of the row
-            if (c >= r_nch) continue;
+        const uint32_t tot = (uint32_t)__shfl((int)inc, kWave - 1);
+        // this wavefront's chunks among the tot chunks of these rows: global numbers cbase + rel with (cbase + rel) % W == wi
+        for (uint32_t rel = (wi + W - (cbase % W)) % W; rel < tot; rel += W) {
+            const int t = __popcll(__ballot(inc <= rel));          // the row the chunk is in (inc is non-decreasing over the lanes)
+            const uint32_t c = rel - ((uint32_t)__shfl((int)inc, t) - (uint32_t)__shfl((int)nch, t));
             const int32_t rv = __shfl(v, t);
             const uint32_t ra = (uint32_t)(nv - 1 - h0 - t);
             const uint32_t r_fu = (uint32_t)__shfl((int)fuv, t), r_eb = (uint32_t)__shfl((int)eb, t), r_reg = (uint32_t)__shfl((int)reg, t), r_end = (uint32_t)__shfl((int)end, t);
-            for (; c < r_nch; c += W) {
+            {
                 const uint32_t j0 = r_fu + c * kHeavyChunk;
                 constexpr int kU = (int)(kHeavyChunk / kWave);
                 bool on[kU];
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept_heavy(const uint32_t *__re
                 for (int u = 0; u < kU; ++u) {
                     const uint32_t k = r_eb + (j0 + (uint32_t)(u * kWave + lane) - r_fu);
                     const bool mine = on[u] && b[u] > ra, theirs = on[u] && b[u] < ra;
-                    if (theirs) tmp[atomicSub(&backcur[wv[u]], 1u)] = make_uint2(ra, k);
+                    if (theirs) tmp[atomicSub(&backcur[b[u]], 1u)] = make_uint2(ra, k);
                     const uint64_t K = __ballot(mine);
                     if (K) {
                         const int lead = __ffsll((long long)K) - 1;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept_heavy(const uint32_t *__re
                 }
             }
         }
-        cbase += (uint32_t)__shfl((int)inc, kWave - 1);
+        cbase += tot;
         if (nh < kWave) break;
     }
 }
@@ -228,16 +231,15 @@ __global__ __launch_bounds__(kBlock) void k_prep_kept_heavy(const uint32_t *__re
 // ---- 3. d+(v) = the edges v kept itself + the edges it was given; by internal id, for the scan -- and, also by internal id, where
 // step 4 finds the two parts of the vertex' list: { start of the front part, its length, start of the back part } (one
 // coalesced 16-byte read per row there instead of four gathers through i2o)
-__global__ __launch_bounds__(kBlock) void k_prep_dplus(const uint32_t *__restrict__ rowptr, int64_t nv, const int32_t *__restrict__ o2i,
-                                                       const uint32_t *__restrict__ regstart,
-                                                       const uint32_t *__restrict__ nlocal, const uint32_t *__restrict__ backcur,
+__global__ __launch_bounds__(kBlock) void k_prep_dplus(int64_t nv, const int32_t *__restrict__ i2o, const uint32_t *__restrict__ sorted_deg,
+                                                       const uint32_t *__restrict__ regbase, const uint32_t *__restrict__ backcur,
+                                                       const uint32_t *__restrict__ nlocal,
                                                        uint32_t *__restrict__ dplus_i, uint4 *__restrict__ where_i, unsigned long long *__restrict__ own_bound)
 {
     unsigned long long ob = 0;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock) {
-        const uint32_t nl = nlocal[v], bk = backcur[v] + 1u, reg = regstart[v];
-        const unsigned long long d = nl + (reg + (rowptr[v + 1] - rowptr[v]) - bk);
-        const int32_t a = o2i[v];
+    for (int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x; a < nv; a += (int64_t)gridDim.x * kBlock) {
+        const uint32_t nl = nlocal[i2o[a]], bk = backcur[a] + 1u, reg = regbase[a];       // (the one gather: the kept count is by original id)
+        const unsigned long long d = nl + (reg + sorted_deg[a] - bk);
         dplus_i[a] = (uint32_t)d;
         where_i[a] = make_uint4(reg, nl, bk, 0u);
         ob += d ? d * (d - 1ull) : 0ull;
@@ -570,7 +572,7 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
 
     DevBufs bufs(ctx);
     uint32_t *d_dk[2] = {nullptr, nullptr}, *d_dv[2] = {nullptr, nullptr}, *d_fu = nullptr, *d_uc = nullptr, *d_ebase = nullptr, *d_dplus = nullptr;
-    uint32_t *d_nlocal = nullptr, *d_backcur = nullptr, *d_regbase = nullptr, *d_regstart = nullptr;
+    uint32_t *d_nlocal = nullptr, *d_backcur = nullptr, *d_regbase = nullptr;
     uint4 *d_where = nullptr;
     uint32_t *d_tcnt = nullptr, *d_hlist = nullptr, *d_words = nullptr;
     unsigned long long *d_acc = nullptr;                             // [0] own bound, [1..4] what the host reads back
@@ -581,10 +583,9 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     KOMB_HIP(ctx, bufs.alloc(&d_ebase, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_dplus, (size_t)nv + 1));
     KOMB_HIP(ctx, bufs.alloc(&d_nlocal, (size_t)nv));
-    KOMB_HIP(ctx, bufs.alloc(&d_backcur, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_where, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_regbase, (size_t)nv + 1));
-    KOMB_HIP(ctx, bufs.alloc(&d_regstart, (size_t)nv));
+    KOMB_HIP(ctx, bufs.alloc(&d_backcur, (size_t)nv));
     KOMB_HIP(ctx, bufs.alloc(&d_tcnt, (size_t)nv + 1));
     const uint32_t hcap = (uint32_t)(ne / kRowCap + 64);
     KOMB_HIP(ctx, bufs.alloc(&d_hlist, (size_t)hcap));
@@ -603,15 +604,15 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     if (nv > 0) {
         KOMB_TRY(prim_sort_pairs_u32_u32(ctx, d_dk[0], d_dk[1], d_dv[0], d_dv[1], nv, id_bits(nv), &sk, &sv));
         KOMB_TRY(prim_exclusive_sum_u32(ctx, sk, d_regbase, nv));                   // the scratch regions, in internal order (the last one ends at ns)
-        k_prep_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, sk, d_regbase, nv, P.i2o, P.o2i, d_regstart, d_backcur, d_nlocal);
+        k_prep_invert<<<grid_for(nv), kBlock, 0, s>>>(sv, sk, d_regbase, nv, P.i2o, P.o2i, d_backcur, d_nlocal);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_uc, d_ebase, nv + 1));
     KOMB_HIP(ctx, hipEventRecord(ev[1], s));
     // 2. every canonical edge to the row of its lower-rank endpoint; the canonical edge list; 3. d+ and the oriented row pointers
     if (nv > 0) {
-        k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_regstart, d_tmp, d_nlocal, d_backcur);
-        k_prep_kept_heavy<<<256 * 4, kBlock, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_regstart, d_tmp, d_nlocal, d_backcur);
-        k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(rowptr, nv, P.o2i, d_regstart, d_nlocal, d_backcur, d_dplus, d_where, d_acc);
+        k_prep_kept<<<gwave, kBlock, 0, s>>>(rowptr, col, nv, P.o2i, d_fu, d_ebase, d_regbase, d_tmp, d_nlocal, d_backcur);
+        k_prep_kept_heavy<<<256 * 4, kBlock, 0, s>>>(rowptr, col, nv, sk, P.i2o, P.o2i, d_fu, d_ebase, d_regbase, d_tmp, d_nlocal, d_backcur);
+        k_prep_dplus<<<grid_for(nv), kBlock, 0, s>>>(nv, P.i2o, sk, d_regbase, d_backcur, d_nlocal, d_dplus, d_where, d_acc);
     }
     KOMB_TRY(prim_exclusive_sum_u32(ctx, d_dplus, P.orow, nv + 1));
     KOMB_HIP(ctx, hipEventRecord(ev[2], s));
