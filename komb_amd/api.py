@@ -169,6 +169,11 @@ class KombAccel:
         """komb_graph_moments (measurement only): fills stats sum_deg_sq / wedge_items / max_degree / oriented_items."""
         self._check(self._lib.komb_graph_moments(self._ctx))
 
+    def truss_fetch_into(self, eu=None, ev=None, tr=None):
+        """komb_truss_fetch into caller-owned int32 arrays of komb_truss_count entries; None = not wanted."""
+        self._check(self._lib.komb_truss_fetch(self._ctx, ptr(eu) if eu is not None else None, ptr(ev) if ev is not None else None,
+                                               ptr(tr) if tr is not None else None))
+
     def truss_fetch(self, with_support=False):
         n = ctypes.c_int64()
         self._check(self._lib.komb_truss_count(self._ctx, ctypes.byref(n)))
