@@ -427,10 +427,18 @@ template <typename F>
 int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *launches_out)
 {
     // launch(i) issues the launch with index i; the state says which index it expects (PeelCtrl::seq)
+    // Launches per batch.  What is queued behind the launch that finishes the peel is wasted (a launch that finds nothing to do
+    // is ~5 us, and the host sees `done` one batch late): on average 1.5 batches.  The first batch is long (the giant steps of
+    // the first levels keep the GPU busy while the host queues); the next few are short, because the graphs this path is
+    // measured on hand over to a finish after 35-50 launches (C3: 37 of 72 launches did something with batches of 24; C2
+    // k-core: 41 of 72); a peel that is still running after those has thousands of sub-rounds to go and gets long batches.
 #ifndef KOMB_PEEL_BATCH
 #define KOMB_PEEL_BATCH 24
 #endif
-    constexpr int kBatch = KOMB_PEEL_BATCH;
+#ifndef KOMB_PEEL_BATCH_SHORT
+#define KOMB_PEEL_BATCH_SHORT 6
+#endif
+    constexpr int kBatch = KOMB_PEEL_BATCH, kBatchShort = KOMB_PEEL_BATCH_SHORT, kShortBatches = 6;
     PeelCtrl first;
     KOMB_HIP(ctx, d2h(ctx, &first, d_ctrl, sizeof(PeelCtrl)));
     int32_t next = first.seq;
@@ -470,12 +478,13 @@ int drive_peel(komb_ctx *ctx, PeelCtrl *d_ctrl, int64_t units, F &&launch, int *
     hipEvent_t ev[2] = {nullptr, nullptr};
     KOMB_HIP(ctx, evs.make(&ev[0], hipEventDisableTiming));
     KOMB_HIP(ctx, evs.make(&ev[1], hipEventDisableTiming));
-    const int64_t max_batches = (4 * units + 4096) / kBatch + 16;   // > 2 launches per unit: cannot be reached
+    const int64_t max_batches = (4 * units + 4096) / kBatch + 16 + kShortBatches;   // > 2 launches per unit: cannot be reached
     int launches = 0, slot = 0, status = KOMB_OK;
     bool have_prev = false, finished = false, stuck = false;
     int32_t seen_seq = first.seq - 1;
     for (int64_t batch = 0; batch < max_batches && !finished; ++batch) {
-        for (int i = 0; i < kBatch; ++i) { launch(next); ++next; ++launches; }
+        const int nb = (batch >= 1 && batch <= kShortBatches) ? kBatchShort : kBatch;
+        for (int i = 0; i < nb; ++i) { launch(next); ++next; ++launches; }
         if (hipMemcpyAsync(&ctx->h_ctrl[slot], d_ctrl, sizeof(PeelCtrl), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipEventRecord(ev[slot], ctx->stream) != hipSuccess) { status = KOMB_ERR_DEVICE; break; }
         if (have_prev) {
