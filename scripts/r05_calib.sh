@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 1: calibration + per-step traces of round 4's engines (debug build), the data the round's plan is made from
+# round 5: calibration + per-step traces of round 4's engines (debug build), the data the round's plan is made from
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout -k 10 120 scripts/calib/bin/atomic_rate > gpurun_out/atomic_rate.txt 2>&1 || exit 1
