@@ -65,7 +65,7 @@ def algorithmic_bytes(st):
     survey_peel = 8 * E + 4 * st["sum_deg_sq"] + 16 * T # SURVEY 8(d) B_peel (merge re-intersection; not what we do)
     sort = 2 * 2 * 12 * R                               # the passes that run: two radix passes over 12-byte records, read + write
     finish = 16 * E + 48 * T + 4 * R                    # supports and slice pairs; every entry in once (record or block entry), out once
-    gather = 24 * E                                     # one pass: stamp, slice pair and canonical id in; the initial support (by internal id) and the trussness (at its canonical id) out
+    gather = 12 * E                                     # one pass: stamp and canonical id in; the trussness (at its canonical id) out
     return {"prepare": prepare, "prep_vertex": prep_vertex, "prep_edges": prep_edges, "prep_rows": prep_rows, "tri_count": tri_count, "peel": peel, "survey_peel": survey_peel,
             "sort": sort, "finish": finish, "gather": gather}
 

@@ -238,7 +238,7 @@ struct komb_ctx {
     // ---- k-truss results (canonical order)
     int64_t t_ne = -1;                       // edges of the (sub)graph last run
     int32_t *d_t_eu = nullptr, *d_t_ev = nullptr, *d_t_truss = nullptr, *d_t_sup = nullptr;
-    int32_t *d_t_sup0 = nullptr;             // [t_ne] the supports the peel started from, by INTERNAL edge id: komb_truss_fetch_support puts them in canonical
+    uint2 *d_t_slice = nullptr;              // [t_ne] (start, length) of every internal edge's index slice: the length is the support the peel started from; komb_truss_fetch_support puts them in canonical
     uint32_t t_k_lo = 0, t_k_hi = 0;         // the canonical edges the last run materialised (komb_truss_run_slice: this rank's slice)
     bool t_sup_ready = false;                // order on its first call (d_t_sup; igraph_trussness has no such output, and the timed step does not make it)
     bool t_own_edges = false;                // d_t_eu / d_t_ev are pool blocks of this result (induced subgraph), not the graph's cached list
@@ -412,7 +412,7 @@ void induced_free(komb_ctx *ctx, InducedCsr *g);
 int edge_list(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_t nv, const int32_t *vold, int32_t *eu, int32_t *ev);
 int truss_edges_canonical(komb_ctx *ctx);      // ktruss.hip: d_t_eu / d_t_ev of the last whole-graph run (komb_truss_fetch: on the first request per graph)
 void truss_free(komb_ctx *ctx);
-int truss_support_canonical(komb_ctx *ctx);    // ktruss.hip: d_t_sup from d_t_sup0 (whole-graph runs: on the first komb_truss_fetch_support)
+int truss_support_canonical(komb_ctx *ctx);    // ktruss.hip: d_t_sup from d_t_slice (whole-graph runs: on the first komb_truss_fetch_support)
 void peel_ctrl_pre(hipStream_t s, uint32_t *d_grp_done);
 void peel_collect_ctrl(hipStream_t s, PeelCtrl *d_collect, const PeelCtrl *d_from);
 void peel_ctrl_init(hipStream_t s, PeelCtrl *d_ctrl, uint32_t *d_grp_done, uint32_t units, uint32_t tail_limit = 0);

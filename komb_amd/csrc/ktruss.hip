@@ -280,8 +280,9 @@ void truss_free(komb_ctx *ctx)
     if (ctx->t_own_edges) { ctx->pool.put(ctx->d_t_eu); ctx->pool.put(ctx->d_t_ev); }
     ctx->pool.put(ctx->d_t_truss);
     ctx->pool.put(ctx->d_t_sup);
-    ctx->pool.put(ctx->d_t_sup0);
-    ctx->d_t_eu = ctx->d_t_ev = ctx->d_t_truss = ctx->d_t_sup = ctx->d_t_sup0 = nullptr;
+    ctx->pool.put(ctx->d_t_slice);
+    ctx->d_t_eu = ctx->d_t_ev = ctx->d_t_truss = ctx->d_t_sup = nullptr;
+    ctx->d_t_slice = nullptr;
     ctx->t_sup_ready = false;
     ctx->t_own_edges = false;
     ctx->t_ne = -1; ctx->truss_done = false;
@@ -306,14 +307,14 @@ int truss_edges_canonical(komb_ctx *ctx)
 int truss_support_canonical(komb_ctx *ctx)
 {
     if (ctx->t_sup_ready) return KOMB_OK;
-    if (!ctx->truss_done || !ctx->d_t_sup0 || !ctx->prep.valid || ctx->prep.ne != ctx->t_ne)
+    if (!ctx->truss_done || !ctx->d_t_slice || !ctx->prep.valid || ctx->prep.ne != ctx->t_ne)
         KOMB_FAIL(ctx, KOMB_ERR_STATE, "komb_truss_fetch_support: no k-truss result to take the supports from");
     hipStream_t s = ctx->stream;
     const int64_t m = ctx->t_ne;
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
     if (ctx->t_k_lo) KOMB_HIP(ctx, hipMemsetAsync(ctx->d_t_sup, 0, (size_t)ctx->t_k_lo * sizeof(int32_t), s));
     if (ctx->t_k_hi < (uint32_t)m) KOMB_HIP(ctx, hipMemsetAsync(ctx->d_t_sup + ctx->t_k_hi, 0, ((size_t)m - ctx->t_k_hi) * sizeof(int32_t), s));
-    k_scatter_i32<<<grid_for(m), kBlock, 0, s>>>(ctx->d_t_sup0, ctx->prep.e2k, m, ctx->t_k_lo, ctx->t_k_hi, ctx->d_t_sup);
+    k_scatter_len<<<grid_for(m), kBlock, 0, s>>>(ctx->d_t_slice, ctx->prep.e2k, m, ctx->t_k_lo, ctx->t_k_hi, ctx->d_t_sup);
     KOMB_HIP(ctx, hipStreamSynchronize(s));
     ctx->t_sup_ready = true;
     return KOMB_OK;
@@ -846,9 +847,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     phase.next("truss: canonical gather");
     ctx->timer.start(s);
     // every edge's trussness (from its sub-round stamp, or from the finish) goes where its canonical id says; its initial support
-    // stays by internal id for komb_truss_fetch_support
+    // is the length of its index slice: the slice table stays with the result for komb_truss_fetch_support
     KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_truss, (size_t)m * sizeof(int32_t)));
-    KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup0, (size_t)m * sizeof(int32_t)));
     uint32_t k_lo = 0, k_hi = (uint32_t)m;
     if (!vmask_host) {
         ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;          // (the graph's canonical edge list: made when a fetch asks for endpoints)
@@ -866,12 +866,14 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
         KOMB_TRY(edge_list(ctx, sub.rowptr, sub.col, sub.nv, sub.vold, ctx->d_t_eu, ctx->d_t_ev));
     }
     ctx->t_k_lo = k_lo; ctx->t_k_hi = k_hi;
-    k_truss_results<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, d_off2, tp->e2k, m, k_lo, k_hi, ctx->d_t_truss, ctx->d_t_sup0);
+    k_truss_results<<<grid_for(m), kBlock, 0, s>>>(d_stamp, Q.rlevel, d_truss, tp->e2k, m, k_lo, k_hi, ctx->d_t_truss);
+    ctx->d_t_slice = d_off2;
+    bufs.detach(d_off2);
     ctx->t_sup_ready = false;
     if (vmask_host) {                                                // (the subgraph's preparation goes with this call: its supports are put in order now)
         ctx->t_ne = m;
         KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_t_sup, (size_t)m * sizeof(int32_t)));
-        k_scatter_i32<<<grid_for(m), kBlock, 0, s>>>(ctx->d_t_sup0, tp->e2k, m, 0u, (uint32_t)m, ctx->d_t_sup);
+        k_scatter_len<<<grid_for(m), kBlock, 0, s>>>(ctx->d_t_slice, tp->e2k, m, 0u, (uint32_t)m, ctx->d_t_sup);
         ctx->t_sup_ready = true;
     }
     st.ms_gather = ctx->timer.stop(s);
