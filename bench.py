@@ -54,11 +54,11 @@ def algorithmic_bytes(st):
     """Bytes each phase must move, per step (DESIGN.md 'Algorithmic bytes').
     V = vertices, E = edges, T = triangles, O = sum over oriented edges of d+(a)+d+(b), R = record positions of the stream."""
     V, E, T, O, R = st["nv"], st["ne"], st["triangles"], st["oriented_items"], st["tri_records"]
-    # preparation: the symmetric CSR in once (rowptr + both directions of every edge); out once: oriented targets + sources,
+    # preparation: the symmetric CSR in once (rowptr + both directions of every edge); out once: oriented targets,
     # the canonical map, one 64-byte line and two id maps per vertex
     prep_vertex = 4 * V + 3 * 2 * 8 * V + 8 * V         # row pointers in; three radix passes over (degree, id) pairs, read + write; two id maps out
     prep_edges = (4 * V + 4 * E) + 8 * E                # the upper half of the CSR in; one (id, canonical id) pair per edge out
-    prep_rows = 8 * E + 8 * E + 4 * E + 64 * V          # the pairs in; oriented targets + sources, every slot's canonical id and one 64-byte line per vertex out
+    prep_rows = 8 * E + 4 * E + 4 * E + 64 * V          # the pairs in; oriented targets, every slot's canonical id and one 64-byte line per vertex out
     prepare = prep_vertex + prep_edges + prep_rows
     tri_count = 12 * E + 4 * O + 24 * T                 # SURVEY 8(d) B_sup
     peel = 8 * E + 24 * T + 24 * T + 16 * T             # truss+stamp per edge; slice entries; two stamps per entry; 2 RMW per triangle

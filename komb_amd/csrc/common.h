@@ -201,7 +201,7 @@ struct TrussPrep {
     int64_t nv = 0, ne = 0;
     int32_t  *o2i = nullptr, *i2o = nullptr; // [nv] original -> internal id (rank in (degree, original id) order) and back
     uint32_t *orow = nullptr;                // [nv+1]  oriented CSR, INTERNAL ids, rows ascending (source below target): internal edge id = oriented slot
-    int32_t  *ocol = nullptr, *osrc = nullptr;   // [ne + 8], [ne] target / source of every oriented slot
+    int32_t  *ocol = nullptr, *osrc = nullptr;   // [ne + 8] target of every oriented slot; [ne] its source -- only once prep_sources was asked (LDS tail, moments)
     uint32_t *e2k = nullptr;                 // [ne] canonical edge id of every internal edge (oriented slot)
     uint4    *vline = nullptr;               // [4*nv] one 64-byte line per vertex: start, length, pivots and signature of its oriented row (truss_line.h)
     void     *wtasks = nullptr;              // [n_wtasks] task descriptors of the triangle enumeration (truss_line.h)
@@ -380,7 +380,6 @@ int prim_sort_pairs_desc_i64(komb_ctx *ctx, int64_t *keys, int64_t *keys_tmp, ui
 
 int prim_sort_pairs_u32_u64(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, unsigned long long *vals, unsigned long long *vals_alt,
                             int64_t n, int begin_bit, int end_bit, uint32_t **sorted_keys, unsigned long long **sorted_vals);
-int prim_select_reversed(komb_ctx *ctx, const int32_t *osrc, const int32_t *ocol, int64_t m, uint32_t *out, uint32_t *d_num);
 int prim_sort_pairs_u32_u32(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
                             int64_t n, int end_bit, uint32_t **sorted_keys, uint32_t **sorted_vals);
 int prim_sort_pairs_u64_u32(komb_ctx *ctx, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
@@ -402,6 +401,7 @@ void warm_up(komb_ctx *ctx);                 // graph_build.hip: first kernel la
 int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_t nv, int64_t ns, TrussPrep *out);
 void prep_free(komb_ctx *ctx, TrussPrep *p);
 int prep_ensure(komb_ctx *ctx);              // the resident graph's preparation, built if absent (ctx->prep)
+int prep_sources(komb_ctx *ctx, TrussPrep *p);   // p->osrc, made on first use
 // sum d^2, sum min(d,d), max d, (unused), sum d+ + d+ of the resident graph: the roofline model's inputs (measurement only)
 int graph_moments(komb_ctx *ctx, int64_t out[5]);
 // the subgraph induced by a vertex mask as a symmetric CSR of its own (new ids = ranks among the kept vertices)

@@ -350,7 +350,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     InducedCsr sub;
     TrussPrep sub_prep;
     struct SubGuard { komb_ctx *c; InducedCsr *g; TrussPrep *p; ~SubGuard() { prep_free(c, p); induced_free(c, g); } } sub_guard{ctx, &sub, &sub_prep};
-    const TrussPrep *tp = &ctx->prep;
+    TrussPrep *tp = &ctx->prep;
     if (vmask_host) {
         ctx->timer.start(s);
         KOMB_TRY(induce_csr(ctx, vmask_host, &sub));
@@ -368,7 +368,7 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     const int64_t nv = tp->nv;
     const int64_t m = tp->ne;
     const uint32_t *d_orow = tp->orow;
-    const int32_t *d_ocol = tp->ocol, *d_osrc = tp->osrc;
+    const int32_t *d_ocol = tp->ocol;
     const uint4 *d_line = tp->vline;
     const uint2 *d_wtasks = (const uint2 *)tp->wtasks;
     const int64_t n_wtasks = tp->n_wtasks;
@@ -403,6 +403,8 @@ int truss_run(komb_ctx *ctx, const uint8_t *vmask_host, int rank, int world, kom
     // supports the build finds.
     // how the peel ends (common.h): local fixed point (default), LDS tail (truss_tail.h), or the general engine alone
     const FinishMode fin = finish_mode(ctx, FIN_LOCAL);
+    if (fin == FIN_LDS) KOMB_TRY(prep_sources(ctx, tp));            // (the LDS tail reads every edge's source)
+    const int32_t *d_osrc = tp->osrc;
     uint32_t tail_limit = 0;
     if (fin == FIN_LDS) {
         tail_limit = kTailEdges;

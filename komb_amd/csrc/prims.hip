@@ -114,25 +114,6 @@ int prim_sort_pairs_u32_u64(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, u
     return KOMB_OK;
 }
 
-// ordered list of the oriented slots whose source id is above their target id (the edges whose canonical copy sits in
-// the OTHER endpoint's row): a stable stream compaction over the slot indices.  d_num: one device word of scratch.
-struct ReversedSlot {
-    const int32_t *src, *col;
-    __host__ __device__ bool operator()(uint32_t o) const { return src[o] > col[o]; }
-};
-int prim_select_reversed(komb_ctx *ctx, const int32_t *osrc, const int32_t *ocol, int64_t m, uint32_t *out, uint32_t *d_num)
-{
-    if (m > INT32_MAX) KOMB_FAIL(ctx, KOMB_ERR_LIMIT, "select: %lld items exceed the 2^31-1 primitive limit", (long long)m);
-    if (m == 0) return KOMB_OK;
-    hipcub::CountingInputIterator<uint32_t> idx(0u);
-    size_t bytes = 0;
-    KOMB_HIP(ctx, hipcub::DeviceSelect::If(nullptr, bytes, idx, out, d_num, (int)m, ReversedSlot{osrc, ocol}, ctx->stream));
-    TempBuf t(ctx);
-    KOMB_HIP(ctx, t.get(bytes));
-    KOMB_HIP(ctx, hipcub::DeviceSelect::If(t.p, bytes, idx, out, d_num, (int)m, ReversedSlot{osrc, ocol}, ctx->stream));
-    return KOMB_OK;
-}
-
 // stable sort of (32-bit key, 32-bit value) pairs by the key bits [0, end_bit).  Asynchronous on the context's stream.
 int prim_sort_pairs_u32_u32(komb_ctx *ctx, uint32_t *keys, uint32_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
                             int64_t n, int end_bit, uint32_t **sorted_keys, uint32_t **sorted_vals)

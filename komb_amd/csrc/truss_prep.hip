@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_dplus(int64_t nv, const int32_t
 // front of the vertex' region, the rest behind its back cursor) are read into LDS in batches of <= kRowCap entries (whole
 // rows), every entry is ranked among its row's by counting, and leaves as the row's rank-th slot.
 __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict__ orow, int64_t nv, const uint4 *__restrict__ where_i,
-                                                      const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
+                                                      const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol,
                                                       uint32_t *__restrict__ e2k, uint4 *__restrict__ line)
 {
     __shared__ int32_t sh_b[kPW][kRowCap];
@@ -306,7 +306,6 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
                 for (uint32_t x = first; x < last; ++x) rank += s_b[x] < mine ? 1u : 0u;
                 const uint32_t e = s_ob[t] + rank;
                 ocol[e] = mine;
-                osrc[e] = (int32_t)(a0 + t);
                 e2k[e] = s_kk[k];
                 uint32_t blk; unsigned long long mask;
                 sig_slot(mine, blk, mask);
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows(const uint32_t *__restrict
 // global memory beyond (quadratic in a row that long: a graph with such rows is far beyond the index's triangle limit)
 __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__restrict__ hlist, const uint32_t *__restrict__ hcount,
                                                             const uint32_t *__restrict__ orow, const uint4 *__restrict__ where_i,
-                                                            const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol, int32_t *__restrict__ osrc,
+                                                            const uint2 *__restrict__ tmp, int32_t *__restrict__ ocol,
                                                             uint32_t *__restrict__ e2k, uint4 *__restrict__ line, uint32_t stage_cap)
 {
     // stage_cap: rows up to this many entries are ranked out of LDS (kRowStage; less only in tests: option PREP_ROW_STAGE)
@@ -363,7 +362,6 @@ __global__ __launch_bounds__(kBlock) void k_prep_rows_heavy(const uint32_t *__re
             else for (uint32_t x = 0; x < d; ++x) rank += (int32_t)entry(x).x < mine ? 1u : 0u;
             const uint32_t e = ob + rank;
             ocol[e] = mine;
-            osrc[e] = (int32_t)a;
             e2k[e] = ent.y;
             uint32_t blk; unsigned long long mask;
             sig_slot(mine, blk, mask);
@@ -539,7 +537,7 @@ template <class T> hipError_t pool_get(komb_ctx *ctx, T **out, size_t count)
 
 void prep_free(komb_ctx *ctx, TrussPrep *p)
 {
-    void *all[] = {p->o2i, p->i2o, p->orow, p->ocol, p->osrc, p->e2k, p->vline, p->wtasks};
+    void *all[] = {p->o2i, p->i2o, p->orow, p->ocol, p->osrc, p->e2k, p->vline, p->wtasks};   // (osrc: only when prep_sources made it)
     for (void *q : all) ctx->pool.put(q);
     *p = TrussPrep{};
 }
@@ -561,7 +559,6 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     KOMB_HIP(ctx, pool_get(ctx, &P.i2o, (size_t)nv));
     KOMB_HIP(ctx, pool_get(ctx, &P.orow, (size_t)nv + 1));
     KOMB_HIP(ctx, pool_get(ctx, &P.ocol, (size_t)ne + 8));           // + 8: the enumeration and line_find read 16 bytes at a time, past the end of the last row
-    KOMB_HIP(ctx, pool_get(ctx, &P.osrc, (size_t)ne));
     KOMB_HIP(ctx, pool_get(ctx, &P.e2k, (size_t)ne));
     KOMB_HIP(ctx, pool_get(ctx, &P.vline, 4 * (size_t)nv));
     // the task table's size is known on the device only: room for the most it can be (a start per vertex, a row of d slots in
@@ -621,10 +618,10 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     k_task_count<<<gv, kBlock, 0, s>>>(P.orow, nv, group, d_tcnt, d_hlist, d_words, hcap);
     // 4. oriented rows, lines, the canonical map
     if (nv > 0) {
-        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, d_where, d_tmp, P.ocol, P.osrc, P.e2k, P.vline);
+        k_prep_rows<<<gwave, kBlock, 0, s>>>(P.orow, nv, d_where, d_tmp, P.ocol, P.e2k, P.vline);
         uint32_t stage_cap = kRowStage;
         if (const char *e = ctx_opt(ctx, "PREP_ROW_STAGE")) stage_cap = std::min<uint32_t>(kRowStage, (uint32_t)strtoul(e, nullptr, 10));   // (tests: the unstaged path)
-        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, d_where, d_tmp, P.ocol, P.osrc, P.e2k, P.vline, stage_cap);
+        k_prep_rows_heavy<<<1024, kBlock, 0, s>>>(d_hlist, d_words, P.orow, d_where, d_tmp, P.ocol, P.e2k, P.vline, stage_cap);
     }
     KOMB_HIP(ctx, hipEventRecord(ev[3], s));
     // 5b. tasks
@@ -650,6 +647,27 @@ int prep_build(komb_ctx *ctx, const uint32_t *rowptr, const int32_t *col, int64_
     return KOMB_OK;
 }
 
+// osrc[e] = the source of oriented slot e: read by the LDS tail (option FINISH=lds) and by the moments kernel only, so it is
+// made when one of them asks (it used to be one more 4-byte stream out of k_prep_rows in every preparation)
+namespace {
+__global__ __launch_bounds__(kBlock) void k_prep_sources(const uint32_t *__restrict__ orow, int64_t nv, int32_t *__restrict__ osrc)
+{
+    const int lane = lane_id();
+    const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t a = gw; a < nv; a += nw)
+        for (uint32_t e = orow[a] + (uint32_t)lane, e1 = orow[a + 1]; e < e1; e += kWave) osrc[e] = (int32_t)a;
+}
+} // namespace
+
+int prep_sources(komb_ctx *ctx, TrussPrep *p)
+{
+    if (p->osrc || !p->valid) return KOMB_OK;
+    KOMB_HIP(ctx, ctx->pool.get((void **)&p->osrc, (size_t)(p->ne ? p->ne : 1) * sizeof(int32_t)));
+    if (p->nv > 0) k_prep_sources<<<grid_for(p->nv, kPW, 256 * 8), kBlock, 0, ctx->stream>>>(p->orow, p->nv, p->osrc);
+    KOMB_HIP(ctx, hipGetLastError());
+    return KOMB_OK;
+}
+
 int prep_ensure(komb_ctx *ctx)
 {
     if (ctx->prep.valid) return KOMB_OK;
@@ -659,6 +677,7 @@ int prep_ensure(komb_ctx *ctx)
 int graph_moments(komb_ctx *ctx, int64_t out[5])
 {
     KOMB_TRY(prep_ensure(ctx));
+    KOMB_TRY(prep_sources(ctx, &ctx->prep));
     const TrussPrep &P = ctx->prep;
     unsigned long long *d_mom = nullptr, h[5] = {0, 0, 0, 0, 0};
     DevBufs bufs(ctx);
