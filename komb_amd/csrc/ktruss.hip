@@ -294,10 +294,16 @@ int truss_edges_canonical(komb_ctx *ctx)
 {
     if (ctx->t_own_edges || ctx->t_ne <= 0) return KOMB_OK;         // an induced subgraph's result carries its own list
     if (!ctx->d_ceu) {
-        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_ceu, (size_t)ctx->ne * sizeof(int32_t)));
-        KOMB_HIP(ctx, ctx->pool.get((void **)&ctx->d_cev, (size_t)ctx->ne * sizeof(int32_t)));
-        const int rc = edge_list(ctx, ctx->d_o_rowptr, ctx->d_o_col, ctx->nv, nullptr, ctx->d_ceu, ctx->d_cev);
-        if (rc != KOMB_OK) { ctx->pool.put(ctx->d_ceu); ctx->pool.put(ctx->d_cev); ctx->d_ceu = ctx->d_cev = nullptr; return rc; }
+        int32_t *eu = nullptr, *ev = nullptr;                       // (published only when both exist and are filled)
+        hipError_t e = ctx->pool.get((void **)&eu, (size_t)ctx->ne * sizeof(int32_t));
+        if (e == hipSuccess) e = ctx->pool.get((void **)&ev, (size_t)ctx->ne * sizeof(int32_t));
+        const int rc = e == hipSuccess ? edge_list(ctx, ctx->d_o_rowptr, ctx->d_o_col, ctx->nv, nullptr, eu, ev) : KOMB_ERR_NOMEM;
+        if (rc != KOMB_OK) {
+            ctx->pool.put(eu); ctx->pool.put(ev);
+            if (e != hipSuccess) KOMB_FAIL(ctx, KOMB_ERR_NOMEM, "komb_truss_fetch: no memory for the canonical edge list (%s)", hipGetErrorString(e));
+            return rc;
+        }
+        ctx->d_ceu = eu; ctx->d_cev = ev;
     }
     ctx->d_t_eu = ctx->d_ceu; ctx->d_t_ev = ctx->d_cev;
     return KOMB_OK;
