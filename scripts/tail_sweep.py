@@ -16,10 +16,10 @@ with komb_amd.KombAccel() as a:
     a.from_edges(nv, uv); del uv
     a.truss_run()
     for setting in SETTINGS:
-        kv = dict(x.split("=") for x in setting.split(",") if x)
+        kv = dict(x.split("=") for x in setting.split(",") if "=" in x)
         for k, v in kv.items(): a.set_option(k, v)
         best = None
-        for _ in range(2):
+        for _ in range(3):
             a.truss_run()
             st = a.stats()
             if best is None or st["ms_peel"] < best["ms_peel"]: best = st
