@@ -506,6 +506,54 @@ def test_truss_preparation_lifecycle(K, O):
             a.truss_run()
 
 
+def test_results_made_on_demand(K, O, monkeypatch):
+    """What the timed call does not make: the canonical edge LIST (igraph_edge's answer, reference src/graph.cpp:529-532) comes
+    with the first komb_truss_fetch that asks for endpoints and stays with the graph; the supports in canonical order come with
+    the first komb_truss_fetch_support after a run (from the slice table the result keeps); the oriented slots' sources are made
+    when the LDS tail (FINISH=lds) asks.  Any fetch order, any of the outputs left out, runs in between, a vmask run in
+    between (its result carries its own list), a new graph afterwards."""
+    nv = 30000
+    uv = np.asarray(K.gen_hug_edges(nv, 90000, 2.3, 17)).reshape(-1, 2)
+    o_rowptr, o_col = O.simplify(nv, uv)
+    rows = np.repeat(np.arange(nv), np.diff(o_rowptr))
+    up = o_col > rows
+    ceu, cev = rows[up].astype(np.int32), o_col[up].astype(np.int32)
+    otr, osup = O.trussness(o_rowptr, o_col), O.support(o_rowptr, o_col)[0]
+    m = len(ceu)
+    with K.KombAccel() as a:
+        a.from_edges(nv, uv)
+        a.truss_run()
+        tr = np.full(m, -1, np.int32)
+        a.truss_fetch_into(None, None, tr)                                  # trussness alone: no edge list yet
+        assert np.array_equal(tr, otr)
+        ev = np.full(m, -1, np.int32)
+        a.truss_fetch_into(None, ev, None)                                  # one endpoint array alone
+        assert np.array_equal(ev, cev)
+        eu2, ev2, tr2, sup2 = a.truss_fetch(with_support=True)
+        assert np.array_equal(eu2, ceu) and np.array_equal(ev2, cev) and np.array_equal(tr2, otr) and np.array_equal(sup2, osup)
+        a.truss_run()                                                       # a new result: the list stays, the supports are made again
+        eu3, ev3, tr3, sup3 = a.truss_fetch(with_support=True)
+        assert np.array_equal(eu3, ceu) and np.array_equal(ev3, cev) and np.array_equal(tr3, otr) and np.array_equal(sup3, osup)
+        mask = np.zeros(nv, np.uint8); mask[::2] = 1
+        seu, sev, stra, ssup = a.run_truss(mask, with_support=True)
+        weu, wev, wtr = O.trussness_induced(o_rowptr, o_col, mask)
+        assert np.array_equal(seu, weu) and np.array_equal(sev, wev) and np.array_equal(stra, wtr) and np.all(ssup + 2 >= stra)
+        eu4, ev4, tr4 = a.run_truss()
+        assert np.array_equal(eu4, ceu) and np.array_equal(ev4, cev) and np.array_equal(tr4, otr)
+        a.truss_unprepare()                                                 # the preparation goes, the list is the graph's
+        a.set_option("FINISH", "lds"); a.set_option("TAIL", "3000")          # the LDS tail reads the slots' sources: made for it
+        eu5, ev5, tr5, sup5 = a.run_truss(with_support=True)
+        assert np.array_equal(eu5, ceu) and np.array_equal(tr5, otr) and np.array_equal(sup5, osup) and a.stats()["truss_tail_runs"] >= 1
+        seu, sev, stra = a.run_truss(mask)                                  # ... and for an induced subgraph's temporary preparation
+        assert np.array_equal(seu, weu) and np.array_equal(stra, wtr)
+        a.set_option("FINISH", None); a.set_option("TAIL", None)
+        # a new graph in the same context: nothing of the old one's list survives
+        uvb = np.stack([np.arange(0, 99), np.arange(1, 100)], axis=1).astype(np.int64)
+        a.from_edges(100, uvb)
+        eu6, ev6, tr6, sup6 = a.run_truss(with_support=True)
+        assert np.array_equal(eu6, np.arange(99)) and np.array_equal(ev6, np.arange(1, 100)) and np.all(tr6 == 2) and np.all(sup6 == 0)
+
+
 def test_preparation_long_rows(K, O, monkeypatch):
     """The preparation's workgroup paths (truss_prep.hip): oriented rows beyond one wavefront's 1024-entry sort (K_1500: rows of
     up to 1499 entries, ranked out of LDS by a workgroup -- and, with the staging switched off, out of global memory), symmetric
